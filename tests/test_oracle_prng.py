@@ -1,0 +1,53 @@
+"""Pins the oracle's PRNG: Random123 KATs for the block function, jax-documented split values."""
+import numpy as np
+
+from oracle import prng
+
+
+def _tf(k, c):
+    y0, y1 = prng.threefry2x32(k, np.array([c[0]], dtype=np.uint32), np.array([c[1]], dtype=np.uint32))
+    return int(y0[0]), int(y1[0])
+
+
+def test_threefry_random123_kat():
+    # Random123 kat_vectors, threefry2x32 20 rounds (also used by jax's own test-suite)
+    assert _tf((0, 0), (0, 0)) == (0x6B200159, 0x99BA4EFE)
+    assert _tf((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF)) == (0x1CB996FC, 0xBB002BE7)
+    assert _tf((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3)) == (0xC4923A9C, 0x483DF7A0)
+
+
+def test_split_matches_jax_documentation_values():
+    # values printed in the jax documentation for random.split(PRNGKey(0)) / PRNGKey(42)
+    np.testing.assert_array_equal(prng.split(prng.PRNGKey(0), 2),
+                                  [[4146024105, 967050713], [2718843009, 1272950319]])
+    np.testing.assert_array_equal(prng.split(prng.PRNGKey(42), 2),
+                                  [[2465931498, 3679230171], [255383827, 267815257]])
+
+
+def test_row_helpers_equal_per_key_calls():
+    keys = prng.split(prng.PRNGKey(7), 5)
+    nr = prng.normal_rows(keys, 6)
+    ur = prng.uniform_rows(keys, 6)
+    us = prng.uniform_rows(keys)
+    sr = prng.split_rows(keys, 4)
+    for i, k in enumerate(keys):
+        np.testing.assert_array_equal(nr[i], prng.normal(k, (6,)))
+        np.testing.assert_array_equal(ur[i], prng.uniform(k, (6,)))
+        assert us[i] == prng.uniform(k, ())
+        np.testing.assert_array_equal(sr[i], prng.split(k, 4))
+    np.testing.assert_array_equal(prng.split_at(prng.PRNGKey(3), 9, [0, 4, 8]), prng.split(prng.PRNGKey(3), 9)[[0, 4, 8]])
+    np.testing.assert_array_equal(prng.split_at(prng.PRNGKey(3), 8, np.arange(8)), prng.split(prng.PRNGKey(3), 8))
+
+
+def test_sharded_draws_equal_full_draw():
+    k = prng.PRNGKey(11)
+    full = prng.normal(k, (10, 3))
+    part = prng.normal(k, (10, 3), start=4 * 3, count=5 * 3).reshape(5, 3)
+    np.testing.assert_array_equal(full[4:9], part)
+
+
+def test_normal_moments_and_range():
+    x = prng.normal(prng.PRNGKey(5), (200000,))
+    assert abs(x.mean()) < 0.01 and abs(x.std() - 1) < 0.01
+    u = prng.uniform(prng.PRNGKey(5), (200000,))
+    assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.005
