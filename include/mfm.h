@@ -1,0 +1,135 @@
+/* libmfm_hip -- C ABI of the MI355X-native Markovian Flow Matching inner loop.
+ *
+ * This is the drop-in boundary for the hot path of albcab/mfm (reference paths relative to /root/reference):
+ * every entry point replaces one jit-compiled XLA executable (or a piece of one) that the reference's `run()` loop
+ * (exe_flow_matching.py:432-449) calls.  The reference has no FFI of its own (it is pure Python on JAX); the
+ * binding a maintainer adds is the ctypes layer in mfm_amd/_lib.py.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns 0 on success and a negative
+ *    MFM_E* code on failure; mfm_last_error() gives the message.  No exceptions or aborts cross the boundary.
+ *  - Pointers named d_* are DEVICE pointers owned by the caller (e.g. torch.Tensor.data_ptr()); h_* are host
+ *    pointers.  Chain state is row-major [n_chain_local, dim] float32; log-densities are float64 [n_chain_local].
+ *  - The context owns the network parameters (canonical flat float32 vector + MFMA-packed copies), the AdamW
+ *    state, all workspaces and remembers the HIP stream work is queued on.  Calls are asynchronous on that stream;
+ *    mfm_sync() or any h_* output synchronises.  One context per GPU per process; not thread-safe.
+ *  - PRNG keys are jax-style uint32[2] passed by value as two words; draws are indexed by GLOBAL chain id
+ *    (chain_offset + local row) out of n_chain_total, so results do not depend on how chains are sharded.
+ *
+ * Canonical flat parameter layout (mfm_set_params / mfm_get_params / gradients): for Dense_0 .. Dense_7 in flax
+ * creation order (exe_flow_matching.py:74-86): kernel [in][out] row-major, then bias [out].
+ */
+#ifndef MFM_H
+#define MFM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mfm_ctx mfm_ctx;
+
+enum { MFM_OK = 0, MFM_EINVAL = -1, MFM_EUNSUPPORTED = -2, MFM_ETOOLARGE = -3, MFM_EHIP = -4, MFM_ENOTARGET = -5 };
+
+enum { MFM_PHI4 = 0, MFM_GMM = 1, MFM_LGCP = 2 };                 /* distributions.py:114,42,231 */
+enum { MFM_FLOW_RWMH = 0, MFM_FLOW_IMH = 1 };                      /* exe_flow_matching.py:264-278 / :246-260 */
+
+typedef struct mfm_config {
+  int32_t dim;                 /* args.dim */
+  int32_t fourier_dim;         /* args.fourier_dim  (multi_modal.py:156) */
+  int32_t hidden_t[2];         /* args.hidden_t     (:179)  multiples of 16 */
+  int32_t hidden_x[2];         /* args.hidden_x     (:178) */
+  int32_t hidden_xt[2];        /* args.hidden_xt    (:180) */
+  int32_t n_chain_local;       /* chains resident on this GPU (multiple of 16) */
+  int32_t n_chain_total;       /* args.num_chain over all GPUs */
+  int32_t chain_offset;        /* global id of local chain 0 */
+  float grad_clip;             /* args.gradient_clip if dim > 128 else 0   (exe_flow_matching.py:351) */
+  float sigma;                 /* args.sigma        (:155) */
+  int32_t cond_flow;           /* args.cond_flow    (:162-163) */
+  int32_t hutch;               /* args.hutchs       (:158) */
+  double rtol, atol;           /* args.rtol / atol  (:207-208) */
+  int32_t mxstep;              /* args.mxstep       (:209) */
+  int32_t n_ts;                /* 5 for "4-mode", else 2 (exe_flow_matching.py:347) */
+  /* optimizer (multi_modal.py:199-205) */
+  double learning_rate, adam_b1, adam_b2, adam_eps, weight_decay, update_clip;
+  int32_t learning_iter, warmup_steps;
+  int32_t max_eval_samples;    /* largest n passed to mfm_fm_loss / mfm_vf_apply (0: n_chain_local) */
+} mfm_config;
+
+const char* mfm_last_error(void);
+int mfm_version(void);
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------ */
+int mfm_create(const mfm_config* cfg, mfm_ctx** out);
+int mfm_destroy(mfm_ctx* ctx);
+int mfm_set_stream(mfm_ctx* ctx, void* hip_stream);            /* hipStream_t; NULL = default stream */
+int mfm_sync(mfm_ctx* ctx);
+int mfm_num_params(const mfm_ctx* ctx);                        /* P_w + P_b */
+
+/* ---- target (distributions.py) ---------------------------------------------------------------------------------
+ * MFM_PHI4: h_params = {a, beta}                                    (PhiFour.__init__, :115-129)
+ * MFM_GMM : h_params = {n_modes, modes[K*d], stds[K*d], weights[K]} (GaussianMixture, :43-56; stds = sqrt(covs))
+ * MFM_LGCP: h_params = {mu, poisson_a, log_norm, counts[d], Kinv[d*d]}  (LogGaussianCoxPines, :233-281) */
+int mfm_set_target(mfm_ctx* ctx, int kind, const double* h_params, size_t n);
+
+/* ---- network parameters (VectorFieldNet, exe_flow_matching.py:56-90,350-353) --------------------------------- */
+int mfm_set_fourier(mfm_ctx* ctx, const float* h_fourier_random);              /* [fourier_dim] */
+int mfm_set_params(mfm_ctx* ctx, const float* h_flat);                          /* canonical flat layout */
+int mfm_get_params(mfm_ctx* ctx, float* h_flat);
+int mfm_reset_optimizer(mfm_ctx* ctx);
+
+/* ---- K1/K2: MALA kernel API (bblackjax/mcmc/mala.py) ------------------------------------------------------------ */
+/* init (mala.py:51-54) vmapped as init_fn (exe_flow_matching.py:316): logdensity and gradient of the tempered target
+ * beta * loglik + logprior at d_pos. */
+int mfm_mala_init(mfm_ctx* ctx, const float* d_pos, double beta, double* d_logp, float* d_grad);
+/* kernel (mala.py:86-118) vmapped with per-chain keys split(key, n_chain_total) (exe_flow_matching.py:303,313).
+ * State is updated in place; the MALAInfo outputs may be NULL. */
+int mfm_mala_step(mfm_ctx* ctx, uint32_t key0, uint32_t key1, double beta, double step_size, int textbook,
+                  float* d_pos, double* d_logp, float* d_grad,
+                  float* d_acceptance_rate, uint8_t* d_is_accepted, float* d_proposed_position,
+                  float* d_proposed_weight);
+/* vmap(dist.loglik) (exe_flow_matching.py:418) */
+int mfm_loglik(mfm_ctx* ctx, const float* d_pos, double* d_out);
+
+/* ---- K3/K4/K9: flow-matching loss and gradient (exe_flow_matching.py:151-178,362-365) ------------------------------ */
+/* loss and parameter gradient on the local chains; d_grads [num_params] (canonical layout) and d_loss [1] are caller
+ * owned so a multi-GPU host can all-reduce them (SUM) before mfm_adamw_step. */
+int mfm_fm_loss_grad(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const float* d_pos, double* d_loss, float* d_grads);
+/* loss only on n samples (eval_step, :370-374); n multiple of 16, draws indexed out of n_total starting at offset */
+int mfm_fm_loss(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const float* d_samples, int n, int n_total, int offset,
+                double* d_loss);
+
+/* ---- K7: optimizer step (exe_flow_matching.py:129-137,184,366) ------------------------------------------------ */
+int mfm_adamw_step(mfm_ctx* ctx, const float* d_grads);
+/* host copies of {step, count, notfinite_count, last_applied} and the learning rate logged at :367 */
+int mfm_opt_state(mfm_ctx* ctx, int32_t h_out[4], float* h_last_lr);
+
+/* ---- K5/K6: CNF transforms and flow-MH step (exe_flow_matching.py:206-242,246-278) ------------------------------ */
+/* v(x, t) and optionally the x-JVP (d_tangent, d_jvp may be NULL); n multiple of 16 */
+int mfm_vf_apply(mfm_ctx* ctx, const float* d_x, const float* d_t, const float* d_tangent, int n,
+                 float* d_v, float* d_jvp);
+/* direction +1: transform_and_logdet (:206-221); -1: inverse_and_logdet (:223-242).  Hutchinson keys: per_chain_keys
+ * != 0 -> d_keys is uint32[n][2] (one key per sample, flow-MH steps); else key0/key1 is ONE key shared by all samples
+ * (final sampling, :455).  d_nsteps (may be NULL) receives the attempted Dopri5 steps per sample. */
+int mfm_ode_transform(mfm_ctx* ctx, int direction, int per_chain_keys, const uint32_t* d_keys, uint32_t key0,
+                      uint32_t key1, const float* d_in, int n, float* d_out, float* d_ldj, int32_t* d_nsteps);
+/* one flow-based MH step for every local chain with keys split(key, n_chain_total) (:303,312); state in place */
+int mfm_flow_step(mfm_ctx* ctx, int mode, uint32_t key0, uint32_t key1, double beta,
+                  float* d_pos, double* d_logp, float* d_grad,
+                  float* d_acceptance_rate, uint8_t* d_is_accepted, float* d_proposed_position, int32_t* d_nsteps);
+
+/* ---- K8: annealing (exe_flow_matching.py:391-417) ------------------------------------------------------------- */
+/* Bisection for the next beta on n (global) log-likelihoods; h_beta_out gets the new beta (synchronises). */
+int mfm_beta_update(mfm_ctx* ctx, double prev_beta, const double* d_logliks, int n, double alpha, double* h_beta_out);
+
+/* ---- test helpers (host only, no GPU needed) ------------------------------------------------------------------- */
+int mfm_pack_index(int k, int n, int KB);       /* float index of W[k][n] inside a packed layer */
+int mfm_pack_index_T(int k, int n, int NB);
+int mfm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFM_H */

@@ -1,0 +1,205 @@
+"""ctypes binding of libmfm_hip (include/mfm.h) -- the reference-side stub a maintainer adds.
+
+Every device buffer is a ``torch.Tensor`` on the GPU; only its ``data_ptr()`` crosses the boundary.  The library
+fails loudly: a missing ``.so`` raises at load, a missing GPU raises at ``Context`` creation, and every non-zero
+status code becomes ``MfmError`` carrying ``mfm_last_error()``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB
+
+PHI4, GMM, LGCP = 0, 1, 2
+FLOW_RWMH, FLOW_IMH = 0, 1
+
+
+class MfmError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("fourier_dim", C.c_int32),
+        ("hidden_t", C.c_int32 * 2), ("hidden_x", C.c_int32 * 2), ("hidden_xt", C.c_int32 * 2),
+        ("n_chain_local", C.c_int32), ("n_chain_total", C.c_int32), ("chain_offset", C.c_int32),
+        ("grad_clip", C.c_float), ("sigma", C.c_float), ("cond_flow", C.c_int32), ("hutch", C.c_int32),
+        ("rtol", C.c_double), ("atol", C.c_double), ("mxstep", C.c_int32), ("n_ts", C.c_int32),
+        ("learning_rate", C.c_double), ("adam_b1", C.c_double), ("adam_b2", C.c_double), ("adam_eps", C.c_double),
+        ("weight_decay", C.c_double), ("update_clip", C.c_double),
+        ("learning_iter", C.c_int32), ("warmup_steps", C.c_int32), ("max_eval_samples", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_U32 = C.c_uint32
+_SIGS = {
+    "mfm_last_error": (C.c_char_p, []),
+    "mfm_version": (C.c_int, []),
+    "mfm_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "mfm_destroy": (C.c_int, [_P]),
+    "mfm_set_stream": (C.c_int, [_P, _P]),
+    "mfm_sync": (C.c_int, [_P]),
+    "mfm_num_params": (C.c_int, [_P]),
+    "mfm_set_target": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.c_size_t]),
+    "mfm_set_fourier": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "mfm_set_params": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "mfm_get_params": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "mfm_reset_optimizer": (C.c_int, [_P]),
+    "mfm_mala_init": (C.c_int, [_P, _P, C.c_double, _P, _P]),
+    "mfm_mala_step": (C.c_int, [_P, _U32, _U32, C.c_double, C.c_double, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "mfm_loglik": (C.c_int, [_P, _P, _P]),
+    "mfm_fm_loss_grad": (C.c_int, [_P, _U32, _U32, _P, _P, _P]),
+    "mfm_fm_loss": (C.c_int, [_P, _U32, _U32, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "mfm_adamw_step": (C.c_int, [_P, _P]),
+    "mfm_opt_state": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
+    "mfm_vf_apply": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
+    "mfm_ode_transform": (C.c_int, [_P, C.c_int, C.c_int, _P, _U32, _U32, _P, C.c_int, _P, _P, _P]),
+    "mfm_flow_step": (C.c_int, [_P, C.c_int, _U32, _U32, C.c_double, _P, _P, _P, _P, _P, _P, _P]),
+    "mfm_beta_update": (C.c_int, [_P, C.c_double, _P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    "mfm_pack_index": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "mfm_pack_index_T": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "mfm_threefry2x32": (C.c_int, [_U32, _U32, _U32, _U32, C.POINTER(_U32)]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Load libmfm_hip.so (raises if it has not been built: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise MfmError(f"{LIB} not found: build it with `python -m mfm_amd.build` (hipcc, gfx950)")
+        lib = C.CDLL(LIB)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise MfmError(f"libmfm_hip error {rc}: {load().mfm_last_error().decode()}")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context:
+    """Owner of one ``mfm_ctx`` (one GPU, one process)."""
+
+    def __init__(self, **kw):
+        import torch
+        self.lib = load()
+        if not torch.cuda.is_available():
+            raise MfmError("no GPU visible: the MFM hot path has no CPU fallback")
+        cfg = Config()
+        defaults = dict(fourier_dim=128, hidden_t=(128, 128), hidden_x=(128, 128), hidden_xt=(128, 128),
+                        chain_offset=0, grad_clip=0.0, sigma=1e-4, cond_flow=1, hutch=0, rtol=1e-5, atol=1e-5,
+                        mxstep=1000, n_ts=2, learning_rate=1e-3, adam_b1=0.9, adam_b2=0.999, adam_eps=1e-8,
+                        weight_decay=1e-4, update_clip=1.0, learning_iter=400, warmup_steps=0, max_eval_samples=0)
+        defaults.update(kw)
+        defaults.setdefault("n_chain_total", defaults["n_chain_local"])
+        for k, v in defaults.items():
+            if k in ("hidden_t", "hidden_x", "hidden_xt"):
+                setattr(cfg, k, (C.c_int32 * 2)(*[int(h) for h in v]))
+            else:
+                setattr(cfg, k, v)
+        self.cfg = cfg
+        self.dim, self.n_local = int(cfg.dim), int(cfg.n_chain_local)
+        h = _P()
+        _chk(self.lib.mfm_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.n_params = self.lib.mfm_num_params(h)
+        self.use_current_stream()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mfm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def use_current_stream(self):
+        import torch
+        _chk(self.lib.mfm_set_stream(self.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def sync(self):
+        _chk(self.lib.mfm_sync(self.h))
+
+    # ---- target / parameters ------------------------------------------------------------------------------
+    def set_target(self, kind, params):
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        _chk(self.lib.mfm_set_target(self.h, kind, p.ctypes.data_as(C.POINTER(C.c_double)), p.size))
+
+    def set_fourier(self, f):
+        f = _f32(f)
+        assert f.size == self.cfg.fourier_dim
+        _chk(self.lib.mfm_set_fourier(self.h, f.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def set_params(self, flat):
+        flat = _f32(flat)
+        assert flat.size == self.n_params, (flat.size, self.n_params)
+        _chk(self.lib.mfm_set_params(self.h, flat.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def get_params(self):
+        out = np.empty(self.n_params, dtype=np.float32)
+        _chk(self.lib.mfm_get_params(self.h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def reset_optimizer(self):
+        _chk(self.lib.mfm_reset_optimizer(self.h))
+
+    # ---- kernels ----------------------------------------------------------------------------------------------
+    def mala_init(self, pos, beta, logp, grad):
+        _chk(self.lib.mfm_mala_init(self.h, _ptr(pos), float(beta), _ptr(logp), _ptr(grad)))
+
+    def mala_step(self, key, beta, step_size, pos, logp, grad, acc=None, is_acc=None, proposed=None, weight=None,
+                  textbook=False):
+        _chk(self.lib.mfm_mala_step(self.h, int(key[0]), int(key[1]), float(beta), float(step_size), int(textbook),
+                                    _ptr(pos), _ptr(logp), _ptr(grad), _ptr(acc), _ptr(is_acc), _ptr(proposed), _ptr(weight)))
+
+    def loglik(self, pos, out):
+        _chk(self.lib.mfm_loglik(self.h, _ptr(pos), _ptr(out)))
+
+    def fm_loss_grad(self, key, pos, loss, grads):
+        _chk(self.lib.mfm_fm_loss_grad(self.h, int(key[0]), int(key[1]), _ptr(pos), _ptr(loss), _ptr(grads)))
+
+    def fm_loss(self, key, samples, loss, n_total=None, offset=0):
+        n = samples.shape[0]
+        _chk(self.lib.mfm_fm_loss(self.h, int(key[0]), int(key[1]), _ptr(samples), n, n if n_total is None else n_total,
+                                  offset, _ptr(loss)))
+
+    def adamw_step(self, grads):
+        _chk(self.lib.mfm_adamw_step(self.h, _ptr(grads)))
+
+    def opt_state(self):
+        out = (C.c_int32 * 4)()
+        lr = C.c_float()
+        _chk(self.lib.mfm_opt_state(self.h, out, C.byref(lr)))
+        return dict(step=out[0], count=out[1], notfinite_count=out[2], last_applied=out[3], last_lr=lr.value)
+
+    def vf_apply(self, x, t, v, tangent=None, jvp=None):
+        _chk(self.lib.mfm_vf_apply(self.h, _ptr(x), _ptr(t), _ptr(tangent), x.shape[0], _ptr(v), _ptr(jvp)))
+
+    def ode_transform(self, direction, x, out, ldj, keys=None, key=(0, 0), nsteps=None):
+        _chk(self.lib.mfm_ode_transform(self.h, direction, 0 if keys is None else 1, _ptr(keys), int(key[0]), int(key[1]),
+                                        _ptr(x), x.shape[0], _ptr(out), _ptr(ldj), _ptr(nsteps)))
+
+    def flow_step(self, mode, key, beta, pos, logp, grad, acc=None, is_acc=None, proposed=None, nsteps=None):
+        _chk(self.lib.mfm_flow_step(self.h, mode, int(key[0]), int(key[1]), float(beta), _ptr(pos), _ptr(logp), _ptr(grad),
+                                    _ptr(acc), _ptr(is_acc), _ptr(proposed), _ptr(nsteps)))
+
+    def beta_update(self, prev_beta, logliks, alpha):
+        out = C.c_double()
+        _chk(self.lib.mfm_beta_update(self.h, float(prev_beta), _ptr(logliks), logliks.numel(), float(alpha), C.byref(out)))
+        return out.value

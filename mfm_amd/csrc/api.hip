@@ -1,0 +1,380 @@
+// C ABI of libmfm_hip (include/mfm.h).  Unity build: the kernel translation units are included here so one hipcc
+// invocation produces the shared library.
+#include "../../include/mfm.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "mala.hip"
+#include "fm.hip"
+#include "optim.hip"
+#include "ode.hip"
+#include "anneal.hip"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+  return code;
+}
+#define HIPCHK(x)                                                                                        \
+  do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MFM_EHIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+#define LAUNCHCHK()                                                                                      \
+  do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(MFM_EHIP, "kernel launch: %s", hipGetErrorString(e_)); } while (0)
+
+struct mfm_ctx {
+  mfm_config cfg;
+  hipStream_t stream;
+  NetDev net;
+  WsLayout ws;
+  bool has_target, has_fourier;
+  float *master, *mu, *nu, *Wp, *WpT, *bias, *fourier;
+  float *acts, *dzs, *slabs;
+  double* loss_part; int loss_cap;
+  WgradJob* jobs; int n_jobs, split;
+  OptState* opt; int* flag;
+  float *gmm_mode, *gmm_std, *gmm_logw, *counts, *Kinv;
+  OdeWs ode;
+  double* beta_out;
+};
+
+extern "C" const char* mfm_last_error(void) { return g_err; }
+extern "C" int mfm_version(void) { return 1; }
+extern "C" int mfm_pack_index(int k, int n, int KB) { return pack_index(k, n, KB); }
+extern "C" int mfm_pack_index_T(int k, int n, int NB) { return pack_index_T(k, n, NB); }
+extern "C" int mfm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]) {
+  threefry2x32(Key2{k0, k1}, c0, c1, out[0], out[1]);
+  return 0;
+}
+
+static void build_net(const mfm_config& c, NetDev& n) {
+  memset(&n, 0, sizeof n);
+  n.d = c.dim; n.dp = ceil16(c.dim); n.F = c.fourier_dim; n.F2p = ceil16(2 * c.fourier_dim);
+  n.ht1 = c.hidden_t[0]; n.ht2 = c.hidden_t[1]; n.hx1 = c.hidden_x[0]; n.hx2 = c.hidden_x[1];
+  n.hj1 = c.hidden_xt[0]; n.hj2 = c.hidden_xt[1];
+  const int K[8] = {2 * c.fourier_dim, n.ht1, c.dim, n.hx1, n.ht2, n.hx2 + n.ht2, n.hj1, n.hj2};
+  const int N[8] = {n.ht1, n.ht2, n.hx1, n.hx2, c.dim, n.hj1, n.hj2, c.dim};
+  int wo = 0, bo = 0, mo = 0;
+  for (int l = 0; l < 8; ++l) {
+    LayerDesc& L = n.L[l];
+    L.K = K[l]; L.N = N[l]; L.Kp = ceil16(K[l]); L.Np = ceil16(N[l]);
+    L.w_off = wo; wo += L.Kp * L.Np;
+    L.b_off = bo; bo += L.Np;
+    L.m_w = mo; mo += K[l] * N[l];
+    L.m_b = mo; mo += N[l];
+  }
+  n.n_packed = wo; n.n_bias = bo; n.n_params = mo;
+  n.grad_clip = c.grad_clip;
+}
+
+static void build_ws(const NetDev& n, WsLayout& w) {
+  int o = 0;
+  auto take = [&](int feat) { int r = o; o += feat / 16; return r; };
+  w.a_ffat = take(n.F2p); w.a_t1 = take(n.ht1); w.a_st = take(n.ht2); w.a_cond = take(n.dp);
+  w.a_x1 = take(n.hx1); w.a_sx = take(n.hx2); w.a_j1 = take(n.hj1); w.a_j2 = take(n.hj2); w.a_tiles = o;
+  o = 0;
+  w.z_t1 = take(n.ht1); w.z_t2 = take(n.ht2); w.z_x1 = take(n.hx1); w.z_x2 = take(n.hx2);
+  w.z_gate = take(n.dp); w.z_j1 = take(n.hj1); w.z_j2 = take(n.hj2); w.z_out = take(n.dp); w.z_tiles = o;
+}
+
+extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
+  if (!cfg || !out) return fail(MFM_EINVAL, "null argument");
+  const mfm_config& c = *cfg;
+  if (c.dim <= 0 || c.fourier_dim <= 0) return fail(MFM_EINVAL, "dim / fourier_dim must be positive");
+  const int hs[6] = {c.hidden_t[0], c.hidden_t[1], c.hidden_x[0], c.hidden_x[1], c.hidden_xt[0], c.hidden_xt[1]};
+  for (int h : hs)
+    if (h <= 0 || h % 16) return fail(MFM_EUNSUPPORTED, "hidden widths must be positive multiples of 16 (got %d)", h);
+  if (c.n_chain_local <= 0 || c.n_chain_local % 16)
+    return fail(MFM_EUNSUPPORTED, "n_chain_local must be a positive multiple of 16 (got %d)", c.n_chain_local);
+  if (c.chain_offset < 0 || c.chain_offset + c.n_chain_local > c.n_chain_total)
+    return fail(MFM_EINVAL, "chain shard [%d, %d) outside n_chain_total=%d", c.chain_offset,
+                c.chain_offset + c.n_chain_local, c.n_chain_total);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MFM_EHIP, "no HIP device available");
+  mfm_ctx* x = new mfm_ctx();
+  memset(x, 0, sizeof *x);
+  x->cfg = c;
+  build_net(c, x->net);
+  build_ws(x->net, x->ws);
+  NetDev& n = x->net;
+  {
+    const FmLds L = fm_lds_layout(n, true);
+    if ((size_t)L.total * 4 > 160 * 1024 || (n.dp / 16 + 3) / 4 > 4) {
+      delete x;
+      return fail(MFM_ETOOLARGE, "network does not fit the fused 16-chain tile kernel (LDS %zu B, dim %d)", (size_t)L.total * 4, c.dim);
+    }
+  }
+  const int nbb = c.n_chain_local / 16;
+  x->split = nbb < 16 ? nbb : 16;
+  x->loss_cap = (c.max_eval_samples > c.n_chain_local ? c.max_eval_samples : c.n_chain_local) / 16 + 1;
+  // wgrad job table
+  std::vector<WgradJob> jobs;
+  for (int l = 0; l < 8; ++l)
+    for (int nt = 0; nt < n.L[l].Np / 16; nt += 2)
+      for (int kt = 0; kt < n.L[l].Kp / 16; kt += 2) jobs.push_back(WgradJob{l, kt, nt});
+  x->n_jobs = (int)jobs.size();
+#define ALLOC(p, cnt) HIPCHK(hipMalloc((void**)&(p), (size_t)(cnt) * sizeof(*(p))))
+  ALLOC(x->master, n.n_params); ALLOC(x->mu, n.n_params); ALLOC(x->nu, n.n_params);
+  ALLOC(x->Wp, n.n_packed); ALLOC(x->WpT, n.n_packed); ALLOC(x->bias, n.n_bias); ALLOC(x->fourier, n.F);
+  ALLOC(x->acts, (size_t)x->ws.a_tiles * nbb * 256); ALLOC(x->dzs, (size_t)x->ws.z_tiles * nbb * 256);
+  ALLOC(x->slabs, (size_t)x->split * n.n_params);
+  ALLOC(x->loss_part, x->loss_cap);
+  ALLOC(x->jobs, x->n_jobs); ALLOC(x->opt, 1); ALLOC(x->flag, 1); ALLOC(x->beta_out, 4);
+  HIPCHK(hipMemcpy(x->jobs, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(x->master, 0, n.n_params * 4)); HIPCHK(hipMemset(x->mu, 0, n.n_params * 4));
+  HIPCHK(hipMemset(x->nu, 0, n.n_params * 4)); HIPCHK(hipMemset(x->Wp, 0, n.n_packed * 4));
+  HIPCHK(hipMemset(x->WpT, 0, n.n_packed * 4)); HIPCHK(hipMemset(x->bias, 0, n.n_bias * 4));
+  HIPCHK(hipMemset(x->opt, 0, sizeof(OptState))); HIPCHK(hipMemset(x->flag, 0, 4));
+  n.Wp = x->Wp; n.WpT = x->WpT; n.bias = x->bias; n.fourier = x->fourier;
+  int rc = ode_ws_alloc(n, c, x->ode);
+  if (rc) return fail(rc, "ODE workspace allocation failed");
+  *out = x;
+  return MFM_OK;
+}
+
+extern "C" int mfm_destroy(mfm_ctx* x) {
+  if (!x) return MFM_OK;
+  hipDeviceSynchronize();
+  void* ps[] = {x->master, x->mu, x->nu, x->Wp, x->WpT, x->bias, x->fourier, x->acts, x->dzs, x->slabs, x->loss_part,
+                x->jobs, x->opt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->beta_out};
+  for (void* p : ps) if (p) hipFree(p);
+  ode_ws_free(x->ode);
+  delete x;
+  return MFM_OK;
+}
+
+extern "C" int mfm_set_stream(mfm_ctx* x, void* s) { if (!x) return fail(MFM_EINVAL, "null ctx"); x->stream = (hipStream_t)s; return MFM_OK; }
+extern "C" int mfm_sync(mfm_ctx* x) { if (!x) return fail(MFM_EINVAL, "null ctx"); HIPCHK(hipStreamSynchronize(x->stream)); return MFM_OK; }
+extern "C" int mfm_num_params(const mfm_ctx* x) { return x ? x->net.n_params : MFM_EINVAL; }
+
+extern "C" int mfm_set_target(mfm_ctx* x, int kind, const double* p, size_t np) {
+  if (!x || !p) return fail(MFM_EINVAL, "null argument");
+  TargetDev& T = x->net.T;
+  const int d = x->cfg.dim;
+  memset(&T, 0, sizeof T);
+  T.kind = kind; T.dim = d;
+  if (kind == MFM_PHI4) {
+    if (np != 2) return fail(MFM_EINVAL, "phi4 target takes {a, beta}");
+    T.coef = (float)(p[0] * d); T.tbeta = (float)p[1];
+  } else if (kind == MFM_GMM) {
+    const int K = (int)p[0];
+    if (K <= 0 || K > MFM_GMM_MAX_MODES || np != (size_t)(1 + 2 * K * d + K)) return fail(MFM_EINVAL, "bad GMM parameter block");
+    if (d > 8) return fail(MFM_EUNSUPPORTED, "GMM targets support dim <= 8 (the reference forces dim = 2)");
+    std::vector<float> mode(K * d), sd(K * d), lw(K);
+    for (int i = 0; i < K * d; ++i) { mode[i] = (float)p[1 + i]; sd[i] = (float)p[1 + K * d + i]; }
+    for (int k = 0; k < K; ++k) {
+      double s = std::log(p[1 + 2 * K * d + k]) - 0.5 * d * std::log(2.0 * M_PI);
+      for (int j = 0; j < d; ++j) s -= std::log(p[1 + K * d + k * d + j]);
+      lw[k] = (float)s;
+    }
+    for (float** q : {&x->gmm_mode, &x->gmm_std, &x->gmm_logw}) if (*q) { hipFree(*q); *q = nullptr; }
+    ALLOC(x->gmm_mode, K * d); ALLOC(x->gmm_std, K * d); ALLOC(x->gmm_logw, K);
+    HIPCHK(hipMemcpy(x->gmm_mode, mode.data(), K * d * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(x->gmm_std, sd.data(), K * d * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(x->gmm_logw, lw.data(), K * 4, hipMemcpyHostToDevice));
+    T.n_modes = K; T.gmm_mode = x->gmm_mode; T.gmm_std = x->gmm_std; T.gmm_logw = x->gmm_logw;
+  } else if (kind == MFM_LGCP) {
+    return fail(MFM_EUNSUPPORTED, "LGCP target: not built yet (SURVEY.md section 8a row T3)");
+  } else {
+    return fail(MFM_EINVAL, "unknown target kind %d", kind);
+  }
+  x->has_target = true;
+  return MFM_OK;
+}
+
+extern "C" int mfm_set_fourier(mfm_ctx* x, const float* h) {
+  if (!x || !h) return fail(MFM_EINVAL, "null argument");
+  HIPCHK(hipMemcpy(x->fourier, h, x->net.F * 4, hipMemcpyHostToDevice));
+  x->has_fourier = true;
+  return MFM_OK;
+}
+extern "C" int mfm_set_params(mfm_ctx* x, const float* h) {
+  if (!x || !h) return fail(MFM_EINVAL, "null argument");
+  HIPCHK(hipMemcpyAsync(x->master, h, (size_t)x->net.n_params * 4, hipMemcpyHostToDevice, x->stream));
+  launch_pack(x->net, x->master, x->Wp, x->WpT, x->bias, x->stream);
+  LAUNCHCHK();
+  HIPCHK(hipStreamSynchronize(x->stream));
+  return MFM_OK;
+}
+extern "C" int mfm_get_params(mfm_ctx* x, float* h) {
+  if (!x || !h) return fail(MFM_EINVAL, "null argument");
+  HIPCHK(hipStreamSynchronize(x->stream));
+  HIPCHK(hipMemcpy(h, x->master, (size_t)x->net.n_params * 4, hipMemcpyDeviceToHost));
+  return MFM_OK;
+}
+extern "C" int mfm_reset_optimizer(mfm_ctx* x) {
+  if (!x) return fail(MFM_EINVAL, "null ctx");
+  HIPCHK(hipMemsetAsync(x->mu, 0, (size_t)x->net.n_params * 4, x->stream));
+  HIPCHK(hipMemsetAsync(x->nu, 0, (size_t)x->net.n_params * 4, x->stream));
+  HIPCHK(hipMemsetAsync(x->opt, 0, sizeof(OptState), x->stream));
+  return MFM_OK;
+}
+
+#define NEED_TARGET() do { if (!x) return fail(MFM_EINVAL, "null ctx"); if (!x->has_target) return fail(MFM_ENOTARGET, "mfm_set_target has not been called"); } while (0)
+
+static MalaArgs mala_args(mfm_ctx* x, double beta) {
+  MalaArgs a; memset(&a, 0, sizeof a);
+  a.T = x->net.T; a.n_total = x->cfg.n_chain_total; a.chain_offset = x->cfg.chain_offset; a.B = x->cfg.n_chain_local;
+  a.beta = beta;
+  return a;
+}
+
+extern "C" int mfm_mala_init(mfm_ctx* x, const float* d_pos, double beta, double* d_logp, float* d_grad) {
+  NEED_TARGET();
+  if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
+  MalaArgs a = mala_args(x, beta);
+  a.pos = const_cast<float*>(d_pos); a.logp = d_logp; a.grad = d_grad;
+  if (launch_mala_init(a, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large for the MALA kernel", x->cfg.dim);
+  LAUNCHCHK();
+  return MFM_OK;
+}
+
+extern "C" int mfm_mala_step(mfm_ctx* x, uint32_t k0, uint32_t k1, double beta, double step, int textbook, float* d_pos,
+                             double* d_logp, float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, float* d_pw) {
+  NEED_TARGET();
+  if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
+  if (!(step > 0)) return fail(MFM_EINVAL, "step_size must be positive");
+  MalaArgs a = mala_args(x, beta);
+  a.key = Key2{k0, k1}; a.eps = step; a.textbook = textbook;
+  a.pos = d_pos; a.logp = d_logp; a.grad = d_grad;
+  a.acc_prob = d_acc; a.accepted = d_isacc; a.proposed = d_prop; a.prop_weight = d_pw;
+  if (launch_mala_step(a, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large for the MALA kernel", x->cfg.dim);
+  LAUNCHCHK();
+  return MFM_OK;
+}
+
+extern "C" int mfm_loglik(mfm_ctx* x, const float* d_pos, double* d_out) {
+  NEED_TARGET();
+  if (!d_pos || !d_out) return fail(MFM_EINVAL, "null device pointer");
+  MalaArgs a = mala_args(x, 1.0);
+  a.pos = const_cast<float*>(d_pos);
+  if (launch_loglik(a, d_out, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large", x->cfg.dim);
+  LAUNCHCHK();
+  return MFM_OK;
+}
+
+static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_samples, int n, int n_total, int offset, bool train,
+                     double* d_loss) {
+  if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
+  if (n <= 0 || n % 16) return fail(MFM_EUNSUPPORTED, "sample count must be a positive multiple of 16 (got %d)", n);
+  if (n / 16 > x->loss_cap) return fail(MFM_ETOOLARGE, "n=%d exceeds max_eval_samples given at mfm_create", n);
+  FmArgs a; memset(&a, 0, sizeof a);
+  a.net = x->net; a.ws = x->ws;
+  const Key2 key{k0, k1};
+  if (x->cfg.cond_flow) {                       // exe_flow_matching.py:153
+    a.key_time = split_at(key, 4, 0); a.key_ref = split_at(key, 4, 1); a.key_gauss = split_at(key, 4, 2);
+  } else {                                      // :141
+    a.key_time = split_at(key, 2, 0); a.key_ref = split_at(key, 2, 1);
+  }
+  a.n_total = n_total; a.chain_offset = offset; a.B = n; a.sigma = x->cfg.sigma; a.cond_flow = x->cfg.cond_flow;
+  a.pos = d_samples; a.acts = x->acts; a.dzs = x->dzs; a.loss_part = x->loss_part;
+  int rc = launch_fm(a, train, x->stream);
+  if (rc) return fail(rc, "fm kernel cannot be launched for this configuration");
+  LAUNCHCHK();
+  launch_reduce_loss(x->loss_part, n / 16, d_loss, 0, x->stream);
+  LAUNCHCHK();
+  return MFM_OK;
+}
+
+extern "C" int mfm_fm_loss_grad(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_pos, double* d_loss, float* d_grads) {
+  NEED_TARGET();
+  if (!d_pos || !d_loss || !d_grads) return fail(MFM_EINVAL, "null device pointer");
+  int rc = fm_common(x, k0, k1, d_pos, x->cfg.n_chain_local, x->cfg.n_chain_total, x->cfg.chain_offset, true, d_loss);
+  if (rc) return rc;
+  WgradArgs w; memset(&w, 0, sizeof w);
+  w.net = x->net; w.ws = x->ws; w.acts = x->acts; w.dzs = x->dzs; w.jobs = x->jobs; w.n_jobs = x->n_jobs;
+  w.nbb = x->cfg.n_chain_local / 16; w.split = x->split; w.slabs = x->slabs;
+  launch_wgrad(w, x->stream);
+  LAUNCHCHK();
+  launch_reduce_slabs(x->slabs, x->split, x->net.n_params, d_grads, x->stream);
+  LAUNCHCHK();
+  return MFM_OK;
+}
+
+extern "C" int mfm_fm_loss(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_samples, int n, int n_total, int offset, double* d_loss) {
+  NEED_TARGET();
+  if (!d_samples || !d_loss) return fail(MFM_EINVAL, "null device pointer");
+  return fm_common(x, k0, k1, d_samples, n, n_total, offset, false, d_loss);
+}
+
+extern "C" int mfm_adamw_step(mfm_ctx* x, const float* d_grads) {
+  if (!x || !d_grads) return fail(MFM_EINVAL, "null argument");
+  const mfm_config& c = x->cfg;
+  AdamArgs a; memset(&a, 0, sizeof a);
+  a.net = x->net; a.grads = d_grads; a.n_slabs = 1;
+  a.master = x->master; a.mu = x->mu; a.nu = x->nu; a.Wp = x->Wp; a.WpT = x->WpT; a.bias = x->bias;
+  a.st = x->opt; a.flag = x->flag;
+  a.lr0 = c.learning_rate; a.learning_iter = c.learning_iter; a.warmup = c.warmup_steps;
+  a.b1 = c.adam_b1; a.b2 = c.adam_b2; a.eps = (float)c.adam_eps; a.wd = (float)c.weight_decay; a.clip = (float)c.update_clip;
+  a.max_err = 10;
+  launch_adamw(a, x->stream);
+  LAUNCHCHK();
+  return MFM_OK;
+}
+
+extern "C" int mfm_opt_state(mfm_ctx* x, int32_t out[4], float* lr) {
+  if (!x || !out) return fail(MFM_EINVAL, "null argument");
+  OptState s;
+  HIPCHK(hipStreamSynchronize(x->stream));
+  HIPCHK(hipMemcpy(&s, x->opt, sizeof s, hipMemcpyDeviceToHost));
+  out[0] = s.step; out[1] = s.count; out[2] = s.notfinite_count; out[3] = s.last_applied;
+  if (lr) *lr = s.last_lr;
+  return MFM_OK;
+}
+
+extern "C" int mfm_vf_apply(mfm_ctx* x, const float* d_x, const float* d_t, const float* d_tan, int n, float* d_v, float* d_jvp) {
+  NEED_TARGET();
+  if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
+  if (!d_x || !d_t || !d_v || ((d_tan == nullptr) != (d_jvp == nullptr))) return fail(MFM_EINVAL, "bad pointer arguments");
+  if (n <= 0 || n % 16) return fail(MFM_EUNSUPPORTED, "n must be a positive multiple of 16");
+  int rc = launch_vf_apply(x->net, d_x, d_t, d_tan, n, d_v, d_jvp, x->stream);
+  if (rc) return fail(rc, "vf_apply cannot be launched for this configuration");
+  LAUNCHCHK();
+  return MFM_OK;
+}
+
+extern "C" int mfm_ode_transform(mfm_ctx* x, int direction, int per_chain, const uint32_t* d_keys, uint32_t k0, uint32_t k1,
+                                 const float* d_in, int n, float* d_out, float* d_ldj, int32_t* d_nsteps) {
+  NEED_TARGET();
+  if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
+  if (!d_in || !d_out || !d_ldj || (per_chain && !d_keys)) return fail(MFM_EINVAL, "null device pointer");
+  if (direction != 1 && direction != -1) return fail(MFM_EINVAL, "direction must be +1 or -1");
+  if (n <= 0 || n % 16) return fail(MFM_EUNSUPPORTED, "n must be a positive multiple of 16");
+  OdeArgs a = ode_args(x->net, x->cfg, x->ode);
+  a.direction = direction; a.per_chain_keys = per_chain; a.keys = d_keys; a.key = Key2{k0, k1};
+  a.in = d_in; a.out = d_out; a.ldj = d_ldj; a.nsteps = d_nsteps; a.n = n;
+  int rc = launch_ode_transform(a, x->stream);
+  if (rc) return fail(rc, "ODE kernel cannot be launched for this configuration");
+  LAUNCHCHK();
+  return MFM_OK;
+}
+
+extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, double beta, float* d_pos, double* d_logp,
+                             float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, int32_t* d_nsteps) {
+  NEED_TARGET();
+  if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
+  if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
+  if (mode != MFM_FLOW_RWMH && mode != MFM_FLOW_IMH) return fail(MFM_EINVAL, "unknown flow step mode %d", mode);
+  OdeArgs a = ode_args(x->net, x->cfg, x->ode);
+  a.n = x->cfg.n_chain_local;
+  FlowArgs f; memset(&f, 0, sizeof f);
+  f.mode = mode; f.key = Key2{k0, k1}; f.n_total = x->cfg.n_chain_total; f.chain_offset = x->cfg.chain_offset;
+  f.beta = beta; f.pos = d_pos; f.logp = d_logp; f.grad = d_grad; f.acc_prob = d_acc; f.accepted = d_isacc;
+  f.proposed = d_prop; f.nsteps = d_nsteps;
+  int rc = launch_flow_step(a, f, x->stream);
+  if (rc) return fail(rc, "flow step cannot be launched for this configuration");
+  LAUNCHCHK();
+  return MFM_OK;
+}
+
+extern "C" int mfm_beta_update(mfm_ctx* x, double prev_beta, const double* d_ll, int n, double alpha, double* h_out) {
+  if (!x || !d_ll || !h_out) return fail(MFM_EINVAL, "null argument");
+  if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
+  launch_beta(prev_beta, d_ll, n, alpha, x->beta_out, x->stream);
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(h_out, x->beta_out, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  HIPCHK(hipStreamSynchronize(x->stream));
+  return MFM_OK;
+}

@@ -1,0 +1,453 @@
+// K3 + K4 (+ K9): flow-matching batch construction, vector-field forward, loss, and the data-gradient half of the
+// backward pass, fused in ONE kernel per tile of 16 chains; then the weight-gradient GEMMs (reduction over chains)
+// as a second kernel on the packed activations the first one leaves behind.
+//
+// Replaces exe_flow_matching.py:151-178 (cond_flow_fn / flow_fn + flow_matching_loss) and the XLA backward of
+// jax.value_and_grad(loss_fn, argnums=2) at :364-365.  K3 is fused into the prologue (no HBM round trip for t, x0,
+// eps, cond, target); the loss is the SUM over chains and dims (:178).
+#include "mlp.cuh"
+#include "prng.cuh"
+
+struct WsLayout {            // tile-row offsets (units: NBB * 256 floats) into the packed activation workspaces
+  int a_ffat, a_t1, a_st, a_cond, a_x1, a_sx, a_j1, a_j2, a_tiles;
+  int z_t1, z_t2, z_x1, z_x2, z_gate, z_j1, z_j2, z_out, z_tiles;
+};
+
+struct FmArgs {
+  NetDev net;
+  WsLayout ws;
+  Key2 key_time, key_ref, key_gauss;
+  uint32_t n_total, chain_offset;
+  int B;                 // samples handled by this launch (multiple of 16)
+  float sigma;
+  int cond_flow;
+  const float* pos;      // [B][d] samples x1
+  float* acts;           // packed activations (TRAIN only)
+  float* dzs;            // packed pre-activation gradients (TRAIN only)
+  double* loss_part;     // [gridDim.x] partial sums of squared residuals
+};
+
+struct FmLds {           // float offsets into dynamic LDS
+  int ff, ldff, x, ldx, t1, ldt1, cat, ldcat, x1, ldx1, j1, ldj1, j2, ldj2, g, ldg;
+  int dv, lddv, d1, ldd1, d2, ldd2, dcat, gcs, red, total;
+};
+
+__host__ __device__ inline FmLds fm_lds_layout(const NetDev& n, bool train) {
+  FmLds L;
+  int o = 0;
+  auto take = [&](int rows, int ld) { int r = o; o += rows * ld; return r; };
+  L.ldff = n.F2p + 4;            L.ff = take(16, L.ldff);
+  L.ldx = n.dp + 8;              L.x = take(16, L.ldx);          // data starts at col 4: x[-1] and x[d] pads exist
+  L.ldt1 = n.ht1 + 4;            L.t1 = take(16, L.ldt1);
+  L.ldcat = n.hx2 + n.ht2 + 4;   L.cat = take(16, L.ldcat);
+  L.ldx1 = n.hx1 + 4;            L.x1 = take(16, L.ldx1);
+  L.ldj1 = n.hj1 + 4;            L.j1 = take(16, L.ldj1);
+  L.ldj2 = n.hj2 + 4;            L.j2 = take(16, L.ldj2);
+  L.ldg = n.dp + 4;              L.g = take(16, L.ldg);
+  L.lddv = n.dp + 4; L.ldd1 = n.hj2 + 4; L.ldd2 = n.hj1 + 4;
+  L.dv = L.d1 = L.d2 = L.dcat = 0;
+  if (train) {
+    L.dv = take(16, L.lddv);
+    L.d1 = take(16, L.ldd1);
+    L.d2 = take(16, L.ldd2);
+    L.dcat = take(16, L.ldcat);
+  }
+  L.gcs = take(16, 8);
+  L.red = take(1, 16);
+  L.total = o;
+  return L;
+}
+
+__device__ __forceinline__ void store_packed(float* base, int tile_row, int nbb, int bb, int lane, f32x4 v) {
+  reinterpret_cast<f32x4*>(base)[((size_t)tile_row * nbb + bb) * 64 + lane] = v;
+}
+
+// grad log pi(x)[row][col], clipped, for the tile whose positions sit in LDS `xrow0` (row stride ldx, data at +4)
+__device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf, int ldx, const float* gcs, int row, int col) {
+  float gv;
+  if (n.T.kind == MFM_TARGET_PHI4) gv = phi4_grad(n.T, xbuf + row * ldx + 4, col);
+  else gv = gcs[row * 8 + col];
+  return clipf(gv, n.grad_clip);
+}
+
+template <int TPW, bool TRAIN>
+__global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const NetDev& n = a.net;
+  const FmLds L = fm_lds_layout(n, TRAIN);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int bb = blockIdx.x, b0 = bb * 16, nbb = a.B / 16;
+  const int d = n.d;
+
+  float* bFF = lds + L.ff;  float* bX = lds + L.x;   float* bT1 = lds + L.t1; float* bCat = lds + L.cat;
+  float* bX1 = lds + L.x1;  float* bJ1 = lds + L.j1; float* bJ2 = lds + L.j2; float* bG = lds + L.g;
+  float* bDV = lds + L.dv;  float* bD1 = lds + L.d1; float* bD2 = lds + L.d2; float* bDC = lds + L.dcat;
+  float* gcs = lds + L.gcs; double* red = reinterpret_cast<double*>(lds + L.red);
+
+  // ---------------- prologue: K3 batch construction (exe_flow_matching.py:151-169 / :139-147) ----------------
+  for (int i = threadIdx.x; i < 16 * L.ldx; i += MLP_THREADS) bX[i] = 0.f;      // pads (incl. x[-1], x[d..])
+  __syncthreads();
+  float tt[4];
+  Key2 kref[4];
+  uint32_t bglob[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bglob[i] = a.chain_offset + (uint32_t)(b0 + 4 * g + i);
+    tt[i] = (float)uniform01(a.key_time, bglob[i], a.n_total);                  // :154 / :142
+    kref[i] = split_at(a.key_ref, a.n_total, bglob[i]);                         // :155
+  }
+  float tgt[TPW][4];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int nt = wave + 4 * q, col = nt * 16 + c;
+    f32x4 cv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tgt[q][i] = 0.f;
+      if (nt * 16 < n.dp && col < d) {
+        const int row = 4 * g + i;
+        const double x1v = a.pos[(size_t)(b0 + row) * d + col];
+        const double t = tt[i];
+        double cnd, tg;
+        if (a.cond_flow) {
+          const double x0 = normal64(kref[i], (uint32_t)col, (uint32_t)d);
+          const double ne = normal64(a.key_gauss, bglob[i] * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);  // :166
+          cnd = (double)a.sigma * ne + t * x1v + (1.0 - t) * x0;               // :167
+          tg = x1v - x0;                                                       // :168
+        } else {
+          const double x0 = normal64(a.key_ref, bglob[i] * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);   // :143
+          const double sds = 1.0 - (1.0 - (double)a.sigma) * t;                // :144
+          cnd = t * x1v + sds * x0;                                            // :145
+          tg = x1v - (1.0 - (double)a.sigma) * x0;                             // :146
+        }
+        cv[i] = (float)cnd;
+        tgt[q][i] = (float)tg;
+        bX[row * L.ldx + 4 + col] = cv[i];
+      }
+    }
+    if (TRAIN && nt * 16 < n.dp) store_packed(a.acts, a.ws.a_cond + nt, nbb, bb, lane, cv);
+  }
+  // Fourier features of t (:70-71)
+  for (int nt = wave; nt * 16 < n.F2p; nt += 4) {
+    const int col = nt * 16 + c;
+    f32x4 fv = {0.f, 0.f, 0.f, 0.f};
+    if (col < 2 * n.F) {
+      const bool is_sin = col >= n.F;
+      const double f = n.fourier[is_sin ? col - n.F : col];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double ft = f * (double)tt[i];
+        ft -= rint(ft);
+        float sv, cvv;
+        sincospif(2.f * (float)ft, &sv, &cvv);
+        fv[i] = is_sin ? sv : cvv;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bFF[(4 * g + i) * L.ldff + col] = fv[i];
+    if (TRAIN) store_packed(a.acts, a.ws.a_ffat + nt, nbb, bb, lane, fv);
+  }
+  __syncthreads();
+  if (n.T.kind == MFM_TARGET_GMM && threadIdx.x < 16) {
+    double lp; float gg[8];
+    gmm_eval<8>(n.T, bX + threadIdx.x * L.ldx + 4, &lp, gg);
+    for (int j = 0; j < d; ++j) gcs[threadIdx.x * 8 + j] = gg[j];
+  }
+
+  // ---------------- forward ----------------------------------------------------------------------------------
+  auto relu_store = [&](const LayerDesc& ld, float* out, int ldo, int coff, int a_tile) {
+    return [&, out, ldo, coff, a_tile](int q, int nt, int m, f32x4 acc) {
+      const float bias = n.bias[ld.b_off + nt * 16 + c];
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = fmaxf(acc[i] + bias, 0.f);
+        out[(4 * g + i) * ldo + coff + nt * 16 + c] = v[i];
+      }
+      if (TRAIN) store_packed(a.acts, a_tile + nt, nbb, bb, lane, v);
+    };
+  };
+  layer_gemm<1, 2>(bFF, L.ldff, n.Wp + n.L[0].w_off, n.L[0].Kp / 16, n.L[0].Np / 16, wave, lane,
+                   relu_store(n.L[0], bT1, L.ldt1, 0, a.ws.a_t1));
+  layer_gemm<1, 2>(bX + 4, L.ldx, n.Wp + n.L[2].w_off, n.L[2].Kp / 16, n.L[2].Np / 16, wave, lane,
+                   relu_store(n.L[2], bX1, L.ldx1, 0, a.ws.a_x1));
+  __syncthreads();
+  layer_gemm<1, 2>(bT1, L.ldt1, n.Wp + n.L[1].w_off, n.L[1].Kp / 16, n.L[1].Np / 16, wave, lane,
+                   relu_store(n.L[1], bCat, L.ldcat, n.hx2, a.ws.a_st));
+  layer_gemm<1, 2>(bX1, L.ldx1, n.Wp + n.L[3].w_off, n.L[3].Kp / 16, n.L[3].Np / 16, wave, lane,
+                   relu_store(n.L[3], bCat, L.ldcat, 0, a.ws.a_sx));
+  __syncthreads();
+  layer_gemm<1, 2>(bCat + n.hx2, L.ldcat, n.Wp + n.L[4].w_off, n.L[4].Kp / 16, n.L[4].Np / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc) {
+                     const float bias = n.bias[n.L[4].b_off + nt * 16 + c];
+#pragma unroll
+                     for (int i = 0; i < 4; ++i) bG[(4 * g + i) * L.ldg + nt * 16 + c] = acc[i] + bias;
+                   });
+  layer_gemm<1, 2>(bCat, L.ldcat, n.Wp + n.L[5].w_off, n.L[5].Kp / 16, n.L[5].Np / 16, wave, lane,
+                   relu_store(n.L[5], bJ1, L.ldj1, 0, a.ws.a_j1));
+  __syncthreads();
+  layer_gemm<1, 2>(bJ1, L.ldj1, n.Wp + n.L[6].w_off, n.L[6].Kp / 16, n.L[6].Np / 16, wave, lane,
+                   relu_store(n.L[6], bJ2, L.ldj2, 0, a.ws.a_j2));
+  __syncthreads();
+  // output layer + loss (:88-90, :177-178); dv = 2 (v - target), dgate = dv * clip(grad log pi)
+  float loss_loc = 0.f;
+  layer_gemm<1, 2>(bJ2, L.ldj2, n.Wp + n.L[7].w_off, n.L[7].Kp / 16, n.L[7].Np / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc) {
+                     const int col = nt * 16 + c;
+                     const float bias = n.bias[n.L[7].b_off + col];
+                     f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                     for (int i = 0; i < 4; ++i) {
+                       const int row = 4 * g + i;
+                       if (col < d) {
+                         const float gc = target_gclip(n, bX, L.ldx, gcs, row, col);
+                         const float v = acc[i] + bias + bG[row * L.ldg + col] * gc;
+                         // tgt is indexed by the static slot q: select without dynamic register indexing
+                         float tg = 0.f;
+#pragma unroll
+                         for (int qq = 0; qq < TPW; ++qq) tg = (qq == q) ? tgt[qq][i] : tg;
+                         const float r = v - tg;
+                         loss_loc += r * r;
+                         dv[i] = 2.f * r;
+                         dg[i] = dv[i] * gc;
+                       }
+                       if (TRAIN) { bDV[row * L.lddv + col] = dv[i]; bG[row * L.ldg + col] = dg[i]; }
+                     }
+                     if (TRAIN) {
+                       store_packed(a.dzs, a.ws.z_out + nt, nbb, bb, lane, dv);
+                       store_packed(a.dzs, a.ws.z_gate + nt, nbb, bb, lane, dg);
+                     }
+                   });
+  {
+    double lw = wave_sum((double)loss_loc);
+    if (lane == 0) red[wave] = lw;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.loss_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (!TRAIN) return;
+
+  // ---------------- backward (data gradients only; weight gradients: wgrad_kernel) -----------------------------
+  // d j2
+  layer_gemm<1, 2>(bDV, L.lddv, n.WpT + n.L[7].w_off, n.L[7].Np / 16, n.L[7].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc) {
+                     f32x4 z;
+#pragma unroll
+                     for (int i = 0; i < 4; ++i) {
+                       const int row = 4 * g + i, col = nt * 16 + c;
+                       z[i] = bJ2[row * L.ldj2 + col] > 0.f ? acc[i] : 0.f;
+                       bD1[row * L.ldd1 + col] = z[i];
+                     }
+                     store_packed(a.dzs, a.ws.z_j2 + nt, nbb, bb, lane, z);
+                   });
+  __syncthreads();
+  // d j1
+  layer_gemm<1, 2>(bD1, L.ldd1, n.WpT + n.L[6].w_off, n.L[6].Np / 16, n.L[6].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc) {
+                     f32x4 z;
+#pragma unroll
+                     for (int i = 0; i < 4; ++i) {
+                       const int row = 4 * g + i, col = nt * 16 + c;
+                       z[i] = bJ1[row * L.ldj1 + col] > 0.f ? acc[i] : 0.f;
+                       bD2[row * L.ldd2 + col] = z[i];
+                     }
+                     store_packed(a.dzs, a.ws.z_j1 + nt, nbb, bb, lane, z);
+                   });
+  __syncthreads();
+  // d [sx | st] through j1; the sx half is finished here (-> dz of x2), the st half waits for the gate path
+  layer_gemm<1, 2>(bD2, L.ldd2, n.WpT + n.L[5].w_off, n.L[5].Np / 16, n.L[5].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc) {
+                     const int col = nt * 16 + c;
+                     const bool is_sx = col < n.hx2;
+                     f32x4 z;
+#pragma unroll
+                     for (int i = 0; i < 4; ++i) {
+                       const int row = 4 * g + i;
+                       z[i] = is_sx ? (bCat[row * L.ldcat + col] > 0.f ? acc[i] : 0.f) : acc[i];
+                       bDC[row * L.ldcat + col] = z[i];
+                     }
+                     if (is_sx) store_packed(a.dzs, a.ws.z_x2 + nt, nbb, bb, lane, z);
+                   });
+  __syncthreads();
+  // d st += dgate . W_gate^T ; then relu mask -> dz of t2
+  layer_gemm<1, 2>(bG, L.ldg, n.WpT + n.L[4].w_off, n.L[4].Np / 16, n.L[4].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc) {
+                     f32x4 z;
+#pragma unroll
+                     for (int i = 0; i < 4; ++i) {
+                       const int row = 4 * g + i, col = n.hx2 + nt * 16 + c;
+                       const float ds = acc[i] + bDC[row * L.ldcat + col];
+                       z[i] = bCat[row * L.ldcat + col] > 0.f ? ds : 0.f;
+                       bDC[row * L.ldcat + col] = z[i];
+                     }
+                     store_packed(a.dzs, a.ws.z_t2 + nt, nbb, bb, lane, z);
+                   });
+  __syncthreads();
+  // d x1 (only needed by wgrad) and d t1
+  layer_gemm<1, 2>(bDC, L.ldcat, n.WpT + n.L[3].w_off, n.L[3].Np / 16, n.L[3].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc) {
+                     f32x4 z;
+#pragma unroll
+                     for (int i = 0; i < 4; ++i) z[i] = bX1[(4 * g + i) * L.ldx1 + nt * 16 + c] > 0.f ? acc[i] : 0.f;
+                     store_packed(a.dzs, a.ws.z_x1 + nt, nbb, bb, lane, z);
+                   });
+  layer_gemm<1, 2>(bDC + n.hx2, L.ldcat, n.WpT + n.L[1].w_off, n.L[1].Np / 16, n.L[1].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc) {
+                     f32x4 z;
+#pragma unroll
+                     for (int i = 0; i < 4; ++i) z[i] = bT1[(4 * g + i) * L.ldt1 + nt * 16 + c] > 0.f ? acc[i] : 0.f;
+                     store_packed(a.dzs, a.ws.z_t1 + nt, nbb, bb, lane, z);
+                   });
+}
+
+// ---- weight gradients: dW[k][n] = sum_b A[b][k] dZ[b][n], db[n] = sum_b dZ[b][n] ------------------------------
+// One wave per 32 x 32 output block (2 x 2 MFMA tiles), 4 waves per workgroup, SPLIT slices of the chain axis.
+// Both operands are float4 loads from the packed workspaces; partial sums go to slab[split][n_params] in the
+// canonical flat layout (deterministic: no atomics), reduced by reduce_slabs_kernel / the AdamW kernel.
+struct WgradJob { int layer, kt0, nt0; };   // kt0, nt0 in units of 16; covers tiles kt0..kt0+1, nt0..nt0+1
+
+struct WgradArgs {
+  NetDev net;
+  WsLayout ws;
+  const float* acts; const float* dzs;
+  const WgradJob* jobs; int n_jobs;
+  int nbb, split;
+  float* slabs;            // [split][n_params]
+};
+
+__device__ __forceinline__ int wgrad_a_tile(const NetDev& n, const WsLayout& w, int layer, int kt) {
+  switch (layer) {
+    case 0: return w.a_ffat + kt;
+    case 1: return w.a_t1 + kt;
+    case 2: return w.a_cond + kt;
+    case 3: return w.a_x1 + kt;
+    case 4: return w.a_st + kt;
+    case 5: return kt < n.hx2 / 16 ? w.a_sx + kt : w.a_st + (kt - n.hx2 / 16);
+    case 6: return w.a_j1 + kt;
+    default: return w.a_j2 + kt;
+  }
+}
+__device__ __forceinline__ int wgrad_z_tile(const WsLayout& w, int layer, int nt) {
+  switch (layer) {
+    case 0: return w.z_t1 + nt;
+    case 1: return w.z_t2 + nt;
+    case 2: return w.z_x1 + nt;
+    case 3: return w.z_x2 + nt;
+    case 4: return w.z_gate + nt;
+    case 5: return w.z_j1 + nt;
+    case 6: return w.z_j2 + nt;
+    default: return w.z_out + nt;
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int job = blockIdx.x * 4 + wave;
+  if (job >= a.n_jobs) return;
+  const WgradJob J = a.jobs[job];
+  const NetDev& n = a.net;
+  const LayerDesc& ld = n.L[J.layer];
+  const int KT = ld.Kp / 16, NT = ld.Np / 16;
+  const int sp = blockIdx.y;
+  const int bb_lo = (int)((long long)a.nbb * sp / a.split), bb_hi = (int)((long long)a.nbb * (sp + 1) / a.split);
+  const bool k1 = J.kt0 + 1 < KT, n1 = J.nt0 + 1 < NT;
+  const f32x4* A0 = reinterpret_cast<const f32x4*>(a.acts) + (size_t)wgrad_a_tile(n, a.ws, J.layer, J.kt0) * a.nbb * 64 + lane;
+  const f32x4* A1 = reinterpret_cast<const f32x4*>(a.acts) + (size_t)wgrad_a_tile(n, a.ws, J.layer, k1 ? J.kt0 + 1 : J.kt0) * a.nbb * 64 + lane;
+  const f32x4* Z0 = reinterpret_cast<const f32x4*>(a.dzs) + (size_t)wgrad_z_tile(a.ws, J.layer, J.nt0) * a.nbb * 64 + lane;
+  const f32x4* Z1 = reinterpret_cast<const f32x4*>(a.dzs) + (size_t)wgrad_z_tile(a.ws, J.layer, n1 ? J.nt0 + 1 : J.nt0) * a.nbb * 64 + lane;
+  f32x4 acc00 = {0, 0, 0, 0}, acc01 = acc00, acc10 = acc00, acc11 = acc00, bs0 = acc00, bs1 = acc00;
+  f32x4 a0 = A0[(size_t)bb_lo * 64], a1 = A1[(size_t)bb_lo * 64], z0 = Z0[(size_t)bb_lo * 64], z1 = Z1[(size_t)bb_lo * 64];
+  for (int bb = bb_lo; bb < bb_hi; ++bb) {
+    f32x4 na0 = a0, na1 = a1, nz0 = z0, nz1 = z1;
+    if (bb + 1 < bb_hi) {
+      na0 = A0[(size_t)(bb + 1) * 64]; na1 = A1[(size_t)(bb + 1) * 64];
+      nz0 = Z0[(size_t)(bb + 1) * 64]; nz1 = Z1[(size_t)(bb + 1) * 64];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], z0[s], acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], z1[s], acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], z0[s], acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], z1[s], acc11, 0, 0, 0);
+    }
+    bs0 += z0; bs1 += z1;
+    a0 = na0; a1 = na1; z0 = nz0; z1 = nz1;
+  }
+  float* slab = a.slabs + (size_t)sp * n.n_params;
+  auto put = [&](f32x4 acc, int kt, int nt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kt * 16 + 4 * g + i, nn = nt * 16 + c;
+      if (k < ld.K && nn < ld.N) slab[ld.m_w + k * ld.N + nn] = acc[i];
+    }
+  };
+  put(acc00, J.kt0, J.nt0);
+  if (n1) put(acc01, J.kt0, J.nt0 + 1);
+  if (k1) put(acc10, J.kt0 + 1, J.nt0);
+  if (k1 && n1) put(acc11, J.kt0 + 1, J.nt0 + 1);
+  if (J.kt0 == 0) {     // bias gradient: sum over chains of dZ, for the n-tiles of this job
+    float s0 = bs0[0] + bs0[1] + bs0[2] + bs0[3], s1 = bs1[0] + bs1[1] + bs1[2] + bs1[3];
+    s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    if (g == 0) {
+      const int nn0 = J.nt0 * 16 + c, nn1 = (J.nt0 + 1) * 16 + c;
+      if (nn0 < ld.N) slab[ld.m_b + nn0] = s0;
+      if (n1 && nn1 < ld.N) slab[ld.m_b + nn1] = s1;
+    }
+  }
+}
+
+// grads[p] = sum_s slabs[s][p]
+__global__ void reduce_slabs_kernel(const float* slabs, int split, int n, float* out) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < split; ++k) s += slabs[(size_t)k * n + p];
+  out[p] = s;
+}
+
+__global__ void reduce_loss_kernel(const double* part, int n, double* out, int accumulate) {
+  __shared__ double sm[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = accumulate ? *out + sm[0] : sm[0];
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------
+int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
+  const FmLds L = fm_lds_layout(a.net, train);
+  const size_t sm = (size_t)L.total * sizeof(float);
+  if (sm > 160 * 1024) return -3;
+  const int tpw = (a.net.dp / 16 + 3) / 4;
+  dim3 grid(a.B / 16), block(MLP_THREADS);
+#define FM_LAUNCH(T, TR)                                                                                   \
+  do {                                                                                                     \
+    (void)hipFuncSetAttribute((const void*)fm_fwd_bwd_kernel<T, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+    hipLaunchKernelGGL((fm_fwd_bwd_kernel<T, TR>), grid, block, sm, stream, a);                           \
+  } while (0)
+  if (train) {
+    if (tpw <= 1) FM_LAUNCH(1, true); else if (tpw <= 4) FM_LAUNCH(4, true); else return -3;
+  } else {
+    if (tpw <= 1) FM_LAUNCH(1, false); else if (tpw <= 4) FM_LAUNCH(4, false); else return -3;
+  }
+#undef FM_LAUNCH
+  return 0;
+}
+
+int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
+  dim3 grid((a.n_jobs + 3) / 4, a.split), block(256);
+  hipLaunchKernelGGL(wgrad_kernel, grid, block, 0, stream, a);
+  return 0;
+}
+
+void launch_reduce_slabs(const float* slabs, int split, int n, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, slabs, split, n, out);
+}
+void launch_reduce_loss(const double* part, int n, double* out, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, stream, part, n, out, accumulate);
+}

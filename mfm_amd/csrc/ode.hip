@@ -1,0 +1,806 @@
+// K5 + K6: continuous-normalising-flow transforms with log-det (adaptive Dormand-Prince 5(4), Hutchinson or exact
+// trace) and the flow-based Metropolis-Hastings steps, one persistent workgroup per tile of 16 chains.
+//
+// Replaces exe_flow_matching.py:206-221 (transform_and_logdet), :223-242 (inverse_and_logdet), :246-260 / :264-278
+// (independent / random-walk MH in latent space) and the third-party integrator they call,
+// jax.experimental.ode.odeint (:13,345-349; restated in oracle/ode.py): same tableau, same
+// controller (RMS error ratio over d+1 components, accept <= 1, factor clip(0.9 r^-1/5, dfactor, 10)), same initial
+// step heuristic, output at t = 1 by the 4th-order interpolant of the last accepted step.  Each chain runs its OWN
+// adaptive sequence (its own t, dt); the 16 chains of a tile execute in masked lock-step like a vmapped while_loop.
+//
+// Per RHS evaluation the tile pushes value AND tangent rows through the MLP together (forward-mode, M = 32 rows for
+// the x-path layers), so every streamed weight fragment is used twice.  z is drawn once per solve,
+// so the first x-layer's tangent pre-activation z W_x1 is computed once per solve and only re-masked afterwards.
+// The Runge-Kutta stages k1..k7 never leave registers: they are kept in the MFMA accumulator layout of the output
+// layer, which is also the layout the next stage's input is assembled in.
+//
+// The intermediate output times of the "4-mode" example (n_ts = 5) do not change the step sequence (steps are not
+// clamped to output times); they only reset odeint's attempted-step counter, so mxstep is applied per segment as
+// mxstep * (n_ts - 1) attempted steps in total.
+#include "mlp.cuh"
+#include "prng.cuh"
+
+struct OdeWs { int unused; };
+static int ode_ws_alloc(const NetDev&, const mfm_config&, OdeWs&) { return 0; }
+static void ode_ws_free(OdeWs&) {}
+
+struct OdeArgs {
+  NetDev net;
+  int hutch;
+  float rtol, atol;
+  int max_attempts;
+  int direction, per_chain_keys;
+  const uint32_t* keys; Key2 key;
+  const float* in; float* out; float* ldj; int* nsteps;
+  int n;
+};
+
+struct FlowArgs {
+  int mode; Key2 key; uint32_t n_total, chain_offset;
+  double beta;
+  float* pos; double* logp; float* grad;
+  float* acc_prob; uint8_t* accepted; float* proposed; int* nsteps;
+};
+
+static OdeArgs ode_args(const NetDev& n, const mfm_config& c, const OdeWs&) {
+  OdeArgs a; memset(&a, 0, sizeof a);
+  a.net = n; a.hutch = c.hutch; a.rtol = (float)c.rtol; a.atol = (float)c.atol;
+  a.max_attempts = c.mxstep * (c.n_ts > 1 ? c.n_ts - 1 : 1);
+  return a;
+}
+
+struct OdeLds {   // float offsets
+  int ff_j1, ldff, ldj1, x, ldx, z, cat, ldcat, x1, ldx1, j2_t1, ldj2, ldt1, red, gcs, total;
+};
+__host__ __device__ inline OdeLds ode_lds_layout(const NetDev& n) {
+  OdeLds L; int o = 0;
+  auto take = [&](int cnt) { int r = o; o += cnt; return r; };
+  L.ldff = n.F2p + 4; L.ldj1 = n.hj1 + 4;
+  { int a = 16 * L.ldff, b = 32 * L.ldj1; L.ff_j1 = take(a > b ? a : b); }
+  L.ldx = n.dp + 8; L.x = take(16 * L.ldx); L.z = take(16 * L.ldx);
+  L.ldcat = n.hx2 + n.ht2 + 4; L.cat = take(32 * L.ldcat);
+  L.ldx1 = n.hx1 + 4; L.x1 = take(32 * L.ldx1);
+  L.ldj2 = n.hj2 + 4; L.ldt1 = n.ht1 + 4;
+  { int a = 32 * L.ldj2, b = 16 * L.ldt1; L.j2_t1 = take(a > b ? a : b); }
+  L.red = take(8 * 64);      // 8 reduction slots of [4 waves][16 rows]
+  L.gcs = take(16 * 24);     // small-d targets: grad[8], hvp[8], inside-mask[8] per row
+  L.total = o;
+  return L;
+}
+
+// Dormand-Prince tableau (oracle/ode.py)
+__device__ static const float DP_E[7] = {(float)(35.0 / 384 - 1951.0 / 21600), 0.f, (float)(500.0 / 1113 - 22642.0 / 50085),
+                                         (float)(125.0 / 192 - 451.0 / 720), (float)(-2187.0 / 6784 + 12231.0 / 42400),
+                                         (float)(11.0 / 84 - 649.0 / 6300), (float)(-1.0 / 60)};
+__device__ static const float DP_M[7] = {(float)(6025192743.0 / 30085553152.0 / 2), 0.f, (float)(51252292925.0 / 65400821598.0 / 2),
+                                         (float)(-2691868925.0 / 45128329728.0 / 2), (float)(187940372067.0 / 1594534317056.0 / 2),
+                                         (float)(-1776094331.0 / 19743644256.0 / 2), (float)(11237099.0 / 235043384.0 / 2)};
+
+template <int TPW>
+struct OdeTile {
+  const NetDev* n;
+  OdeLds L;
+  float* lds;
+  int lane, wave, g, c;
+  bool hutch;
+  int sign;                 // +1 forward (:208-218), -1 inverse (:225-239)
+  float tz1[2][4];          // z W_x1 for this lane's x1-layer tiles (hx1 <= 128 -> <= 2 tiles per wave)
+
+  __device__ __forceinline__ float* bFF() { return lds + L.ff_j1; }
+  __device__ __forceinline__ float* bJ1() { return lds + L.ff_j1; }
+  __device__ __forceinline__ float* bX() { return lds + L.x; }
+  __device__ __forceinline__ float* bZ() { return lds + L.z; }
+  __device__ __forceinline__ float* bCat() { return lds + L.cat; }
+  __device__ __forceinline__ float* bX1() { return lds + L.x1; }
+  __device__ __forceinline__ float* bJ2() { return lds + L.j2_t1; }
+  __device__ __forceinline__ float* bT1() { return lds + L.j2_t1; }
+  __device__ __forceinline__ float* red(int slot) { return lds + L.red + slot * 64; }
+  __device__ __forceinline__ float* gcs() { return lds + L.gcs; }
+
+  // sum over the tile's columns of per-lane partials (rows 4g..4g+3); uses reduction slot `slot`.
+  // The caller guarantees a barrier between two uses of the same slot.
+  __device__ __forceinline__ void row_reduce(float (&p)[4], int slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = group16_sum(p[i]);
+    float* r = red(slot);
+    if (c == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[wave * 16 + 4 * g + i] = p[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int row = 4 * g + i; p[i] = r[row] + r[16 + row] + r[32 + row] + r[48 + row]; }
+  }
+
+  // z W_x1 (no bias), once per solve.  Requires bZ filled and a barrier before.
+  __device__ __forceinline__ void precompute_tz1() {
+    const LayerDesc& l2 = n->L[2];
+    layer_gemm<1, 2>(bZ() + 4, L.ldx, n->Wp + l2.w_off, l2.Kp / 16, l2.Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc) {
+#pragma unroll
+                       for (int i = 0; i < 4; ++i) { if (q == 0) tz1[0][i] = acc[i]; else tz1[1][i] = acc[i]; }
+                     });
+  }
+
+  // One evaluation of the augmented field at the positions in bX (value rows) and times tt[i] (this lane's rows).
+  // Outputs: kv[q][i] = dx/dt for (row 4g+i, col 16(wave+4q)+c); dl[i] = d(logdet)/dt for row 4g+i (all lanes agree).
+  template <bool WANT_JZ = false>
+  __device__ __forceinline__ void eval(const float (&tt)[4], float (&kv)[TPW][4], float (&dl)[4], int red_slot,
+                                       float (*jzo)[4] = nullptr) {
+    const NetDev& N = *n;
+    const int d = N.d;
+    // Fourier features (:70-71)
+    for (int nt = wave; nt * 16 < N.F2p; nt += 4) {
+      const int col = nt * 16 + c;
+      const bool is_sin = col >= N.F;
+      const double f = col < 2 * N.F ? (double)N.fourier[is_sin ? col - N.F : col] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = 0.f;
+        if (col < 2 * N.F) {
+          const double te = sign > 0 ? (double)tt[i] : 1.0 - (double)tt[i];          // :229
+          double ft = f * te;
+          ft -= rint(ft);
+          float sv, cv;
+          sincospif(2.f * (float)ft, &sv, &cv);
+          v = is_sin ? sv : cv;
+        }
+        bFF()[(4 * g + i) * L.ldff + col] = v;
+      }
+    }
+    if (N.T.kind == MFM_TARGET_GMM && threadIdx.x < 16) {    // small-d target: grad / hvp per row by one thread
+      double lp; float gg[8], hv[8];
+      const float* xr = bX() + threadIdx.x * L.ldx + 4;
+      const float* zr = bZ() + threadIdx.x * L.ldx + 4;
+      gmm_eval<8>(N.T, xr, &lp, gg, hutch ? zr : nullptr, hv);
+      float* o = gcs() + threadIdx.x * 24;
+      for (int j = 0; j < d; ++j) {
+        const bool inside = !(N.grad_clip > 0.f) || fabsf(gg[j]) <= N.grad_clip;
+        o[j] = clipf(gg[j], N.grad_clip);
+        o[8 + j] = (hutch && inside) ? hv[j] : 0.f;
+      }
+    }
+    __syncthreads();
+    // t1 ; x1 (value rows; tangent rows = relu' * (z W_x1))
+    layer_gemm<1, 2>(bFF(), L.ldff, N.Wp + N.L[0].w_off, N.L[0].Kp / 16, N.L[0].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc) {
+                       const float b = N.bias[N.L[0].b_off + nt * 16 + c];
+#pragma unroll
+                       for (int i = 0; i < 4; ++i) bT1()[(4 * g + i) * L.ldt1 + nt * 16 + c] = fmaxf(acc[i] + b, 0.f);
+                     });
+    layer_gemm<1, 2>(bX() + 4, L.ldx, N.Wp + N.L[2].w_off, N.L[2].Kp / 16, N.L[2].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc) {
+                       const float b = N.bias[N.L[2].b_off + nt * 16 + c];
+#pragma unroll
+                       for (int i = 0; i < 4; ++i) {
+                         const float pre = acc[i] + b;
+                         const int o = (4 * g + i) * L.ldx1 + nt * 16 + c;
+                         bX1()[o] = fmaxf(pre, 0.f);
+                         const float tz = (q == 0) ? tz1[0][i] : tz1[1][i];
+                         bX1()[16 * L.ldx1 + o] = pre > 0.f ? tz : 0.f;
+                       }
+                     });
+    __syncthreads();
+    // t2 -> st (value rows only) ; x2 on value + tangent rows
+    layer_gemm<1, 2>(bT1(), L.ldt1, N.Wp + N.L[1].w_off, N.L[1].Kp / 16, N.L[1].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc) {
+                       const float b = N.bias[N.L[1].b_off + nt * 16 + c];
+#pragma unroll
+                       for (int i = 0; i < 4; ++i) bCat()[(4 * g + i) * L.ldcat + N.hx2 + nt * 16 + c] = fmaxf(acc[i] + b, 0.f);
+                     });
+    {
+      f32x4 keep = {0, 0, 0, 0};   // value pre-activation of the same tile, handed from m = 0 to m = 1
+      layer_gemm<2, 2>(bX1(), L.ldx1, N.Wp + N.L[3].w_off, N.L[3].Kp / 16, N.L[3].Np / 16, wave, lane,
+                       [&](int q, int nt, int m, f32x4 acc) {
+                         const float b = N.bias[N.L[3].b_off + nt * 16 + c];
+#pragma unroll
+                         for (int i = 0; i < 4; ++i) {
+                           const int o = (4 * g + i) * L.ldcat + nt * 16 + c;
+                           if (m == 0) { keep[i] = acc[i] + b; bCat()[o] = fmaxf(keep[i], 0.f); }
+                           else bCat()[16 * L.ldcat + o] = keep[i] > 0.f ? acc[i] : 0.f;
+                         }
+                       });
+    }
+    __syncthreads();
+    // gate (registers) ; j1
+    float gate[TPW][4];
+    layer_gemm<1, 2>(bCat() + N.hx2, L.ldcat, N.Wp + N.L[4].w_off, N.L[4].Kp / 16, N.L[4].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc) {
+                       const float b = N.bias[N.L[4].b_off + nt * 16 + c];
+#pragma unroll
+                       for (int qq = 0; qq < TPW; ++qq)
+                         if (qq == q) {
+#pragma unroll
+                           for (int i = 0; i < 4; ++i) gate[qq][i] = acc[i] + b;
+                         }
+                     });
+    {
+      f32x4 keep = {0, 0, 0, 0};
+      layer_gemm<2, 2>(bCat(), L.ldcat, N.Wp + N.L[5].w_off, N.L[5].Kp / 16, N.L[5].Np / 16, wave, lane,
+                       [&](int q, int nt, int m, f32x4 acc) {
+                         const float b = N.bias[N.L[5].b_off + nt * 16 + c];
+#pragma unroll
+                         for (int i = 0; i < 4; ++i) {
+                           const int o = (4 * g + i) * L.ldj1 + nt * 16 + c;
+                           if (m == 0) { keep[i] = acc[i] + b; bJ1()[o] = fmaxf(keep[i], 0.f); }
+                           else bJ1()[16 * L.ldj1 + o] = keep[i] > 0.f ? acc[i] : 0.f;
+                         }
+                       });
+    }
+    __syncthreads();
+    {
+      f32x4 keep = {0, 0, 0, 0};
+      layer_gemm<2, 2>(bJ1(), L.ldj1, N.Wp + N.L[6].w_off, N.L[6].Kp / 16, N.L[6].Np / 16, wave, lane,
+                       [&](int q, int nt, int m, f32x4 acc) {
+                         const float b = N.bias[N.L[6].b_off + nt * 16 + c];
+#pragma unroll
+                         for (int i = 0; i < 4; ++i) {
+                           const int o = (4 * g + i) * L.ldj2 + nt * 16 + c;
+                           if (m == 0) { keep[i] = acc[i] + b; bJ2()[o] = fmaxf(keep[i], 0.f); }
+                           else bJ2()[16 * L.ldj2 + o] = keep[i] > 0.f ? acc[i] : 0.f;
+                         }
+                       });
+    }
+    __syncthreads();
+    // out: v = nn_xt + nn_t * clip(grad log pi(x)) (:88-90);  J z = d nn_xt . z + nn_t * 1[|g| <= clip] * (H z)
+    float dpart[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      f32x4 vkeep = {0, 0, 0, 0};
+      layer_gemm<2, 2>(bJ2(), L.ldj2, N.Wp + N.L[7].w_off, N.L[7].Kp / 16, N.L[7].Np / 16, wave, lane,
+                       [&](int q, int nt, int m, f32x4 acc) {
+                         const int col = nt * 16 + c;
+                         const float b = N.bias[N.L[7].b_off + col];
+#pragma unroll
+                         for (int i = 0; i < 4; ++i) {
+                           const int row = 4 * g + i;
+                           float gt = 0.f;
+#pragma unroll
+                           for (int qq = 0; qq < TPW; ++qq) gt = (qq == q) ? gate[qq][i] : gt;
+                           float gc = 0.f, hz = 0.f;
+                           if (col < d) {
+                             if (N.T.kind == MFM_TARGET_PHI4) {
+                               const float* xr = bX() + row * L.ldx + 4;
+                               const float graw = phi4_grad(N.T, xr, col);
+                               gc = clipf(graw, N.grad_clip);
+                               const bool inside = !(N.grad_clip > 0.f) || fabsf(graw) <= N.grad_clip;
+                               if (m == 1 && inside) hz = phi4_hvp(N.T, xr, bZ() + row * L.ldx + 4, col);
+                             } else {
+                               gc = gcs()[row * 24 + col];
+                               hz = gcs()[row * 24 + 8 + col];
+                             }
+                           }
+                           if (m == 0) {
+                             const float v = col < d ? acc[i] + b + gt * gc : 0.f;
+#pragma unroll
+                             for (int qq = 0; qq < TPW; ++qq)
+                               if (qq == q) kv[qq][i] = sign > 0 ? v : -v;
+                           } else if (col < d) {
+                             const float jz = acc[i] + gt * hz;
+                             dpart[i] += bZ()[row * L.ldx + 4 + col] * jz;
+                             if (WANT_JZ) {
+#pragma unroll
+                               for (int qq = 0; qq < TPW; ++qq)
+                                 if (qq == q) jzo[qq][i] = jz;
+                             }
+                           }
+                         }
+                       });
+    }
+    row_reduce(dpart, red_slot);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dl[i] = sign > 0 ? -dpart[i] : dpart[i];     // :218 / :239
+  }
+};
+
+// Integrate the augmented ODE from t = 0 to 1 for the tile whose start positions are in y[][] (accumulator layout);
+// on return y holds the interpolated positions at t = 1, ell the log-det, natt the attempted steps per row.
+// Requires: bZ filled (probe, zero where col >= d), pads of bX / bZ zero, tangent rows of bCat[:, hx2:] zero.
+//
+// ONE call site of the field evaluation, driven by a small state machine (phase 0: f0, phase 1: the extra
+// evaluation of the initial-step heuristic, phases 2..7: the six Runge-Kutta stages), so the kernel carries one copy
+// of the MLP code; stage results are routed into k[.] with predicated moves (static register indices).
+__device__ static const float DP_TAB[8][7] = {   // [phase][j]: input = y + h * sum_j TAB[phase][j] k_j ; last column: time fraction
+    {0, 0, 0, 0, 0, 0, 0.f},
+    {1, 0, 0, 0, 0, 0, 1.f},
+    {1.f / 5, 0, 0, 0, 0, 0, 1.f / 5},
+    {3.f / 40, 9.f / 40, 0, 0, 0, 0, 3.f / 10},
+    {44.f / 45, -56.f / 15, 32.f / 9, 0, 0, 0, 4.f / 5},
+    {19372.f / 6561, -25360.f / 2187, 64448.f / 6561, -212.f / 729, 0, 0, 8.f / 9},
+    {9017.f / 3168, -355.f / 33, 46732.f / 5247, 49.f / 176, -5103.f / 18656, 0, 1.f},
+    {35.f / 384, 0, 500.f / 1113, 125.f / 192, -2187.f / 6784, 11.f / 84, 1.f}};
+
+template <int TPW>
+__device__ __forceinline__ void ode_solve(OdeTile<TPW>& T, float rtol, float atol, int max_attempts,
+                                          float (&y)[TPW][4], float (&ell)[4], int (&natt)[4]) {
+  const NetDev& N = *T.n;
+  const int d = N.d, g = T.g, c = T.c, wave = T.wave;
+  const float inv_n = 1.f / (float)(d + 1);
+  auto colmask = [&](int q) { return (wave + 4 * q) * 16 + c < d; };
+
+  float k[7][TPW][4], kl[7][4];
+  float t[4], dt[4], h0[4], d1[4];
+  bool done[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { t[i] = 0.f; dt[i] = 0.f; h0[i] = 0.f; d1[i] = 0.f; ell[i] = 0.f; natt[i] = 0; done[i] = false; }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kl[j][i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) k[j][q][i] = 0.f;
+  }
+  __syncthreads();
+  if (T.hutch) T.precompute_tz1();      // reads bZ only
+
+  int phase = 0;
+#pragma unroll 1
+  for (;;) {
+    // ---- stage input: y + h * sum_j TAB[phase][j] k_j, written to bX ----
+    float xin[TPW][4], ts[4], hs[4];
+    float cf[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) cf[j] = DP_TAB[phase][j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { hs[i] = phase == 1 ? h0[i] : dt[i]; ts[i] = t[i] + hs[i] * cf[6]; }
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int col = (wave + 4 * q) * 16 + c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc += cf[j] * k[j][q][i];
+        xin[q][i] = y[q][i] + hs[i] * acc;
+      }
+      if (col < N.dp) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) T.bX()[(4 * g + i) * T.L.ldx + 4 + col] = col < d ? xin[q][i] : 0.f;
+      }
+    }
+    __syncthreads();
+    float kv[TPW][4], dlv[4];
+    T.eval(ts, kv, dlv, phase & 1);
+    // ---- route the result: phase 0 -> k[0], phase 1 -> k[1], phase p >= 2 -> k[p - 1] ----
+    const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (j == dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kl[j][i] = dlv[i];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) k[j][q][i] = kv[q][i];
+      }
+
+    if (phase == 0) {
+      // ---- initial step size, part 1 (Hairer II.4, order 4) ----
+      float p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < TPW; ++q)
+        if (colmask(q)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float sc = atol + fabsf(y[q][i]) * rtol;
+            const float a0 = y[q][i] / sc, a1 = k[0][q][i] / sc;
+            p0[i] += a0 * a0; p1[i] += a1 * a1;
+          }
+        }
+      T.row_reduce(p0, 2); T.row_reduce(p1, 3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a1 = kl[0][i] / atol;                              // ell0 = 0 -> scale = atol
+        const float d0 = sqrtf(p0[i]); d1[i] = sqrtf(p1[i] + a1 * a1);
+        h0[i] = (d0 < 1e-5f || d1[i] < 1e-5f) ? 1e-6f : 0.01f * d0 / d1[i];
+      }
+      phase = 1;
+    } else if (phase == 1) {
+      float p2[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < TPW; ++q)
+        if (colmask(q)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float sc = atol + fabsf(y[q][i]) * rtol;
+            const float a2 = (k[1][q][i] - k[0][q][i]) / sc;
+            p2[i] += a2 * a2;
+          }
+        }
+      T.row_reduce(p2, 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a2 = (kl[1][i] - kl[0][i]) / atol;
+        const float d2 = sqrtf(p2[i] + a2 * a2) / h0[i];
+        const float h1 = (d1[i] <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0[i] * 1e-3f)
+                                                           : powf(0.01f / fmaxf(d1[i], d2), 0.2f);
+        dt[i] = fminf(100.f * h0[i], h1);
+      }
+      phase = 2;
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) any |= (dt[i] > 0.f);
+      if (!__syncthreads_or(any ? 1 : 0)) break;
+    } else if (phase < 7) {
+      phase += 1;
+    } else {
+      // ---- end of an attempted step: xin holds y1 (row 7 of the table = 5th-order weights) ----
+      bool active[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) active[i] = !done[i] && natt[i] < max_attempts && dt[i] > 0.f;
+      float e2[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < TPW; ++q)
+        if (colmask(q)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float er = 0.f;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) er += DP_E[j] * k[j][q][i];
+            er *= dt[i];
+            const float tol = atol + rtol * fmaxf(fabsf(y[q][i]), fabsf(xin[q][i]));
+            const float rr = er / tol;
+            e2[i] += rr * rr;
+          }
+        }
+      T.row_reduce(e2, 2);
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float sl = 0.f, el = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sl += DP_TAB[7][j] * kl[j][i];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) el += DP_E[j] * kl[j][i];
+        const float l1 = ell[i] + dt[i] * sl;
+        el *= dt[i];
+        const float tol = atol + rtol * fmaxf(fabsf(ell[i]), fabsf(l1));
+        const float rr = el / tol;
+        const float ratio = sqrtf((e2[i] + rr * rr) * inv_n);
+        const bool acc = active[i] && ratio <= 1.f;
+        const float dfac = ratio < 1.f ? 1.f : 0.2f;
+        const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
+        const float ndt = fmaxf(ratio == 0.f ? dt[i] * 10.f : dt[i] * fac, 0.f);
+        if (acc) {
+          const float tn = t[i] + dt[i];
+          if (tn >= 1.f) {
+            // final output: 4th-order interpolant of this step evaluated at t = 1
+            const float sfrac = (1.f - t[i]) / (tn - t[i]);
+            float lm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) lm += DP_M[j] * kl[j][i];
+            const float y0 = ell[i], y1 = l1, ym = y0 + dt[i] * lm, f0 = dt[i] * kl[0][i], f1 = dt[i] * kl[6][i];
+            const float pa = -2.f * f0 + 2.f * f1 - 8.f * y0 - 8.f * y1 + 16.f * ym;
+            const float pb = 5.f * f0 - 3.f * f1 + 18.f * y0 + 14.f * y1 - 32.f * ym;
+            const float pc = -4.f * f0 + f1 - 11.f * y0 - 5.f * y1 + 16.f * ym;
+            ell[i] = (((pa * sfrac + pb) * sfrac + pc) * sfrac + f0) * sfrac + y0;
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+              float km = 0.f;
+#pragma unroll
+              for (int j = 0; j < 7; ++j) km += DP_M[j] * k[j][q][i];
+              const float x0 = y[q][i], x1 = xin[q][i], xm = x0 + dt[i] * km, g0 = dt[i] * k[0][q][i], g1 = dt[i] * k[6][q][i];
+              const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
+              const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
+              const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
+              y[q][i] = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
+            }
+            done[i] = true;
+          } else {
+            ell[i] = l1;
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) { y[q][i] = xin[q][i]; k[0][q][i] = k[6][q][i]; }
+            kl[0][i] = kl[6][i];
+          }
+          t[i] = tn;
+        }
+        if (active[i]) { dt[i] = ndt; natt[i] += 1; }
+        any |= (!done[i] && natt[i] < max_attempts && dt[i] > 0.f);
+      }
+      // the loop condition must be uniform over the workgroup: every lane only sees its own 4 rows
+      if (!__syncthreads_or(any ? 1 : 0)) break;
+      phase = 2;
+    }
+  }
+}
+
+// fill bZ with the Hutchinson probe of each row (normal(key, (d,)), :212 / :232) or zero it
+template <int TPW>
+__device__ __forceinline__ void fill_probe(OdeTile<TPW>& T, const Key2 (&kz)[4], bool hutch) {
+  const NetDev& N = *T.n;
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int col = (T.wave + 4 * q) * 16 + T.c;
+    if (col < N.dp) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        T.bZ()[(4 * T.g + i) * T.L.ldx + 4 + col] = (hutch && col < N.d) ? (float)normal64(kz[i], (uint32_t)col, (uint32_t)N.d) : 0.f;
+    }
+  }
+}
+
+template <int TPW>
+__device__ __forceinline__ void tile_init(OdeTile<TPW>& T, const NetDev* n, float* lds, bool hutch) {
+  T.n = n; T.L = ode_lds_layout(*n); T.lds = lds;
+  T.lane = threadIdx.x & 63; T.wave = threadIdx.x >> 6; T.g = T.lane >> 4; T.c = T.lane & 15;
+  T.hutch = hutch; T.sign = 1;
+  for (int i = threadIdx.x; i < T.L.total; i += MLP_THREADS) lds[i] = 0.f;     // pads, tangent rows of st, scratch
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { T.tz1[0][i] = 0.f; T.tz1[1][i] = 0.f; }
+  __syncthreads();
+}
+
+template <int TPW>
+__global__ __launch_bounds__(MLP_THREADS) void ode_transform_kernel(OdeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  OdeTile<TPW> T;
+  tile_init(T, &a.net, lds, a.hutch != 0);
+  T.sign = a.direction;
+  const int b0 = blockIdx.x * 16, d = a.net.d;
+  Key2 kz[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = b0 + 4 * T.g + i;
+    kz[i] = a.per_chain_keys ? Key2{a.keys[2 * b], a.keys[2 * b + 1]} : a.key;
+  }
+  fill_probe(T, kz, T.hutch);
+  float y[TPW][4], ell[4]; int natt[4];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int col = (T.wave + 4 * q) * 16 + T.c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[q][i] = col < d ? a.in[(size_t)(b0 + 4 * T.g + i) * d + col] : 0.f;
+  }
+  ode_solve<TPW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int col = (T.wave + 4 * q) * 16 + T.c;
+    if (col < d) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a.out[(size_t)(b0 + 4 * T.g + i) * d + col] = y[q][i];
+    }
+  }
+  if (T.wave == 0 && T.c == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a.ldj[b0 + 4 * T.g + i] = ell[i];
+      if (a.nsteps) a.nsteps[b0 + 4 * T.g + i] = natt[i];
+    }
+  }
+}
+
+// v(x, t) and J z for n samples (mfm_vf_apply): one field evaluation per tile.
+template <int TPW>
+__global__ __launch_bounds__(MLP_THREADS) void vf_apply_kernel(NetDev net, const float* x, const float* t, const float* tan, int n,
+                                                               float* v, float* jvp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  OdeTile<TPW> T;
+  tile_init(T, &net, lds, tan != nullptr);
+  const int b0 = blockIdx.x * 16, d = net.d;
+  float tt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tt[i] = t[b0 + 4 * T.g + i];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int col = (T.wave + 4 * q) * 16 + T.c;
+    if (col < d) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t o = (size_t)(b0 + 4 * T.g + i) * d + col;
+        T.bX()[(4 * T.g + i) * T.L.ldx + 4 + col] = x[o];
+        if (tan) T.bZ()[(4 * T.g + i) * T.L.ldx + 4 + col] = tan[o];
+      }
+    }
+  }
+  __syncthreads();
+  if (tan) T.precompute_tz1();
+  float kv[TPW][4], dl[4], jz[TPW][4];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) jz[q][i] = 0.f;
+  T.template eval<true>(tt, kv, dl, 0, jz);
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int col = (T.wave + 4 * q) * 16 + T.c;
+    if (col < d) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t o = (size_t)(b0 + 4 * T.g + i) * d + col;
+        v[o] = kv[q][i];
+        if (jvp) jvp[o] = jz[q][i];
+      }
+    }
+  }
+}
+
+// One flow-based MH step per chain (random-walk in latent space :264-278, or independent :246-260).
+template <int TPW>
+__global__ __launch_bounds__(MLP_THREADS) void flow_step_kernel(OdeArgs a, FlowArgs f) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  OdeTile<TPW> T;
+  tile_init(T, &a.net, lds, a.hutch != 0);
+  const NetDev& N = a.net;
+  const int b0 = blockIdx.x * 16, d = N.d, g = T.g, c = T.c, wave = T.wave;
+  Key2 k_gen[4], k_acc[4], k_h1[4], k_h2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const Key2 kb = split_at(f.key, f.n_total, f.chain_offset + (uint32_t)(b0 + 4 * g + i));     // :303
+    k_gen[i] = split_at(kb, 4, 0); k_acc[i] = split_at(kb, 4, 1);                                // :265 / :247
+    k_h1[i] = split_at(kb, 4, 2); k_h2[i] = split_at(kb, 4, 3);
+  }
+  float y[TPW][4], ell[4], vol0[4], lq_ref[4] = {0, 0, 0, 0};
+  int natt[4], natt_tot[4];
+  // ---- inverse solve from the current position (:267 / :251) ----
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int col = (wave + 4 * q) * 16 + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[q][i] = col < d ? f.pos[(size_t)(b0 + 4 * g + i) * d + col] : 0.f;
+  }
+  fill_probe(T, k_h2, T.hutch);
+  T.sign = -1;
+  ode_solve<TPW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { vol0[i] = ell[i]; natt_tot[i] = natt[i]; }
+  // ---- proposal in latent space ----
+  {
+    float r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
+    const float scale = 2.38f / sqrtf((float)d);                                                  // :262
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int col = (wave + 4 * q) * 16 + c;
+      if (col < d) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float nz = (float)normal64(k_gen[i], (uint32_t)col, (uint32_t)d);
+          if (f.mode == MFM_FLOW_RWMH) y[q][i] = y[q][i] + scale * nz;                            // :268
+          else { r0[i] += y[q][i] * y[q][i]; y[q][i] = nz; r1[i] += nz * nz; }                    // :249
+        }
+      }
+    }
+    if (f.mode == MFM_FLOW_IMH) {     // ref.logprob(u0) - ref.logprob(up) = -(|u0|^2 - |up|^2) / 2   (:254-255)
+      __syncthreads();
+      T.row_reduce(r0, 5); T.row_reduce(r1, 6);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lq_ref[i] = -0.5f * (r0[i] - r1[i]);
+    }
+  }
+  // ---- forward solve of the proposal (:269 / :250) ----
+  __syncthreads();
+  fill_probe(T, k_h1, T.hutch);
+  T.sign = 1;
+  ode_solve<TPW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
+  // ---- target at the proposal (:270 / :252), tempered: beta * loglik + logprior ----
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int col = (wave + 4 * q) * 16 + c;
+    if (col < N.dp) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) T.bX()[(4 * g + i) * T.L.ldx + 4 + col] = col < d ? y[q][i] : 0.f;
+    }
+  }
+  __syncthreads();
+  double lpn[4];
+  float gnew[TPW][4];
+  if (N.T.kind == MFM_TARGET_PHI4) {
+    double part[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int col = (wave + 4 * q) * 16 + c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        gnew[q][i] = 0.f;
+        if (col < d) {
+          const float* xr = T.bX() + (4 * g + i) * T.L.ldx + 4;
+          part[i] += phi4_term(N.T, xr, col);
+          gnew[q][i] = (float)f.beta * phi4_grad(N.T, xr, col);
+        }
+      }
+    }
+    double* rd = reinterpret_cast<double*>(T.red(0));      // slots 0..1 as [4 waves][16 rows] doubles
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) part[i] += __shfl_xor(part[i], o, 64);
+      if (c == 0) rd[wave * 16 + 4 * g + i] = part[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int row = 4 * g + i; lpn[i] = f.beta * (rd[row] + rd[16 + row] + rd[32 + row] + rd[48 + row]); }
+  } else {
+    double* rd = reinterpret_cast<double*>(T.red(0));
+    if (threadIdx.x < 16) {
+      double lp; float gg[8];
+      gmm_eval<8>(N.T, T.bX() + threadIdx.x * T.L.ldx + 4, &lp, gg);
+      rd[threadIdx.x] = lp;
+      for (int j = 0; j < d; ++j) T.gcs()[threadIdx.x * 24 + j] = gg[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lpn[i] = f.beta * rd[4 * g + i];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int col = (wave + 4 * q) * 16 + c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gnew[q][i] = col < d ? (float)f.beta * T.gcs()[(4 * g + i) * 24 + col] : 0.f;
+    }
+  }
+  // ---- accept / reject (:271-278 / :253-260); the acceptance probability is NOT clipped ----
+  bool acc[4];
+  float aprob[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = b0 + 4 * g + i;
+    const double lp_old = f.logp[b];
+    const double la = lpn[i] - (double)ell[i] - lp_old - (double)vol0[i] + (double)lq_ref[i];
+    const double ap = exp(la);
+    const double u = uniform01(k_acc[i], 0, 1);
+    acc[i] = u <= ap;                     // NaN compares false -> reject
+    aprob[i] = (float)ap;
+  }
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int col = (wave + 4 * q) * 16 + c;
+    if (col < d) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t o = (size_t)(b0 + 4 * g + i) * d + col;
+        if (f.proposed) f.proposed[o] = y[q][i];
+        if (acc[i]) { f.pos[o] = y[q][i]; f.grad[o] = gnew[q][i]; }
+      }
+    }
+  }
+  if (wave == 0 && c == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = b0 + 4 * g + i;
+      if (acc[i]) f.logp[b] = lpn[i];
+      if (f.acc_prob) f.acc_prob[b] = aprob[i];
+      if (f.accepted) f.accepted[b] = acc[i] ? 1 : 0;
+      if (f.nsteps) f.nsteps[b] = natt_tot[i] + natt[i];
+    }
+  }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------
+static int ode_check(const NetDev& n, size_t& sm, int& tpw) {
+  const OdeLds L = ode_lds_layout(n);
+  sm = (size_t)L.total * sizeof(float);
+  tpw = (n.dp / 16 + 3) / 4;
+  if (sm > 160 * 1024 || tpw > 4 || n.hx1 > 128) return -3;
+  return 0;
+}
+#define ODE_LAUNCH(KERN, GRID, ...)                                                                                    \
+  do {                                                                                                                 \
+    if (tpw <= 1) {                                                                                                    \
+      (void)hipFuncSetAttribute((const void*)KERN<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                 \
+      hipLaunchKernelGGL(KERN<1>, GRID, dim3(MLP_THREADS), sm, stream, __VA_ARGS__);                                  \
+    } else {                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)KERN<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                 \
+      hipLaunchKernelGGL(KERN<4>, GRID, dim3(MLP_THREADS), sm, stream, __VA_ARGS__);                                  \
+    }                                                                                                                  \
+  } while (0)
+
+int launch_ode_transform(const OdeArgs& a, hipStream_t stream) {
+  size_t sm; int tpw;
+  if (ode_check(a.net, sm, tpw)) return -3;
+  if (!a.hutch) return -2;   // exact trace: see launch_flow_step
+  ODE_LAUNCH(ode_transform_kernel, dim3(a.n / 16), a);
+  return 0;
+}
+int launch_vf_apply(const NetDev& n, const float* x, const float* t, const float* tan, int cnt, float* v, float* jvp, hipStream_t stream) {
+  size_t sm; int tpw;
+  if (ode_check(n, sm, tpw)) return -3;
+  ODE_LAUNCH(vf_apply_kernel, dim3(cnt / 16), n, x, t, tan, cnt, v, jvp);
+  return 0;
+}
+int launch_flow_step(const OdeArgs& a, const FlowArgs& f, hipStream_t stream) {
+  size_t sm; int tpw;
+  if (ode_check(a.net, sm, tpw)) return -3;
+  if (!a.hutch) return -2;
+  ODE_LAUNCH(flow_step_kernel, dim3(a.n / 16), a, f);
+  return 0;
+}

@@ -1,0 +1,133 @@
+// K7: apply_if_finite(chain(adamw(mask = not-bias), clip(+-c)), 10) as ONE elementwise kernel that also re-emits the
+// MFMA-operand-ready packed weights (forward and transposed) the MLP kernels stream.
+//
+// Replaces state.apply_gradients at exe_flow_matching.py:366 with the optimizer of :129-137,184 (optax 0.1.9 rules:
+// SURVEY.md section 8c).  Quirks kept: the clip acts on the final UPDATE (Q5); the schedule value is
+// lr * (1 - count / learning_iter) at the inner optimizer's pre-increment count (Q6), which only advances on accepted
+// updates; a non-finite gradient zeroes the update and leaves the inner state untouched, up to 10 in a row.
+//
+// The finite check and the step counters live on the device (OptState) so an iteration needs no host sync.
+#include "mlp.cuh"
+
+struct OptState {        // device-resident scalars
+  int step;              // TrainState.step (every call)
+  int count;             // inner adam / schedule count (accepted updates only)
+  int notfinite_count;   // consecutive non-finite gradients
+  int last_applied;      // 1 if the last call changed the parameters
+  float last_lr;         // learning_rate_fn(state.step) as logged at :367 (pre-increment step)
+};
+
+struct AdamArgs {
+  NetDev net;
+  const float* grads; int n_slabs;     // grads = sum over n_slabs slabs of n_params floats
+  float* master; float* mu; float* nu; // canonical flat layout
+  float* Wp; float* WpT; float* bias;  // packed outputs
+  OptState* st;
+  int* flag;                           // scratch: non-finite flag (zeroed by the check kernel's predecessor)
+  double lr0; int learning_iter, warmup;
+  double b1, b2; float eps, wd, clip;
+  int max_err;
+};
+
+__global__ void finite_check_kernel(const float* grads, int n_slabs, int n, int* flag) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (p < n) {
+    float s = 0.f;
+    for (int k = 0; k < n_slabs; ++k) s += grads[(size_t)k * n + p];
+    bad = !isfinite(s);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__device__ __forceinline__ float lr_schedule(double lr0, int learning_iter, int warmup, int count) {
+  // join_schedules([linear(0 -> lr, warmup), linear(lr -> 0, learning_iter - warmup)], [warmup]) (:189-198)
+  if (warmup > 0 && count < warmup) return (float)(lr0 * ((double)count / (double)warmup));
+  const int ts = learning_iter - warmup;
+  if (ts <= 0) return (float)lr0;
+  int cc = count - warmup; cc = cc < 0 ? 0 : (cc > ts ? ts : cc);
+  return (float)(lr0 * (1.0 - (double)cc / (double)ts));
+}
+
+// One thread decides; every thread of the grid must see the same decision -> the decision kernel runs alone first.
+__global__ void opt_decide_kernel(OptState* st, int* flag, double lr0, int learning_iter, int warmup, int max_err) {
+  const bool finite = (*flag == 0);
+  st->notfinite_count = finite ? 0 : st->notfinite_count + 1;
+  st->last_lr = lr_schedule(lr0, learning_iter, warmup, st->step);
+  st->step += 1;
+  st->last_applied = (finite || st->notfinite_count > max_err) ? 1 : 0;
+  *flag = 0;
+}
+
+__global__ void adamw_kernel(AdamArgs a) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const NetDev& n = a.net;
+  if (p >= n.n_params) return;
+  const bool apply = a.st->last_applied != 0;
+  float w = a.master[p];
+  // locate (layer, kernel/bias, k, nn)
+  int layer = 0;
+#pragma unroll
+  for (int l = 1; l < MLP_NLAYER; ++l) if (p >= n.L[l].m_w) layer = l;
+  const LayerDesc& ld = n.L[layer];
+  const bool is_bias = p >= ld.m_b;
+  if (apply) {
+    float gsum = 0.f;
+    for (int k = 0; k < a.n_slabs; ++k) gsum += a.grads[(size_t)k * n.n_params + p];
+    const int c1 = a.st->count + 1;
+    const float bc1 = (float)(1.0 - pow(a.b1, (double)c1));
+    const float bc2 = (float)(1.0 - pow(a.b2, (double)c1));
+    const float b1 = (float)a.b1, b2 = (float)a.b2;
+    const float m = b1 * a.mu[p] + (1.f - b1) * gsum;
+    const float v = b2 * a.nu[p] + (1.f - b2) * gsum * gsum;
+    a.mu[p] = m; a.nu[p] = v;
+    float u = (m / bc1) / (sqrtf(v / bc2) + a.eps);
+    if (!is_bias) u += a.wd * w;
+    u = -lr_schedule(a.lr0, a.learning_iter, a.warmup, a.st->count) * u;
+    u = fminf(fmaxf(u, -a.clip), a.clip);
+    w += u;
+    a.master[p] = w;
+  }
+  // re-emit packed copies (also on rejected updates: cheap, keeps the kernel branch-free for the packer)
+  if (is_bias) {
+    a.bias[ld.b_off + (p - ld.m_b)] = w;
+  } else {
+    const int e = p - ld.m_w, k = e / ld.N, nn = e - k * ld.N;
+    int kk = k;
+    a.Wp[ld.w_off + pack_index(kk, nn, ld.Kp / 16)] = w;
+    a.WpT[ld.w_off + pack_index_T(kk, nn, ld.Np / 16)] = w;
+  }
+}
+
+__global__ void opt_commit_kernel(OptState* st) {
+  if (st->last_applied) st->count += 1;
+}
+
+void launch_adamw(const AdamArgs& a, hipStream_t stream) {
+  const int n = a.net.n_params;
+  dim3 grid((n + 255) / 256), block(256);
+  hipLaunchKernelGGL(finite_check_kernel, grid, block, 0, stream, a.grads, a.n_slabs, n, a.flag);
+  hipLaunchKernelGGL(opt_decide_kernel, dim3(1), dim3(1), 0, stream, a.st, a.flag, a.lr0, a.learning_iter, a.warmup, a.max_err);
+  hipLaunchKernelGGL(adamw_kernel, grid, block, 0, stream, a);
+  hipLaunchKernelGGL(opt_commit_kernel, dim3(1), dim3(1), 0, stream, a.st);
+}
+
+// pack only (after mfm_set_params)
+__global__ void pack_kernel(NetDev n, const float* master, float* Wp, float* WpT, float* bias) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n.n_params) return;
+  int layer = 0;
+#pragma unroll
+  for (int l = 1; l < MLP_NLAYER; ++l) if (p >= n.L[l].m_w) layer = l;
+  const LayerDesc& ld = n.L[layer];
+  const float w = master[p];
+  if (p >= ld.m_b) bias[ld.b_off + (p - ld.m_b)] = w;
+  else {
+    const int e = p - ld.m_w, k = e / ld.N, nn = e - k * ld.N;
+    Wp[ld.w_off + pack_index(k, nn, ld.Kp / 16)] = w;
+    WpT[ld.w_off + pack_index_T(k, nn, ld.Np / 16)] = w;
+  }
+}
+void launch_pack(const NetDev& n, const float* master, float* Wp, float* WpT, float* bias, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_kernel, dim3((n.n_params + 255) / 256), dim3(256), 0, stream, n, master, Wp, WpT, bias);
+}

@@ -1,0 +1,99 @@
+// Target densities evaluated on the device: value, gradient and Hessian-vector product, per chain row.
+// Follows distributions.py:114-165 (PhiFour, Dirichlet b.c.), :42-77 (GaussianMixture, diagonal) and
+// :231-314 (LogGaussianCoxPines, unwhitened).  The reference differentiates with jax.grad / jax.jvp; these are
+// the closed forms, checked against the CPU oracle in tests/test_gpu_*.py.
+//
+// Row convention: a chain's position lives in an LDS row `xs` with one zero pad on EACH side
+// (xs[-1] = xs[d] = 0), so the PhiFour stencil needs no branches.
+#pragma once
+#include "common.cuh"
+
+enum { MFM_TARGET_PHI4 = 0, MFM_TARGET_GMM = 1, MFM_TARGET_LGCP = 2 };
+
+#define MFM_GMM_MAX_MODES 64
+
+struct TargetDev {
+  int kind;
+  int dim;
+  // phi4
+  float coef;      // a * dim
+  float tbeta;     // the model's own beta (20), NOT the annealing temperature
+  // gmm (dim == 2 as the reference forces, distributions.py:53; general small dim supported)
+  int n_modes;
+  const float* gmm_mode;   // [K, d]
+  const float* gmm_std;    // [K, d]
+  const float* gmm_logw;   // [K]  log w_k - sum_j log s_kj - d/2 log 2pi
+  // lgcp
+  const float* counts;     // [d]
+  const float* Kinv;       // [d, d] (symmetric)
+  float mu, poisson_a, log_norm;
+};
+
+// ---- PhiFour --------------------------------------------------------------------------------------
+// loglik terms of element j (to be summed over j): -beta (coef/2 (x_{j+1}-x_j)^2 [+ left edge] + (1-x^2)^2/(4 coef))
+__device__ __forceinline__ float phi4_grad(const TargetDev& T, const float* xs, int j) {
+  float x = xs[j];
+  float lap = 2.f * x - xs[j - 1] - xs[j + 1];
+  return -T.tbeta * (T.coef * lap - x * (1.f - x * x) / T.coef);
+}
+__device__ __forceinline__ double phi4_term(const TargetDev& T, const float* xs, int j) {
+  // each bond (j, j+1) counted once, plus the left boundary bond for j == 0
+  double x = xs[j];
+  double dr = (double)xs[j + 1] - x;
+  double u = dr * dr;
+  if (j == 0) u += x * x;
+  double q = 1.0 - x * x;
+  return -(double)T.tbeta * (0.5 * (double)T.coef * u + q * q / (4.0 * (double)T.coef));
+}
+__device__ __forceinline__ float phi4_hvp(const TargetDev& T, const float* xs, const float* vs, int j) {
+  float x = xs[j], v = vs[j];
+  float lap = 2.f * v - vs[j - 1] - vs[j + 1];
+  return -T.tbeta * (T.coef * lap - (1.f - 3.f * x * x) * v / T.coef);
+}
+
+// ---- Gaussian mixture (evaluated by ONE lane for a whole row; d is tiny) ----------------------------------
+// log-sum-exp form: algebraically identical to the reference's log(sum_k w_k prod_j pdf) (distributions.py:59-61)
+// but does not underflow in float32 ("fp32 vs the reference's fp64").
+template <int MAXD>
+__device__ __forceinline__ void gmm_eval(const TargetDev& T, const float* x, double* logp, float* grad,
+                                         const float* v = nullptr, float* hv = nullptr) {
+  const int d = T.dim, K = T.n_modes;
+  float lw[MFM_GMM_MAX_MODES];
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    float s = T.gmm_logw[k];
+    for (int j = 0; j < d; ++j) {
+      float z = (x[j] - T.gmm_mode[k * d + j]) / T.gmm_std[k * d + j];
+      s -= 0.5f * z * z;
+    }
+    lw[k] = s;
+    m = fmaxf(m, s);
+  }
+  float se = 0.f;
+  for (int k = 0; k < K; ++k) { lw[k] = __expf(lw[k] - m); se += lw[k]; }
+  *logp = (double)m + (double)__logf(se);
+  float g[MAXD], t1[MAXD];
+  for (int j = 0; j < d; ++j) { g[j] = 0.f; t1[j] = 0.f; }
+  for (int k = 0; k < K; ++k) {
+    float r = lw[k] / se;
+    float av = 0.f;
+    float a[MAXD];
+    for (int j = 0; j < d; ++j) {
+      float sd = T.gmm_std[k * d + j];
+      a[j] = -(x[j] - T.gmm_mode[k * d + j]) / (sd * sd);
+      g[j] += r * a[j];
+      if (v) av += a[j] * v[j];
+    }
+    if (v)
+      for (int j = 0; j < d; ++j) {
+        float sd = T.gmm_std[k * d + j];
+        t1[j] += r * (a[j] * av - v[j] / (sd * sd));
+      }
+  }
+  for (int j = 0; j < d; ++j) grad[j] = g[j];
+  if (v) {
+    float gv = 0.f;
+    for (int j = 0; j < d; ++j) gv += g[j] * v[j];
+    for (int j = 0; j < d; ++j) hv[j] = t1[j] - g[j] * gv;
+  }
+}

@@ -1,0 +1,77 @@
+"""Helpers shared by the -m gpu parity tests: build a device context that mirrors an oracle setup."""
+import numpy as np
+
+from oracle import loop, prng, targets
+from oracle.vfield import VectorFieldNet
+
+
+def flat_params(params):
+    return np.concatenate([np.concatenate([p["kernel"].reshape(-1), p["bias"].reshape(-1)]) for p in params]).astype(np.float32)
+
+
+def unflat_params(model, flat):
+    out, o = [], 0
+    for (fi, fo) in model.layer_shapes():
+        W = flat[o:o + fi * fo].reshape(fi, fo); o += fi * fo
+        b = flat[o:o + fo]; o += fo
+        out.append({"kernel": W.astype(np.float32), "bias": b.astype(np.float32)})
+    return out
+
+
+def rand_params(model, seed=0, scale=1.0, out_scale=0.3):
+    """Non-trivial parameters (the flax init has zero output kernels => v == 0, useless for parity)."""
+    rng = np.random.default_rng(seed)
+    ps = []
+    zl = model.zero_layers()
+    for i, (fi, fo) in enumerate(model.layer_shapes()):
+        s = (out_scale if i in zl else scale) / np.sqrt(fi)
+        ps.append({"kernel": (rng.standard_normal((fi, fo)) * s).astype(np.float32),
+                   "bias": (rng.standard_normal(fo) * 0.05).astype(np.float32)})
+    return ps
+
+
+def target_block(dist):
+    from mfm_amd import _lib
+    if dist.kind == "phi4":
+        return _lib.PHI4, [dist.a, dist.beta]
+    if dist.kind == "gmm":
+        K = len(dist.weights)
+        return _lib.GMM, np.concatenate([[K], dist.modes.reshape(-1), dist.chol_covs.reshape(-1), dist.weights])
+    raise NotImplementedError(dist.kind)
+
+
+def make_ctx(dist, args, n_local=None, n_total=None, offset=0, fourier=None, params=None, max_eval=0):
+    from mfm_amd import _lib
+    n_local = args.num_chain if n_local is None else n_local
+    ctx = _lib.Context(
+        dim=args.dim, fourier_dim=args.fourier_dim, hidden_t=args.hidden_t, hidden_x=args.hidden_x,
+        hidden_xt=args.hidden_xt, n_chain_local=n_local, n_chain_total=n_total or n_local, chain_offset=offset,
+        grad_clip=(args.gradient_clip if args.dim > 128 else 0.0), sigma=args.sigma, cond_flow=int(args.cond_flow),
+        hutch=int(args.hutchs), rtol=args.rtol, atol=args.atol, mxstep=int(args.mxstep), n_ts=args.n_ts,
+        learning_rate=args.learning_rate, adam_b1=args.adam_beta1, adam_b2=args.adam_beta2, adam_eps=args.adam_epsilon,
+        weight_decay=args.weight_decay, update_clip=args.gradient_clip, learning_iter=args.learning_iter,
+        warmup_steps=args.warmup_steps, max_eval_samples=max_eval)
+    kind, blk = target_block(dist)
+    ctx.set_target(kind, blk)
+    if fourier is not None:
+        ctx.set_fourier(fourier)
+    if params is not None:
+        ctx.set_params(flat_params(params))
+    return ctx
+
+
+def phi4_setup(d=256, B=64, seed=1, hutch=True, hidden=128, F=128, **kw):
+    args = loop.default_args(example="phi-four", dim=d, num_chain=B, hutchs=hutch, step_size=1e-4, seed=seed,
+                             fourier_dim=F, hidden_x=[hidden, hidden], hidden_t=[hidden, hidden],
+                             hidden_xt=[hidden, hidden], **kw)
+    dist = targets.PhiFour(d)
+    k, model, state, lr_fn, _, _ = loop.setup(dist, args)
+    return args, dist, k, model, state
+
+
+def gmm4_setup(B=64, seed=1, hidden=32, F=16, **kw):
+    args = loop.default_args(example="4-mode", dim=2, num_chain=B, step_size=0.2, seed=seed, fourier_dim=F,
+                             hidden_x=[hidden, hidden], hidden_t=[hidden, hidden], hidden_xt=[hidden, hidden], **kw)
+    dist = targets.GaussianMixture(8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4)
+    k, model, state, lr_fn, _, _ = loop.setup(dist, args)
+    return args, dist, k, model, state

@@ -1,0 +1,131 @@
+"""GPU parity: flow-matching loss + parameter gradient, AdamW chain, eval loss, vector field / JVP -- vs the oracle."""
+import numpy as np
+import pytest
+
+from oracle import fm, optim, prng
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x, dtype=None):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda()
+
+
+def _relerr(a, b):
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+@pytest.mark.parametrize("setup,d,B,hidden,F", [("phi4", 256, 64, 128, 128), ("phi4", 64, 32, 32, 16), ("phi4", 40, 16, 48, 10),
+                                               ("gmm", 2, 64, 32, 16)])
+def test_fm_loss_and_grad_match_oracle(setup, d, B, hidden, F):
+    import torch
+    from tests import gpu_util as gu
+    if setup == "phi4":
+        args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=hidden, F=F)
+    else:
+        args, dist, k, model, state = gu.gmm4_setup(B=B, hidden=hidden, F=F)
+    params = gu.rand_params(model, seed=3)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+    np.testing.assert_array_equal(ctx.get_params(), gu.flat_params(params))
+    x32 = dist.init_params.astype(np.float32)
+    key = prng.PRNGKey(11)
+    loss_o, grads_o = fm.loss_and_grad(model, params, key, x32.astype(np.float64), args.sigma)
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctx.n_params, device="cuda")
+    ctx.fm_loss_grad(key, _dev(x32), loss, grads)
+    assert abs(loss.item() - loss_o) <= 2e-5 * abs(loss_o), (loss.item(), loss_o)
+    g = gu.unflat_params(model, grads.cpu().numpy())
+    for i, (gg, go) in enumerate(zip(g, grads_o)):
+        for kk in ("kernel", "bias"):
+            assert _relerr(gg[kk], go[kk].astype(np.float64)) < 2e-4, (i, kk, _relerr(gg[kk], go[kk]))
+    # eval-only loss (eval_step, exe_flow_matching.py:370-374) on the same samples
+    l2 = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ctx.fm_loss(key, _dev(x32), l2)
+    assert abs(l2.item() - loss_o) <= 2e-5 * abs(loss_o)
+    ctx.close()
+
+
+def test_fm_zero_init_loss_is_target_norm():
+    import torch
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.phi4_setup(d=256, B=32)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=state.params)      # flax-style init: zero output kernels
+    x32 = dist.init_params.astype(np.float32)
+    key = prng.PRNGKey(2)
+    t, cond, target = fm.cond_flow_batch(key, x32.astype(np.float64), args.sigma)
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctx.n_params, device="cuda")
+    ctx.fm_loss_grad(key, _dev(x32), loss, grads)
+    assert abs(loss.item() - (target ** 2).sum()) < 1e-5 * (target ** 2).sum()
+    ctx.close()
+
+
+def test_fm_sharded_loss_and_grads_sum_to_unsharded():
+    import torch
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.phi4_setup(d=64, B=64, hidden=32, F=16)
+    params = gu.rand_params(model, seed=4)
+    x32 = dist.init_params.astype(np.float32)
+    key = prng.PRNGKey(8)
+    tot_l, tot_g = 0.0, 0.0
+    for (n_local, off) in [(64, 0), (32, 0), (32, 32)]:
+        ctx = gu.make_ctx(dist, args, n_local=n_local, n_total=64, offset=off, fourier=model.f, params=params)
+        loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctx.n_params, device="cuda")
+        ctx.fm_loss_grad(key, _dev(x32[off:off + n_local]), loss, grads)
+        if n_local == 64:
+            full_l, full_g = loss.item(), grads.cpu().numpy().astype(np.float64)
+        else:
+            tot_l += loss.item(); tot_g = tot_g + grads.cpu().numpy().astype(np.float64)
+        ctx.close()
+    assert abs(tot_l - full_l) < 1e-9 * abs(full_l)
+    assert _relerr(tot_g, full_g) < 1e-5
+
+
+def test_adamw_chain_matches_oracle():
+    import torch
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.phi4_setup(d=64, B=32, hidden=32, F=16, learning_iter=9)
+    params = gu.rand_params(model, seed=5)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+    st = optim.TrainState(params, optim.learning_rate_fn(9, 0, args.learning_rate))
+    rng = np.random.default_rng(0)
+    for it in range(6):
+        g = [{kk: (rng.standard_normal(v.shape) * 3).astype(np.float32) for kk, v in p.items()} for p in params]
+        if it == 2:
+            g[1]["kernel"][0, 0] = np.inf                               # rejected update: state untouched
+        st.apply_gradients(g)
+        ctx.adamw_step(_dev(gu.flat_params(g)))
+        s = ctx.opt_state()
+        assert (s["step"], s["count"], s["notfinite_count"]) == (st.step, st.count, st.notfinite_count)
+        np.testing.assert_allclose(ctx.get_params(), gu.flat_params(st.params), rtol=3e-6, atol=1e-7)
+    # the packed copies the kernels read must follow the master parameters: loss after the updates matches the oracle
+    x32 = dist.init_params.astype(np.float32)
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ctx.fm_loss(prng.PRNGKey(1), _dev(x32), loss)
+    lo, _ = fm.loss_and_grad(model, st.params, prng.PRNGKey(1), x32.astype(np.float64), args.sigma, need_grad=False)
+    assert abs(loss.item() - lo) < 3e-5 * abs(lo)
+    ctx.close()
+
+
+@pytest.mark.parametrize("setup,d,hidden,F", [("phi4", 256, 128, 128), ("phi4", 40, 32, 10), ("gmm", 2, 32, 16)])
+def test_vector_field_and_jvp_match_oracle(setup, d, hidden, F):
+    import torch
+    from tests import gpu_util as gu
+    B = 32
+    if setup == "phi4":
+        args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=hidden, F=F)
+    else:
+        args, dist, k, model, state = gu.gmm4_setup(B=B, hidden=hidden, F=F)
+    params = gu.rand_params(model, seed=6)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+    rng = np.random.default_rng(1)
+    x = dist.init_params.astype(np.float32); t = rng.uniform(0, 1, B).astype(np.float32)
+    z = rng.standard_normal((B, d)).astype(np.float32)
+    v_o, jv_o = model.forward(params, x.astype(np.float64), t.astype(np.float64), tangent=z.astype(np.float64))
+    v = torch.empty(B, d, device="cuda"); jv = torch.empty(B, d, device="cuda")
+    ctx.vf_apply(_dev(x), _dev(t), v, _dev(z), jv)
+    assert _relerr(v.cpu().numpy(), v_o) < 2e-5
+    assert _relerr(jv.cpu().numpy(), jv_o) < 2e-5
+    v2 = torch.empty(B, d, device="cuda")
+    ctx.vf_apply(_dev(x), _dev(t), v2)
+    assert _relerr(v2.cpu().numpy(), v_o) < 2e-5
+    ctx.close()

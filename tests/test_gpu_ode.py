@@ -1,0 +1,99 @@
+"""GPU parity: Dopri5 CNF transforms with Hutchinson log-det and the flow-MH step -- vs the float64 oracle."""
+import numpy as np
+import pytest
+
+from oracle import flow, mala, ode, prng, targets
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x, dtype=None):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda()
+
+
+def _setup(d, B, hidden, F, seed=9, out_scale=0.5):
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=hidden, F=F)
+    params = gu.rand_params(model, seed=seed, out_scale=out_scale)
+    if d <= 128:
+        # without the +-1 clip the gate * grad log pi term (|grad| ~ 1e3) would make the field stiff: tame the gate layer
+        params[4]["kernel"] *= 1e-3; params[4]["bias"] *= 1e-3
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+    return args, dist, model, params, ctx
+
+
+@pytest.mark.parametrize("d,hidden,F", [(256, 128, 128), (64, 32, 16)])
+def test_ode_transform_and_inverse_match_oracle(d, hidden, F):
+    import torch
+    B = 32
+    args, dist, model, params, ctx = _setup(d, B, hidden, F)
+    x32 = dist.init_params.astype(np.float32)
+    keys = prng.split(prng.PRNGKey(21), B)
+    for direction, fn in ((1, ode.transform_and_logdet), (-1, ode.inverse_and_logdet)):
+        st = {}
+        y_o, l_o = fn(model, params, keys, x32.astype(np.float64), True, args.rtol, args.atol, args.mxstep, stats=st)
+        out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda")
+        ns = torch.empty(B, dtype=torch.int32, device="cuda")
+        ctx.ode_transform(direction, _dev(x32), out, ldj, keys=_dev(keys.astype(np.uint32).view(np.int32)), nsteps=ns)
+        y, l, n = out.cpu().numpy(), ldj.cpu().numpy(), ns.cpu().numpy()
+        assert np.abs(y - x32).max() > 1e-2                      # the flow actually moves the points
+        assert np.abs(y - y_o).max() < 2e-4 * max(1.0, np.abs(y_o).max()), np.abs(y - y_o).max()
+        assert np.abs(l - l_o).max() < 2e-3 * max(1.0, np.abs(l_o).max()), (np.abs(l - l_o).max(), np.abs(l_o).max())
+        assert np.abs(n - st["n_attempted"]).max() <= 2 and (n == st["n_attempted"]).mean() > 0.7
+    # shared key (final sampling, exe_flow_matching.py:455)
+    y_o, l_o = ode.transform_and_logdet(model, params, prng.PRNGKey(4), x32.astype(np.float64), True, args.rtol, args.atol, args.mxstep)
+    out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda")
+    ctx.ode_transform(1, _dev(x32), out, ldj, key=prng.PRNGKey(4))
+    assert np.abs(out.cpu().numpy() - y_o).max() < 2e-4 * max(1.0, np.abs(y_o).max())
+    # round trip: inverse(transform(x)) == x (size-independent property, deterministic given the probe keys)
+    back = torch.empty(B, d, device="cuda"); l2 = torch.empty(B, device="cuda")
+    ctx.ode_transform(-1, out, back, l2, key=prng.PRNGKey(4))
+    assert np.abs(back.cpu().numpy() - x32).max() < 5e-4
+    np.testing.assert_allclose(l2.cpu().numpy(), ldj.cpu().numpy(), atol=5e-3 * max(1.0, np.abs(l_o).max()))
+    ctx.close()
+
+
+def test_ode_identity_flow_at_zero_init():
+    import torch
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.phi4_setup(d=256, B=16)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=state.params)
+    x32 = dist.init_params.astype(np.float32)
+    out = torch.empty(16, 256, device="cuda"); ldj = torch.empty(16, device="cuda"); ns = torch.empty(16, dtype=torch.int32, device="cuda")
+    ctx.ode_transform(1, _dev(x32), out, ldj, key=prng.PRNGKey(1), nsteps=ns)
+    np.testing.assert_array_equal(out.cpu().numpy(), x32)
+    np.testing.assert_array_equal(ldj.cpu().numpy(), 0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("d,hidden,F", [(256, 128, 128), (64, 32, 16)])
+def test_flow_rwmh_step_matches_oracle(d, hidden, F):
+    import torch
+    B = 32
+    args, dist, model, params, ctx = _setup(d, B, hidden, F, out_scale=0.05)
+    beta = 0.8
+    vg = targets.Tempered(dist, beta).value_and_grad
+    x32 = dist.init_params.astype(np.float32)
+    pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+    ctx.mala_init(pos, beta, logp, grad)
+    st = mala.MALAState(x32.astype(np.float64), logp.cpu().numpy(), grad.cpu().numpy().astype(np.float64))
+    key = prng.PRNGKey(31)
+    stats = {}
+    new, info = flow.rwmh_step(prng.split(key, B), st, vg, model, params, args, stats)
+    acc = torch.empty(B, device="cuda"); isacc = torch.empty(B, dtype=torch.uint8, device="cuda")
+    prop = torch.empty(B, d, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
+    from mfm_amd import _lib
+    ctx.flow_step(_lib.FLOW_RWMH, key, beta, pos, logp, grad, acc, isacc, prop, ns)
+    p = prop.cpu().numpy()
+    assert np.abs(p - info.proposed_position).max() < 5e-4
+    # log acceptance ratio: compare in log space (values are O(1e3) apart in magnitude for a random network)
+    with np.errstate(divide="ignore"):
+        la_g, la_o = np.log(acc.cpu().numpy().astype(np.float64)), np.log(info.acceptance_rate)
+    fin = np.isfinite(la_g) & np.isfinite(la_o)
+    if fin.any():
+        assert np.abs(la_g[fin] - la_o[fin]).max() < 0.5
+    np.testing.assert_array_equal(isacc.cpu().numpy().astype(bool)[~fin | (np.abs(la_o) > 1)], info.is_accepted[~fin | (np.abs(la_o) > 1)])
+    tot = stats["n_att_inv"] + stats["n_att_fwd"]
+    assert np.abs(ns.cpu().numpy() - tot).max() <= 3
+    ctx.close()
