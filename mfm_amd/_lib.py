@@ -86,8 +86,18 @@ def _chk(rc):
         raise MfmError(f"libmfm_hip error {rc}: {load().mfm_last_error().decode()}")
 
 
-def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+def _ptr(t, dtype=None):
+    """Device pointer of a contiguous CUDA tensor (dtype-checked: a wrong dtype would be silent garbage)."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.is_contiguous()):
+        raise MfmError("expected a contiguous CUDA tensor")
+    if dtype is not None and str(t.dtype).split(".")[-1] != dtype:
+        raise MfmError(f"expected a {dtype} tensor, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+F32, F64, U8, I32 = "float32", "float64", "uint8", "int32"
 
 
 def _f32(a):
@@ -161,26 +171,27 @@ class Context:
 
     # ---- kernels ----------------------------------------------------------------------------------------------
     def mala_init(self, pos, beta, logp, grad):
-        _chk(self.lib.mfm_mala_init(self.h, _ptr(pos), float(beta), _ptr(logp), _ptr(grad)))
+        _chk(self.lib.mfm_mala_init(self.h, _ptr(pos, F32), float(beta), _ptr(logp, F64), _ptr(grad, F32)))
 
     def mala_step(self, key, beta, step_size, pos, logp, grad, acc=None, is_acc=None, proposed=None, weight=None,
                   textbook=False):
         _chk(self.lib.mfm_mala_step(self.h, int(key[0]), int(key[1]), float(beta), float(step_size), int(textbook),
-                                    _ptr(pos), _ptr(logp), _ptr(grad), _ptr(acc), _ptr(is_acc), _ptr(proposed), _ptr(weight)))
+                                    _ptr(pos, F32), _ptr(logp, F64), _ptr(grad, F32), _ptr(acc, F32), _ptr(is_acc, U8),
+                                    _ptr(proposed, F32), _ptr(weight, F32)))
 
     def loglik(self, pos, out):
-        _chk(self.lib.mfm_loglik(self.h, _ptr(pos), _ptr(out)))
+        _chk(self.lib.mfm_loglik(self.h, _ptr(pos, F32), _ptr(out, F64)))
 
     def fm_loss_grad(self, key, pos, loss, grads):
-        _chk(self.lib.mfm_fm_loss_grad(self.h, int(key[0]), int(key[1]), _ptr(pos), _ptr(loss), _ptr(grads)))
+        _chk(self.lib.mfm_fm_loss_grad(self.h, int(key[0]), int(key[1]), _ptr(pos, F32), _ptr(loss, F64), _ptr(grads, F32)))
 
     def fm_loss(self, key, samples, loss, n_total=None, offset=0):
         n = samples.shape[0]
-        _chk(self.lib.mfm_fm_loss(self.h, int(key[0]), int(key[1]), _ptr(samples), n, n if n_total is None else n_total,
-                                  offset, _ptr(loss)))
+        _chk(self.lib.mfm_fm_loss(self.h, int(key[0]), int(key[1]), _ptr(samples, F32), n, n if n_total is None else n_total,
+                                  offset, _ptr(loss, F64)))
 
     def adamw_step(self, grads):
-        _chk(self.lib.mfm_adamw_step(self.h, _ptr(grads)))
+        _chk(self.lib.mfm_adamw_step(self.h, _ptr(grads, F32)))
 
     def opt_state(self):
         out = (C.c_int32 * 4)()
@@ -189,17 +200,17 @@ class Context:
         return dict(step=out[0], count=out[1], notfinite_count=out[2], last_applied=out[3], last_lr=lr.value)
 
     def vf_apply(self, x, t, v, tangent=None, jvp=None):
-        _chk(self.lib.mfm_vf_apply(self.h, _ptr(x), _ptr(t), _ptr(tangent), x.shape[0], _ptr(v), _ptr(jvp)))
+        _chk(self.lib.mfm_vf_apply(self.h, _ptr(x, F32), _ptr(t, F32), _ptr(tangent, F32), x.shape[0], _ptr(v, F32), _ptr(jvp, F32)))
 
     def ode_transform(self, direction, x, out, ldj, keys=None, key=(0, 0), nsteps=None):
-        _chk(self.lib.mfm_ode_transform(self.h, direction, 0 if keys is None else 1, _ptr(keys), int(key[0]), int(key[1]),
-                                        _ptr(x), x.shape[0], _ptr(out), _ptr(ldj), _ptr(nsteps)))
+        _chk(self.lib.mfm_ode_transform(self.h, direction, 0 if keys is None else 1, _ptr(keys, I32), int(key[0]), int(key[1]),
+                                        _ptr(x, F32), x.shape[0], _ptr(out, F32), _ptr(ldj, F32), _ptr(nsteps, I32)))
 
     def flow_step(self, mode, key, beta, pos, logp, grad, acc=None, is_acc=None, proposed=None, nsteps=None):
-        _chk(self.lib.mfm_flow_step(self.h, mode, int(key[0]), int(key[1]), float(beta), _ptr(pos), _ptr(logp), _ptr(grad),
-                                    _ptr(acc), _ptr(is_acc), _ptr(proposed), _ptr(nsteps)))
+        _chk(self.lib.mfm_flow_step(self.h, mode, int(key[0]), int(key[1]), float(beta), _ptr(pos, F32), _ptr(logp, F64), _ptr(grad, F32),
+                                    _ptr(acc, F32), _ptr(is_acc, U8), _ptr(proposed, F32), _ptr(nsteps, I32)))
 
     def beta_update(self, prev_beta, logliks, alpha):
         out = C.c_double()
-        _chk(self.lib.mfm_beta_update(self.h, float(prev_beta), _ptr(logliks), logliks.numel(), float(alpha), C.byref(out)))
+        _chk(self.lib.mfm_beta_update(self.h, float(prev_beta), _ptr(logliks, F64), logliks.numel(), float(alpha), C.byref(out)))
         return out.value

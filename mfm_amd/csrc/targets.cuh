@@ -51,49 +51,65 @@ __device__ __forceinline__ float phi4_hvp(const TargetDev& T, const float* xs, c
   return -T.tbeta * (T.coef * lap - (1.f - 3.f * x * x) * v / T.coef);
 }
 
-// ---- Gaussian mixture (evaluated by ONE lane for a whole row; d is tiny) ----------------------------------
+// ---- Gaussian mixture (evaluated by ONE lane for a whole row; d <= MAXD is tiny) ------------------------------
 // log-sum-exp form: algebraically identical to the reference's log(sum_k w_k prod_j pdf) (distributions.py:59-61)
 // but does not underflow in float32 ("fp32 vs the reference's fp64").
+// Written without dynamically indexed local arrays (no scratch): component log-weights are recomputed in the
+// second pass instead of being stored.
 template <int MAXD>
-__device__ __forceinline__ void gmm_eval(const TargetDev& T, const float* x, double* logp, float* grad,
-                                         const float* v = nullptr, float* hv = nullptr) {
-  const int d = T.dim, K = T.n_modes;
-  float lw[MFM_GMM_MAX_MODES];
-  float m = -INFINITY;
-  for (int k = 0; k < K; ++k) {
-    float s = T.gmm_logw[k];
-    for (int j = 0; j < d; ++j) {
-      float z = (x[j] - T.gmm_mode[k * d + j]) / T.gmm_std[k * d + j];
+__device__ __forceinline__ float gmm_comp(const TargetDev& T, const float (&x)[MAXD], int k) {
+  float s = T.gmm_logw[k];
+#pragma unroll
+  for (int j = 0; j < MAXD; ++j)
+    if (j < T.dim) {
+      const float z = (x[j] - T.gmm_mode[k * T.dim + j]) / T.gmm_std[k * T.dim + j];
       s -= 0.5f * z * z;
     }
-    lw[k] = s;
-    m = fmaxf(m, s);
-  }
+  return s;
+}
+
+template <int MAXD>
+__device__ __forceinline__ void gmm_eval(const TargetDev& T, const float* xp, double* logp, float* grad,
+                                         const float* vp = nullptr, float* hv = nullptr) {
+  const int d = T.dim, K = T.n_modes;
+  float x[MAXD], v[MAXD], g[MAXD], t1[MAXD];
+#pragma unroll
+  for (int j = 0; j < MAXD; ++j) { x[j] = j < d ? xp[j] : 0.f; v[j] = (vp && j < d) ? vp[j] : 0.f; g[j] = 0.f; t1[j] = 0.f; }
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, gmm_comp<MAXD>(T, x, k));
   float se = 0.f;
-  for (int k = 0; k < K; ++k) { lw[k] = __expf(lw[k] - m); se += lw[k]; }
-  *logp = (double)m + (double)__logf(se);
-  float g[MAXD], t1[MAXD];
-  for (int j = 0; j < d; ++j) { g[j] = 0.f; t1[j] = 0.f; }
   for (int k = 0; k < K; ++k) {
-    float r = lw[k] / se;
-    float av = 0.f;
-    float a[MAXD];
-    for (int j = 0; j < d; ++j) {
-      float sd = T.gmm_std[k * d + j];
-      a[j] = -(x[j] - T.gmm_mode[k * d + j]) / (sd * sd);
-      g[j] += r * a[j];
-      if (v) av += a[j] * v[j];
-    }
-    if (v)
-      for (int j = 0; j < d; ++j) {
-        float sd = T.gmm_std[k * d + j];
-        t1[j] += r * (a[j] * av - v[j] / (sd * sd));
+    const float e = expf(gmm_comp<MAXD>(T, x, k) - m);     // unnormalised responsibility
+    se += e;
+    float a[MAXD], av = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXD; ++j) {
+      a[j] = 0.f;
+      if (j < d) {
+        const float sd = T.gmm_std[k * d + j];
+        a[j] = -(x[j] - T.gmm_mode[k * d + j]) / (sd * sd);
+        g[j] += e * a[j];
+        av += a[j] * v[j];
       }
+    }
+    if (vp) {
+#pragma unroll
+      for (int j = 0; j < MAXD; ++j)
+        if (j < d) {
+          const float sd = T.gmm_std[k * d + j];
+          t1[j] += e * (a[j] * av - v[j] / (sd * sd));
+        }
+    }
   }
-  for (int j = 0; j < d; ++j) grad[j] = g[j];
-  if (v) {
-    float gv = 0.f;
-    for (int j = 0; j < d; ++j) gv += g[j] * v[j];
-    for (int j = 0; j < d; ++j) hv[j] = t1[j] - g[j] * gv;
-  }
+  *logp = (double)m + (double)logf(se);
+  const float inv = 1.f / se;
+  float gv = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXD; ++j) { g[j] *= inv; t1[j] *= inv; gv += g[j] * v[j]; }
+#pragma unroll
+  for (int j = 0; j < MAXD; ++j)
+    if (j < d) {
+      grad[j] = g[j];
+      if (vp) hv[j] = t1[j] - g[j] * gv;
+    }
 }

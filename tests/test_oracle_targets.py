@@ -8,7 +8,14 @@ import torch
 
 from oracle import targets
 
-torch.set_default_dtype(torch.float64)
+
+
+@pytest.fixture(autouse=True)
+def _f64_default():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

@@ -6,7 +6,14 @@ import torch
 from oracle import fm, prng, targets
 from oracle.vfield import VectorFieldNet
 
-torch.set_default_dtype(torch.float64)
+
+
+@pytest.fixture(autouse=True)
+def _f64_default():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
 
 
 def _rand_params(model, seed=0, scale=0.3):
