@@ -1,0 +1,128 @@
+"""Device engine: one ``mfm_ctx`` (libmfm_hip) per GPU/process plus the chain-sharding and RCCL plumbing.
+
+Chains are sharded contiguously over ranks (rank r owns global chains ``[r*B/W, (r+1)*B/W)``); parameters, optimizer
+state and target constants are replicated.  PRNG draws are indexed by global chain id inside the kernels, so chain
+trajectories do not depend on the world size.  The only data-path collective is ONE all-reduce(SUM) of the
+flow-matching gradient (+ the loss scalar) per iteration, issued through ``torch.distributed`` (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" in the CPU tests of the sharding logic).
+"""
+import numpy as np
+
+from . import _lib
+
+
+def _dist():
+    try:
+        import torch.distributed as td
+        if td.is_available() and td.is_initialized():
+            return td
+    except Exception:
+        pass
+    return None
+
+
+def shard(n_total, rank, world):
+    """Contiguous shard of the chain axis; every shard must be a multiple of 16 chains (one MFMA M-tile)."""
+    if n_total % world:
+        raise ValueError(f"num_chain={n_total} is not divisible by world size {world}")
+    n_local = n_total // world
+    if n_local % 16:
+        raise ValueError(f"chains per GPU ({n_local}) must be a multiple of 16")
+    return n_local, rank * n_local
+
+
+class Engine:
+    def __init__(self, dist, args, fourier_random=None, max_eval_samples=0):
+        import torch
+        self.torch = torch
+        td = _dist()
+        self.world = td.get_world_size() if td else 1
+        self.rank = td.get_rank() if td else 0
+        self.n_total = int(args.num_chain)
+        self.n_local, self.offset = shard(self.n_total, self.rank, self.world)
+        self.dim = int(args.dim)
+        if len(args.hidden_x) != 2 or len(args.hidden_t) != 2 or len(args.hidden_xt) != 2:
+            raise NotImplementedError("the fused MLP kernels are built for two hidden layers per branch")
+        if getattr(args, "non_linearity", "relu") != "relu":
+            raise NotImplementedError("only the default relu non-linearity is built (multi_modal.py:177)")
+        if getattr(args, "ref_dist", "stdgauss") != "stdgauss":
+            raise NotImplementedError("only ref_dist='stdgauss' is built (multi_modal.py:161)")
+        if getattr(args, "ot_cond_flow", False):
+            raise NotImplementedError("ot_cond_flow is dead code in the reference (un-imported ott)")
+        self.args = args
+        self.ctx = _lib.Context(
+            dim=self.dim, fourier_dim=int(args.fourier_dim), hidden_t=args.hidden_t, hidden_x=args.hidden_x,
+            hidden_xt=args.hidden_xt, n_chain_local=self.n_local, n_chain_total=self.n_total, chain_offset=self.offset,
+            grad_clip=float(args.gradient_clip) if self.dim > 128 else 0.0,          # exe_flow_matching.py:351
+            sigma=float(args.sigma), cond_flow=int(bool(args.cond_flow)), hutch=int(bool(args.hutchs)),
+            rtol=float(args.rtol), atol=float(args.atol), mxstep=int(args.mxstep),
+            n_ts=5 if getattr(args, "example", "") == "4-mode" else 2,               # :347
+            learning_rate=float(args.learning_rate), adam_b1=float(args.adam_beta1), adam_b2=float(args.adam_beta2),
+            adam_eps=float(args.adam_epsilon), weight_decay=float(args.weight_decay),
+            update_clip=float(args.gradient_clip), learning_iter=int(args.learning_iter),
+            warmup_steps=int(args.warmup_steps), max_eval_samples=int(max_eval_samples))
+        kind, blk = dist.target_block()
+        self.ctx.set_target(kind, blk)
+        self.dist = dist
+        dist._engine = self
+        if fourier_random is not None:
+            self.ctx.set_fourier(np.asarray(fourier_random, dtype=np.float32))
+        self.n_params = self.ctx.n_params
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.dev = dev
+        self.grads = torch.zeros(self.n_params, device=dev, dtype=torch.float32)
+        self.loss = torch.zeros(1, device=dev, dtype=torch.float64)
+
+    # ---- helpers --------------------------------------------------------------------------------------------
+    def local(self, full):
+        """Rows of a [n_total, ...] host array owned by this rank, as a float32 device tensor."""
+        a = np.asarray(full)[self.offset:self.offset + self.n_local]
+        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=self.dev)
+
+    def empty_state(self):
+        t = self.torch
+        return (t.empty(self.n_local, self.dim, device=self.dev, dtype=t.float32),
+                t.empty(self.n_local, device=self.dev, dtype=t.float64),
+                t.empty(self.n_local, self.dim, device=self.dev, dtype=t.float32))
+
+    def loglik(self, pos):
+        out = self.torch.empty(pos.shape[0], device=self.dev, dtype=self.torch.float64)
+        self.ctx.loglik(pos, out)
+        return out
+
+    def all_logliks(self, pos):
+        ll = self.loglik(pos)
+        td = _dist()
+        if td and self.world > 1:
+            parts = [self.torch.empty_like(ll) for _ in range(self.world)]
+            td.all_gather(parts, ll)
+            ll = self.torch.cat(parts)
+        return ll
+
+    # ---- one training step on the local chains (exe_flow_matching.py:362-368) -----------------------------------
+    def train_step(self, key, positions):
+        self.ctx.fm_loss_grad(key, positions, self.loss, self.grads)
+        td = _dist()
+        if td and self.world > 1:
+            td.all_reduce(self.grads, op=td.ReduceOp.SUM)        # the loss is a SUM over chains (:178)
+            td.all_reduce(self.loss, op=td.ReduceOp.SUM)
+        self.ctx.adamw_step(self.grads)
+        return self.loss
+
+    def eval_loss(self, key, samples, out=None, n_total=None, offset=0):
+        out = self.torch.zeros(1, device=self.dev, dtype=self.torch.float64) if out is None else out
+        self.ctx.fm_loss(key, samples, out, n_total=n_total, offset=offset)
+        return out
+
+    def mean_std(self, x):
+        """Global mean / population std of a per-chain quantity (acceptance rate, exe_flow_matching.py:442-443)."""
+        t = self.torch
+        s = t.stack([x.double().sum(), (x.double() ** 2).sum()])
+        td = _dist()
+        if td and self.world > 1:
+            td.all_reduce(s, op=td.ReduceOp.SUM)
+        mean = s[0] / self.n_total
+        return mean, (s[1] / self.n_total - mean * mean).clamp_min(0).sqrt()
+
+    def close(self):
+        self.ctx.close()

@@ -1,0 +1,314 @@
+"""MFM training loop and its building blocks -- drop-in for the reference's ``exe_flow_matching.py`` on MI355X.
+
+Keeps the reference's names and call shapes (``VectorFieldNet``, ``create_train_state``, ``create_learning_rate_fn``,
+``create_train_data_gn -> (train_data_generator, init_fn, transform_and_logdet)``, ``run(dist, args, target_gn)``;
+``exe_flow_matching.py:56-90,93-198,201-318,321-561``) while every array operation of the hot loop (``:432-449``) runs
+in hand-written HIP kernels behind the C ABI (``include/mfm.h``).  What changes at the boundary is listed in
+INTEGRATION.md: arrays are CUDA tensors batched over chains (the reference batches with ``jax.vmap``), parameters
+and optimizer state live on the device (``state.params`` copies them back on demand), and ``jax.random`` keys are
+uint32[2] NumPy arrays with the same split conventions.
+"""
+import logging
+import time
+from typing import Callable
+
+import numpy as np
+
+from . import random as jr
+from . import wandb_shim as wandb
+from ._lib import FLOW_IMH, FLOW_RWMH
+from .bblackjax.mcmc.mala import MALAInfo, MALAState, build_kernel, init  # noqa: F401  (same import as :28)
+from .distributions import IndepGaussian
+from .engine import Engine
+
+logger = logging.getLogger(__name__)
+
+non_lins = {"relu": "relu"}                                   # :40-46 (only the default is built)
+ref_dists = {"stdgauss": lambda dim: IndepGaussian(dim)}      # :48-54 (only the default is built)
+
+
+# ---- parameters: flax-style pytree <-> canonical flat vector (include/mfm.h) ---------------------------------------
+def layer_shapes(dim, fourier_dim, hidden_x, hidden_t, hidden_xt):
+    F2 = 2 * fourier_dim
+    return [(F2, hidden_t[0]), (hidden_t[0], hidden_t[1]), (dim, hidden_x[0]), (hidden_x[0], hidden_x[1]),
+            (hidden_t[1], dim), (hidden_x[1] + hidden_t[1], hidden_xt[0]), (hidden_xt[0], hidden_xt[1]),
+            (hidden_xt[1], dim)]
+
+
+def flatten_params(params):
+    p = params["params"]
+    return np.concatenate([np.concatenate([np.asarray(p[f"Dense_{i}"]["kernel"], np.float32).reshape(-1),
+                                           np.asarray(p[f"Dense_{i}"]["bias"], np.float32).reshape(-1)])
+                           for i in range(len(p))])
+
+
+def unflatten_params(flat, shapes):
+    out, o = {}, 0
+    for i, (fi, fo) in enumerate(shapes):
+        W = flat[o:o + fi * fo].reshape(fi, fo); o += fi * fo
+        b = flat[o:o + fo]; o += fo
+        out[f"Dense_{i}"] = {"kernel": W.copy(), "bias": b.copy()}
+    return {"params": out}
+
+
+class VectorFieldNet:
+    """``exe_flow_matching.py:56-90``.  ``grad_logporob`` is ``dist.grad_logprob`` (the reference passes
+    ``jax.grad(dist.logprob)``, :351); the gradient is evaluated inside the kernels."""
+
+    def __init__(self, fourier_random, grad_logporob, hidden_x, hidden_t, hidden_xt, act_fn="relu", grad_clip=None):
+        if act_fn != "relu":
+            raise NotImplementedError("only relu is built")
+        self.fourier_random = np.asarray(fourier_random, dtype=np.float64)
+        self.dist = getattr(grad_logporob, "__self__", None)
+        if self.dist is None:
+            raise NotImplementedError("grad_logporob must be dist.grad_logprob of a built target")
+        self.hidden_x, self.hidden_t, self.hidden_xt = list(hidden_x), list(hidden_t), list(hidden_xt)
+        self.grad_clip = grad_clip
+        self.engine = None
+
+    def shapes(self):
+        return layer_shapes(self.dist.dim, len(self.fourier_random), self.hidden_x, self.hidden_t, self.hidden_xt)
+
+    def init(self, rng_key, x=None, t=None):
+        """flax ``Module.init``: lecun_normal kernels, zero biases, ZERO gate / output kernels (:81,86), float32."""
+        shapes = self.shapes()
+        keys = jr.split(rng_key, len(shapes))
+        out = {}
+        for i, (fi, fo) in enumerate(shapes):
+            if i in (4, 7):
+                W = np.zeros((fi, fo), np.float32)
+            else:
+                W = (jr.truncated_normal(keys[i], -2.0, 2.0, (fi, fo)) * np.sqrt(1.0 / fi) / 0.87962566103423978).astype(np.float32)
+            out[f"Dense_{i}"] = {"kernel": W, "bias": np.zeros(fo, np.float32)}
+        return {"params": out}
+
+    def attach(self, engine):
+        self.engine = engine
+        return self
+
+    def apply(self, params, x, t):
+        """v(x, t) for CUDA tensors x [n, d], t [n] (n multiple of 16)."""
+        eng = self.engine
+        _maybe_upload(eng, params)
+        v = eng.torch.empty_like(x)
+        eng.ctx.vf_apply(x, t, v)
+        return v
+
+
+class DeviceParams:
+    """Handle for the parameters resident in the device context (what ``state.params`` is during training)."""
+
+    def __init__(self, engine, shapes):
+        self.engine, self.shapes = engine, shapes
+
+    def to_host(self):
+        return unflatten_params(self.engine.ctx.get_params(), self.shapes)
+
+
+def _maybe_upload(engine, params):
+    if isinstance(params, DeviceParams) or params is None:
+        return
+    engine.ctx.set_params(flatten_params(params))
+
+
+def create_learning_rate_fn(num_train_steps, num_warmup_steps: int, learning_rate: float) -> Callable:
+    """``exe_flow_matching.py:189-198`` (evaluated on the device by the optimizer kernel; this is the host twin)."""
+    def schedule_fn(step):
+        step = float(step)
+        if num_warmup_steps > 0 and step < num_warmup_steps:
+            return learning_rate * step / num_warmup_steps
+        ts = num_train_steps - num_warmup_steps
+        if ts <= 0:
+            return learning_rate
+        return learning_rate * (1.0 - min(max(step - num_warmup_steps, 0.0), ts) / ts)
+    return schedule_fn
+
+
+class TrainState:
+    """``flax.training.train_state.TrainState`` twin (:101-110,181-186): parameters, AdamW moments and the step
+    counters live in the device context; ``apply_gradients`` runs the fused apply_if_finite/AdamW/clip kernel."""
+
+    def __init__(self, engine, apply_fn, shapes):
+        self.engine, self.apply_fn = engine, apply_fn
+        self.params = DeviceParams(engine, shapes)
+
+    @property
+    def step(self):
+        return self.engine.ctx.opt_state()["step"]
+
+    def loss_fn(self, rng_key, samples, params=None):
+        """flow_matching_loss (:171-178) on CUDA samples [n, d]; returns a 1-element float64 CUDA tensor."""
+        _maybe_upload(self.engine, params)
+        return self.engine.eval_loss(rng_key, samples)
+
+    def apply_gradients(self, grads):
+        self.engine.ctx.adamw_step(grads)
+        return self
+
+
+def create_train_state(vector_field_apply, vector_field_param, learning_rate_fn, args) -> TrainState:
+    """``exe_flow_matching.py:93-186``.  The optimizer hyper-parameters were given to the engine with ``args``."""
+    model = vector_field_apply.__self__
+    eng = model.engine
+    eng.ctx.set_params(flatten_params(vector_field_param))
+    eng.ctx.reset_optimizer()
+    return TrainState(eng, vector_field_apply, model.shapes())
+
+
+def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
+    """``exe_flow_matching.py:201-318``.  ``ode_integrator`` is accepted for signature parity; the integrator is the
+    in-kernel Dopri5 with the reference's rtol / atol / mxstep (given to the engine with ``args``)."""
+    model = vector_field_apply.__self__
+    eng = model.engine
+    t = eng.torch
+    if args.num_importance_samples > 0:
+        raise NotImplementedError("conditional importance sampling (:280-296): SURVEY.md section 8f row N3")
+    mode = FLOW_IMH if args.num_importance_samples < 0 else FLOW_RWMH                      # :298
+    n, d = eng.n_local, eng.dim
+    info = dict(acc=t.empty(n, device=eng.dev, dtype=t.float32), isacc=t.empty(n, device=eng.dev, dtype=t.uint8),
+                prop=t.empty(n, d, device=eng.dev, dtype=t.float32), w=t.zeros(n, device=eng.dev, dtype=t.float32),
+                nsteps=t.zeros(n, device=eng.dev, dtype=t.int32))
+
+    def transform_and_logdet(key, ref_sample, vector_field_param=None):
+        """:206-221, batched over samples with ONE shared Hutchinson key (as used at :455)."""
+        _maybe_upload(eng, vector_field_param)
+        out = t.empty_like(ref_sample)
+        ldj = t.empty(ref_sample.shape[0], device=eng.dev, dtype=t.float32)
+        eng.ctx.ode_transform(1, ref_sample, out, ldj, key=key)
+        return out, ldj
+
+    def train_data_generator(rng_key, states, count, vector_field_param=None, beta=1.0):
+        """:300-314.  States are updated IN PLACE (and returned); infos are views of reused device buffers."""
+        _maybe_upload(eng, vector_field_param)
+        K = args.mcmc_per_flow_steps
+        if 0 < K < 1:
+            do_flow = count % (int(1 / K) + 1) != 0                                        # :304-309
+        else:
+            do_flow = count % (int(K) + 1) == 0                                            # :311
+        pos, logp, grad = states
+        if do_flow:
+            eng.ctx.flow_step(mode, rng_key, beta, pos, logp, grad, info["acc"], info["isacc"], info["prop"], info["nsteps"])
+        else:
+            eng.ctx.mala_step(rng_key, beta, args.step_size, pos, logp, grad, info["acc"], info["isacc"], info["prop"], info["w"])
+        return MALAState(pos, logp, grad), MALAInfo(info["acc"], info["isacc"], info["prop"], info["w"])
+
+    def init_fn(init_positions, beta=1.0):
+        """:316."""
+        pos = init_positions
+        logp = t.empty(pos.shape[0], device=eng.dev, dtype=t.float64)
+        grad = t.empty_like(pos)
+        eng.ctx.mala_init(pos, beta, logp, grad)
+        return MALAState(pos, logp, grad)
+
+    train_data_generator.info_buffers = info
+    return train_data_generator, init_fn, transform_and_logdet
+
+
+def run(dist, args, target_gn=None, log_every=1, return_extras=False):
+    """``exe_flow_matching.py:321-561``: the hot loop runs entirely on the device; metrics are fetched every
+    ``log_every`` iterations (the reference syncs to the host every iteration for wandb, :442-449)."""
+    import torch
+    logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", datefmt="%m/%d/%Y %H:%M:%S", level=logging.INFO)
+    use_real_samples = args.mcmc_per_flow_steps < 0                                        # :328
+    if use_real_samples:
+        raise NotImplementedError("training on exact samples (mcmc_per_flow_steps < 0): SURVEY.md section 8f row N3")
+    learning_iter = args.learning_iter
+    iter_per_temp = args.anneal_iter // args.num_anneal_temp                                # :330
+    n_iter, n_chain = args.eval_iter, args.num_chain
+    key_target, key_sample, key_init, key_dist, key_fourier, key_gen = jr.split(jr.PRNGKey(args.seed), 6)    # :333
+    dist.initialize_model(key_dist, n_chain)                                                # :334
+    fourier_random = args.fourier_std * jr.normal(key_fourier, (args.fourier_dim,))         # :350
+    model = VectorFieldNet(fourier_random, dist.grad_logprob, args.hidden_x, args.hidden_t, args.hidden_xt,
+                           non_lins[args.non_linearity], args.gradient_clip if args.dim > 128 else None)     # :351
+    n_eval = n_iter * n_chain if target_gn is not None else 0
+    eng = Engine(dist, args, fourier_random, max_eval_samples=max(n_eval, n_iter * n_chain))
+    model.attach(eng)
+    vector_field_param = model.init(key_init, dist.init_params[0], 0.0)                     # :353
+    learning_rate_fn = create_learning_rate_fn(learning_iter, args.warmup_steps, args.learning_rate)          # :355-359
+    state = create_train_state(model.apply, vector_field_param, learning_rate_fn, args)     # :360
+
+    real_samples = None
+    if target_gn is not None:                                                               # :370-374
+        key_gen, key_loss = jr.split(key_target)
+        keys_target = jr.split(key_gen, n_eval)
+        real_host = dist.sample_rows(keys_target)
+        lo = eng.rank * (n_eval // eng.world)
+        real_samples = torch.as_tensor(np.ascontiguousarray(real_host[lo:lo + n_eval // eng.world], dtype=np.float32), device=eng.dev)
+        eval_loss = torch.zeros(1, device=eng.dev, dtype=torch.float64)
+
+    logger.info(f"===== Starting training seed {args.seed} w/ {learning_iter} iterations =====")
+    train_data_generator, init_fn, transform_and_logdet = create_train_data_gn(dist, model.apply, None, args)  # :380-381
+    train_start = time.time()                                                               # :421
+
+    pos0 = eng.local(dist.init_params)
+    beta = eng.ctx.beta_update(0.0, eng.all_logliks(pos0), args.alpha)                      # :426
+    logger.info(f"Initial beta= {beta}")
+    train_states = init_fn(pos0, beta)                                                      # :431
+    metrics = torch.zeros(learning_iter, 4, device=eng.dev, dtype=torch.float64)            # loss, acc mean, acc std, target loss
+    betas, lrs = [], []
+    for count in range(1, learning_iter + 1):                                               # :432
+        key_sample, key_train_gn, key_train_step = jr.split(key_sample, 3)                  # :433
+        train_states, infos = train_data_generator(key_train_gn, train_states, count, state.params, beta)    # :438
+        loss = eng.train_step(key_train_step, train_states.position)                        # :439 (:362-368)
+        lrs.append(learning_rate_fn(count - 1))                                             # :367 (pre-increment step)
+        if count % iter_per_temp == 0 and beta < 1.0:                                       # :440-441, :417
+            beta = eng.ctx.beta_update(beta, eng.all_logliks(train_states.position), args.alpha)              # :413
+            train_states = init_fn(train_states.position, beta)                             # :415
+        m, s = eng.mean_std(infos.acceptance_rate)                                          # :442-443
+        metrics[count - 1, 0] = loss[0]; metrics[count - 1, 1] = m; metrics[count - 1, 2] = s
+        if real_samples is not None:                                                        # :444-446
+            eng.eval_loss(key_loss, real_samples, eval_loss, n_total=n_eval, offset=eng.rank * (n_eval // eng.world))
+            metrics[count - 1, 3] = eval_loss[0]
+        betas.append(beta)
+        if count % log_every == 0 or count == learning_iter:
+            row = metrics[count - 1].tolist()                                               # host sync
+            wandb.log({"loss": row[0], "learning_rate": lrs[-1], "acceptance avg.": row[1], "acceptance std.": row[2],
+                       "target_loss": row[3], "train_time": time.time() - train_start})     # :447-449
+    eng.ctx.sync()
+    train_time = time.time() - train_start
+    logger.info(f"Final beta= {beta}")
+
+    # ---- final flow samples + importance resampling (:453-459) --------------------------------------------------
+    n_final = n_iter * n_chain
+    ref = IndepGaussian(args.dim)
+    u_host = ref.sample_rows(jr.split(key_gen, n_final))                                    # :453 (:389)
+    key_hutch, key_choice = jr.split(key_gen)                                               # :454
+    lo = eng.rank * (n_final // eng.world)
+    u = torch.as_tensor(np.ascontiguousarray(u_host[lo:lo + n_final // eng.world], dtype=np.float32), device=eng.dev)
+    flow_samples, vols = transform_and_logdet(key_hutch, u, state.params)                   # :455
+    samples_logdensity = _logprob_any(eng, flow_samples)                                    # :456
+    ref_lp = (-0.5 * (u.double() ** 2).sum(1) - 0.5 * args.dim * np.log(2 * np.pi))
+    log_weights = samples_logdensity - ref_lp - vols.double()                               # :457
+    weights = torch.exp(log_weights - log_weights.max())                                    # :458
+    p_cuml = torch.cumsum(weights, 0)
+    r = p_cuml[-1] * (1.0 - torch.as_tensor(jr.uniform(key_choice, (flow_samples.shape[0],)), device=eng.dev))
+    idx = torch.searchsorted(p_cuml, r).clamp_max(flow_samples.shape[0] - 1)
+    exact_samples = flow_samples[idx]                                                       # :459
+    logpdf = samples_logdensity.mean().item()                                               # :469
+    logpdf_ = _logprob_any(eng, exact_samples).mean().item()                                # :473
+    logger.info(f"Logpdf of flow samples= {logpdf}")
+    logger.info(f"Logpdf of exact samples= {logpdf_}")
+    nan = float("nan")      # KSD / MMD (mcmc_utils.py:28-111): SURVEY.md section 8f row N2, not built yet
+    res = np.array([logpdf, nan, nan, nan if target_gn is not None else 0.0, train_time])
+    res_ = np.array([logpdf_, nan, nan, nan if target_gn is not None else 0.0, train_time])
+    wandb.finish()
+    if return_extras:
+        return res, res_, dict(metrics=metrics.cpu().numpy(), betas=np.array(betas), lrs=np.array(lrs), states=train_states,
+                               engine=eng, state=state, flow_samples=flow_samples, exact_samples=exact_samples, model=model)
+    eng.close()
+    return res, res_
+
+
+def _logprob_any(eng, x):
+    """vmap(dist.logprob) for any sample count (pads to the engine's chain count; targets built so far have no prior)."""
+    t = eng.torch
+    out = t.empty(x.shape[0], device=eng.dev, dtype=t.float64)
+    n = eng.n_local
+    for s in range(0, x.shape[0], n):
+        chunk = x[s:s + n]
+        if chunk.shape[0] < n:
+            pad = t.zeros(n, x.shape[1], device=eng.dev, dtype=x.dtype); pad[:chunk.shape[0]] = chunk
+            out[s:s + chunk.shape[0]] = eng.loglik(pad)[:chunk.shape[0]]
+        else:
+            out[s:s + n] = eng.loglik(chunk.contiguous())
+    return out

@@ -1,0 +1,84 @@
+"""Host-side key plumbing with jax.random conventions (threefry2x32, 64-bit draws under x64).
+
+Only what the host needs: deriving / splitting keys, one-off draws at set-up time (chain initialisation, Fourier
+frequencies, network initialisation, exact mixture samples).  Per-iteration noise is drawn inside the HIP kernels
+(mfm_amd/csrc/prng.cuh) with the same conventions, so a key means the same stream on both sides.
+Reference call sites: exe_flow_matching.py:333,350,353,371-372,433; distributions.py:70-76,163-164.
+"""
+import numpy as np
+from scipy.special import erf, erfinv
+
+U32 = np.uint32
+
+
+def _rot(x, r):
+    return (x << U32(r)) | (x >> U32(32 - r))
+
+
+def _threefry(k0, k1, x0, x1):
+    with np.errstate(over="ignore"):
+        k0, k1 = U32(k0) if np.isscalar(k0) else k0.astype(U32), U32(k1) if np.isscalar(k1) else k1.astype(U32)
+        ks = (k0, k1, k0 ^ k1 ^ U32(0x1BD11BDA))
+        x0 = (np.asarray(x0, U32) + ks[0]).astype(U32)
+        x1 = (np.asarray(x1, U32) + ks[1]).astype(U32)
+        rots = ((13, 15, 26, 6), (17, 29, 16, 24))
+        for b in range(5):
+            for r in rots[b % 2]:
+                x0 = (x0 + x1).astype(U32)
+                x1 = _rot(x1, r) ^ x0
+            x0 = (x0 + ks[(b + 1) % 3]).astype(U32)
+            x1 = (x1 + ks[(b + 2) % 3] + U32(b + 1)).astype(U32)
+    return x0, x1
+
+
+def PRNGKey(seed):
+    seed = int(seed)
+    return np.array([(seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF], dtype=U32)
+
+
+def split(key, num=2):
+    cnt = np.arange(2 * num, dtype=U32)
+    y0, y1 = _threefry(key[0], key[1], cnt[:num], cnt[num:])
+    return np.concatenate([y0, y1]).reshape(num, 2)
+
+
+def _bits64(keys, size):
+    """keys [n, 2] -> [n, size] uint64 (one independent draw of `size` samples per key)."""
+    keys = np.atleast_2d(np.asarray(keys, U32))
+    i = np.arange(size, dtype=U32)[None, :]
+    y0, y1 = _threefry(keys[:, 0:1], keys[:, 1:2], np.broadcast_to(i, (keys.shape[0], size)),
+                       np.broadcast_to((i + U32(size)).astype(U32), (keys.shape[0], size)))
+    return (y0.astype(np.uint64) << np.uint64(32)) | y1.astype(np.uint64)
+
+
+def _unit(bits):
+    return ((bits >> np.uint64(12)) | np.float64(1.0).view(np.uint64)).view(np.float64) - 1.0
+
+
+def uniform(key, shape=(), minval=0.0, maxval=1.0):
+    shape = tuple(np.atleast_1d(shape)) if np.ndim(shape) or shape != () else ()
+    size = int(np.prod(shape)) if shape else 1
+    u = np.maximum(minval, _unit(_bits64(key, size))[0] * (maxval - minval) + minval)
+    return u.reshape(shape)
+
+
+_LO = np.nextafter(np.float64(-1.0), 0.0)
+
+
+def normal(key, shape=()):
+    return np.sqrt(2.0) * erfinv(uniform(key, shape, _LO, 1.0))
+
+
+def uniform_rows(keys, d):
+    return np.maximum(0.0, _unit(_bits64(keys, d)))
+
+
+def normal_rows(keys, d):
+    u = np.maximum(_LO, _unit(_bits64(keys, d)) * (1.0 - _LO) + _LO)
+    return np.sqrt(2.0) * erfinv(u)
+
+
+def truncated_normal(key, lower, upper, shape):
+    a, b = erf(lower / np.sqrt(2.0)), erf(upper / np.sqrt(2.0))
+    out = np.sqrt(2.0) * erfinv(uniform(key, shape, a, b))
+    return np.clip(out, np.nextafter(lower, np.inf), np.nextafter(upper, -np.inf))
