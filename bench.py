@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- MFM train-steps/s x chains on phi-four (d=256, 4096 chains per GPU, K=100, --hutch).
+
+One "step" = one iteration of the reference's hot loop (exe_flow_matching.py:432-449) at beta = 1, excluding host
+logging: the MCMC half (a fused MALA step, or on every 101st iteration a flow-MH step = two Dopri5 CNF solves with
+Hutchinson log-det) + the learning half (flow-matching loss forward/backward, weight gradients, [RCCL all-reduce],
+AdamW).  Inputs are synthetic and resident in HBM: chains start from the target's own initialiser U(-1,1)^d, the
+network from the flax-style initialiser; the warm-up (default one full 101-iteration cycle) trains it so the timed
+flow steps integrate a non-trivial field.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  value = (chains over all GPUs) * K / (max-over-ranks wall time of the K steps).
+"roofline": the kernel with the largest share of GPU time in the timed region (HIP events recorded by the library on
+its stream, mfm_profile); "cpu_baseline": the float64 numpy oracle (a port of the reference semantics, NOT JAX/XLA)
+timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 (matrix), dense
+PEAK_HBM_GBS = 8000.0
+
+
+def make_args(n_total, learning_iter):
+    from types import SimpleNamespace
+    return SimpleNamespace(
+        example="phi-four", dim=256, num_chain=n_total, seed=1, sigma=1e-4, fourier_dim=128, fourier_std=1.0, hutchs=True,
+        ref_dist="stdgauss", cond_flow=True, ot_cond_flow=False, num_importance_samples=0, mcmc_per_flow_steps=100.0,
+        learning_iter=learning_iter, eval_iter=1, alpha=0.95, anneal_iter=200, num_anneal_temp=200, non_linearity="relu",
+        hidden_x=[128, 128], hidden_t=[128, 128], hidden_xt=[128, 128], step_size=1e-4, learning_rate=1e-3,
+        weight_decay=1e-4, adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8, gradient_clip=1.0, warmup_steps=0,
+        rtol=1e-5, atol=1e-5, mxstep=1000.0)
+
+
+def flops_per_chain(d=256, h=128, F=128):
+    P_w = 2 * F * h + 5 * h * h + 3 * d * h                 # all kernels
+    P_x = 2 * d * h + 3 * h * h                             # weights on the x-tangent path
+    dgrad = 2 * d * h + 5 * h * h                           # out, gate (d*h each), j1 (2h*h), j2, x2, t2 (h*h each)
+    return dict(fwd=2 * P_w, fm_fwd_bwd=2 * P_w + 2 * dgrad, wgrad=2 * P_w, field_eval=2 * P_w + 2 * P_x)
+
+
+def cpu_baseline(params_flat, fourier, steps_mala, chains, seed=1):
+    """Oracle (float64 numpy, multi-threaded BLAS) on a bounded sample: `chains` chains, `steps_mala` MALA+train
+    iterations and ONE flow-MH step + train step, with the network the GPU run has after its warm-up.  Composed into
+    one 101-iteration cycle: 100 * t(MALA+train) + t(flow+train)."""
+    import numpy as np
+    from oracle import flow, fm, loop, mala, optim, prng, targets
+    from oracle.vfield import VectorFieldNet
+    from tests import gpu_util as gu
+    args = loop.default_args(example="phi-four", dim=256, num_chain=chains, hutchs=True, step_size=1e-4, seed=seed,
+                             mcmc_per_flow_steps=100.0, learning_iter=10000)
+    dist = targets.PhiFour(256)
+    dist.initialize_model(prng.PRNGKey(seed), chains)
+    model = VectorFieldNet(fourier, dist, args.hidden_x, args.hidden_t, args.hidden_xt, "relu", 1.0)
+    params = gu.unflat_params(model, params_flat)
+    state = optim.TrainState(params, optim.learning_rate_fn(10000, 0, 1e-3))
+    vg = targets.Tempered(dist, 1.0).value_and_grad
+    st = mala.init(dist.init_params, vg)
+    key = prng.PRNGKey(seed + 1)
+
+    def train(st, k):
+        loss, grads = fm.loss_and_grad(model, state.params, k, st.position, args.sigma)
+        state.apply_gradients(grads)
+
+    t0 = time.perf_counter()
+    for i in range(steps_mala):
+        key, k1, k2 = prng.split(key, 3)
+        st, _, _ = mala.kernel(prng.split(k1, chains), st, vg, args.step_size)
+        train(st, k2)
+    t_mala = (time.perf_counter() - t0) / steps_mala
+    key, k1, k2 = prng.split(key, 3)
+    t0 = time.perf_counter()
+    stats = {}
+    st, _ = flow.rwmh_step(prng.split(k1, chains), st, vg, model, state.params, args, stats)
+    train(st, k2)
+    t_flow = time.perf_counter() - t0
+    cycle = 100 * t_mala + t_flow
+    return dict(value=chains * 101 / cycle, t_mala_train_s=t_mala, t_flow_train_s=t_flow,
+                n_att=float(stats["n_att_inv"].mean() + stats["n_att_fwd"].mean()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=202)       # two full (K+1)-cycles
+    ap.add_argument("--warmup", type=int, default=101)      # one full cycle, incl. one flow step
+    ap.add_argument("--chains-per-gpu", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        sys.exit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    td = None
+    if world > 1:
+        import torch.distributed as td
+        td.init_process_group("nccl")           # RCCL on ROCm
+
+    from mfm_amd import exe_flow_matching as E, random as jr
+    from mfm_amd._lib import FLOW_RWMH
+    from mfm_amd.distributions import PhiFour
+    from mfm_amd.engine import Engine
+
+    n_total = a.chains_per_gpu * world            # weak scaling: per-GPU work fixed
+    args = make_args(n_total, learning_iter=10000)
+    dist = PhiFour(256)
+    key_target, key_sample, key_init, key_dist, key_fourier, key_gen = jr.split(jr.PRNGKey(args.seed), 6)
+    dist.initialize_model(key_dist, n_total)
+    fourier = args.fourier_std * jr.normal(key_fourier, (args.fourier_dim,))
+    eng = Engine(dist, args, fourier)
+    model = E.VectorFieldNet(fourier, dist.grad_logprob, args.hidden_x, args.hidden_t, args.hidden_xt).attach(eng)
+    eng.ctx.set_params(E.flatten_params(model.init(key_init)))
+    ctx = eng.ctx
+    pos = eng.local(dist.init_params)
+    logp = torch.empty(eng.n_local, device=eng.dev, dtype=torch.float64)
+    grad = torch.empty_like(pos)
+    acc = torch.empty(eng.n_local, device=eng.dev, dtype=torch.float32)
+    nst = torch.zeros(eng.n_local, device=eng.dev, dtype=torch.int32)
+    beta = 1.0                                   # steady state
+    ctx.mala_init(pos, beta, logp, grad)
+
+    total = a.warmup + a.steps
+    keys = np.empty((total, 2, 2), dtype=np.uint32)          # key plumbing of :433, precomputed off the clock
+    ks = key_sample
+    for i in range(total):
+        ks, k_gn, k_step = jr.split(ks, 3)
+        keys[i, 0], keys[i, 1] = k_gn, k_step
+    natt_sum = torch.zeros(1, device=eng.dev, dtype=torch.float64)
+    n_flow = [0]
+
+    def step(i, count):
+        if count % 101 == 0:                                                     # :311
+            ctx.flow_step(FLOW_RWMH, keys[i, 0], beta, pos, logp, grad, acc, None, None, nst)
+            natt_sum.add_(nst.double().sum()); n_flow[0] += 1
+        else:
+            ctx.mala_step(keys[i, 0], beta, args.step_size, pos, logp, grad, acc)
+        eng.train_step(keys[i, 1], pos)                                          # loss+grad, all-reduce, AdamW
+
+    def fence():
+        if td is not None:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    count = 0
+    for i in range(a.warmup):
+        count += 1
+        step(i, count)
+    fence()
+    natt_sum.zero_(); n_flow[0] = 0
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for i in range(a.warmup, total):
+        count += 1
+        step(i, count)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    if td is not None:
+        tmax = torch.tensor([dt], device=eng.dev, dtype=torch.float64)
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        dt = tmax.item()
+        td.all_reduce(natt_sum, op=td.ReduceOp.SUM)
+    value = n_total * a.steps / dt
+
+    if rank == 0:
+        fl = flops_per_chain()
+        B = eng.n_local
+        natt_mean = natt_sum.item() / max(1, n_flow[0] * n_total)               # attempted Dopri5 steps per chain per flow step (2 solves)
+        alg = {  # algorithmic FLOPs per launch
+            "fm_fwd_bwd": B * fl["fm_fwd_bwd"], "wgrad": B * fl["wgrad"],
+            "flow_step": B * (4 + 6 * natt_mean) * fl["field_eval"],
+        }
+        dom = max((k for k in prof if k in alg), key=lambda k: prof[k]["ms"], default=None)
+        roof = None
+        if dom is not None and prof[dom]["launches"]:
+            avg_ms = prof[dom]["ms"] / prof[dom]["launches"]
+            ach = alg[dom] / (avg_ms * 1e-3) / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                    "algorithmic_flop_per_launch": alg[dom]}
+        out = {
+            "metric": "MFM train-steps/s x chains (phi-four d=256, 4096 chains per GPU)", "value": round(value, 1),
+            "unit": "chain-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "phi-four d=256, 4096 chains/GPU, mcmc_per_flow_steps=100, --hutch, beta=1 (BASELINE configs[2])",
+                       "chains_total": n_total, "chains_per_gpu": B, "parallelism": f"chains sharded x{world}, RCCL grad all-reduce" if world > 1 else "single GPU",
+                       "flow_steps_timed": n_flow[0], "dopri_attempts_per_chain_per_flow_step": round(natt_mean, 2),
+                       "chain_dim_updates_per_s": round(value * 256, 1)},
+            "roofline": roof,
+            "kernels_ms_total": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in prof.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                from threadpoolctl import threadpool_limits
+                cores = os.cpu_count() or 1
+                params_flat = ctx.get_params()
+                with threadpool_limits(limits=cores):
+                    cb = cpu_baseline(params_flat, fourier, steps_mala=4, chains=512)
+                out["cpu_baseline"] = {"value": round(cb["value"], 1), "unit": "chain-steps/s", "cores": cores, "kind": "port",
+                                       "sample": f"512 chains: 4 MALA+train iterations and 1 flow-MH+train iteration (mean {cb['n_att']:.1f} "
+                                                 f"Dopri5 attempts), same network as the GPU after warm-up; composed into a 101-iteration cycle "
+                                                 f"(t_mala_train={cb['t_mala_train_s']:.3f}s, t_flow_train={cb['t_flow_train_s']:.3f}s); float64 numpy oracle"}
+            except Exception as e:  # the baseline must never hide the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "chain-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    if td is not None:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

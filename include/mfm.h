@@ -124,6 +124,11 @@ int mfm_flow_step(mfm_ctx* ctx, int mode, uint32_t key0, uint32_t key1, double b
 /* Bisection for the next beta on n (global) log-likelihoods; h_beta_out gets the new beta (synchronises). */
 int mfm_beta_update(mfm_ctx* ctx, double prev_beta, const double* d_logliks, int n, double alpha, double* h_beta_out);
 
+/* ---- measurement (bench.py): HIP-event timing of the kernels, recorded on the context's stream ------------------- */
+/* class ids: 0 mala_step, 1 fm_fwd_bwd, 2 wgrad, 3 adamw (4 small kernels), 4 flow_step, 5 fm eval, 6 reductions */
+int mfm_profile(mfm_ctx* ctx, int enable);                      /* enable resets the record */
+int mfm_profile_read(mfm_ctx* ctx, double ms_total[8], int64_t launches[8]);   /* synchronises */
+
 /* ---- test helpers (host only, no GPU needed) ------------------------------------------------------------------- */
 int mfm_pack_index(int k, int n, int KB);       /* float index of W[k][n] inside a packed layer */
 int mfm_pack_index_T(int k, int n, int NB);

@@ -58,6 +58,8 @@ _SIGS = {
     "mfm_ode_transform": (C.c_int, [_P, C.c_int, C.c_int, _P, _U32, _U32, _P, C.c_int, _P, _P, _P]),
     "mfm_flow_step": (C.c_int, [_P, C.c_int, _U32, _U32, C.c_double, _P, _P, _P, _P, _P, _P, _P]),
     "mfm_beta_update": (C.c_int, [_P, C.c_double, _P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    "mfm_profile": (C.c_int, [_P, C.c_int]),
+    "mfm_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mfm_pack_index": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mfm_pack_index_T": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mfm_threefry2x32": (C.c_int, [_U32, _U32, _U32, _U32, C.POINTER(_U32)]),
@@ -209,6 +211,16 @@ class Context:
     def flow_step(self, mode, key, beta, pos, logp, grad, acc=None, is_acc=None, proposed=None, nsteps=None):
         _chk(self.lib.mfm_flow_step(self.h, mode, int(key[0]), int(key[1]), float(beta), _ptr(pos, F32), _ptr(logp, F64), _ptr(grad, F32),
                                     _ptr(acc, F32), _ptr(is_acc, U8), _ptr(proposed, F32), _ptr(nsteps, I32)))
+
+    PROF_CLASSES = ("mala_step", "fm_fwd_bwd", "wgrad", "adamw", "flow_step", "fm_eval", "reduce", "_")
+
+    def profile(self, enable=True):
+        _chk(self.lib.mfm_profile(self.h, int(enable)))
+
+    def profile_read(self):
+        ms, cnt = (C.c_double * 8)(), (C.c_int64 * 8)()
+        _chk(self.lib.mfm_profile_read(self.h, ms, cnt))
+        return {n: dict(ms=ms[i], launches=cnt[i]) for i, n in enumerate(self.PROF_CLASSES) if cnt[i]}
 
     def beta_update(self, prev_beta, logliks, alpha):
         out = C.c_double()

@@ -24,7 +24,17 @@ static int fail(int code, const char* fmt, ...) {
 #define LAUNCHCHK()                                                                                      \
   do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(MFM_EHIP, "kernel launch: %s", hipGetErrorString(e_)); } while (0)
 
+// ---- optional per-kernel timing with HIP events on the context's stream (bench.py roofline) -----------------------
+enum { PROF_MALA = 0, PROF_FM = 1, PROF_WGRAD = 2, PROF_ADAM = 3, PROF_FLOW = 4, PROF_EVAL = 5, PROF_REDUCE = 6, PROF_NCLS = 8 };
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;     // pairs
+  std::vector<int> cls;
+  size_t used = 0;
+};
+
 struct mfm_ctx {
+  Prof* prof;
   mfm_config cfg;
   hipStream_t stream;
   NetDev net;
@@ -40,6 +50,12 @@ struct mfm_ctx {
   double* beta_out;
 };
 
+struct ProfScope {
+  mfm_ctx* x; bool active;
+  ProfScope(mfm_ctx* x_, int cls);
+  ~ProfScope();
+};
+
 extern "C" const char* mfm_last_error(void) { return g_err; }
 extern "C" int mfm_version(void) { return 1; }
 extern "C" int mfm_pack_index(int k, int n, int KB) { return pack_index(k, n, KB); }
@@ -47,6 +63,47 @@ extern "C" int mfm_pack_index_T(int k, int n, int NB) { return pack_index_T(k, n
 extern "C" int mfm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]) {
   threefry2x32(Key2{k0, k1}, c0, c1, out[0], out[1]);
   return 0;
+}
+
+ProfScope::ProfScope(mfm_ctx* x_, int cls) : x(x_), active(false) {
+  Prof* p = x->prof;
+  if (!p || !p->on || p->used + 2 > p->ev.size()) return;
+  active = true;
+  p->cls.push_back(cls);
+  (void)hipEventRecord(p->ev[p->used], x->stream);
+}
+ProfScope::~ProfScope() {
+  if (!active) return;
+  Prof* p = x->prof;
+  (void)hipEventRecord(p->ev[p->used + 1], x->stream);
+  p->used += 2;
+}
+
+extern "C" int mfm_profile(mfm_ctx* x, int enable) {
+  if (!x) return fail(MFM_EINVAL, "null ctx");
+  if (!x->prof) x->prof = new Prof();
+  Prof* p = x->prof;
+  if (enable && p->ev.empty()) {
+    p->ev.resize(2 * 16384);
+    for (auto& e : p->ev) HIPCHK(hipEventCreate(&e));
+  }
+  p->on = enable != 0;
+  if (enable) { p->used = 0; p->cls.clear(); }
+  return MFM_OK;
+}
+
+extern "C" int mfm_profile_read(mfm_ctx* x, double ms[8], int64_t counts[8]) {
+  if (!x || !ms || !counts) return fail(MFM_EINVAL, "null argument");
+  for (int i = 0; i < 8; ++i) { ms[i] = 0.0; counts[i] = 0; }
+  if (!x->prof) return MFM_OK;
+  HIPCHK(hipStreamSynchronize(x->stream));
+  Prof* p = x->prof;
+  for (size_t i = 0; i < p->cls.size(); ++i) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, p->ev[2 * i], p->ev[2 * i + 1]));
+    ms[p->cls[i]] += t; counts[p->cls[i]] += 1;
+  }
+  return MFM_OK;
 }
 
 static void build_net(const mfm_config& c, NetDev& n) {
@@ -141,6 +198,7 @@ extern "C" int mfm_destroy(mfm_ctx* x) {
                 x->jobs, x->opt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->beta_out};
   for (void* p : ps) if (p) hipFree(p);
   ode_ws_free(x->ode);
+  if (x->prof) { for (auto& e : x->prof->ev) (void)hipEventDestroy(e); delete x->prof; }
   delete x;
   return MFM_OK;
 }
@@ -240,6 +298,7 @@ extern "C" int mfm_mala_step(mfm_ctx* x, uint32_t k0, uint32_t k1, double beta, 
   a.key = Key2{k0, k1}; a.eps = step; a.textbook = textbook;
   a.pos = d_pos; a.logp = d_logp; a.grad = d_grad;
   a.acc_prob = d_acc; a.accepted = d_isacc; a.proposed = d_prop; a.prop_weight = d_pw;
+  ProfScope ps_(x, PROF_MALA);
   if (launch_mala_step(a, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large for the MALA kernel", x->cfg.dim);
   LAUNCHCHK();
   return MFM_OK;
@@ -270,9 +329,11 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
   }
   a.n_total = n_total; a.chain_offset = offset; a.B = n; a.sigma = x->cfg.sigma; a.cond_flow = x->cfg.cond_flow;
   a.pos = d_samples; a.acts = x->acts; a.dzs = x->dzs; a.loss_part = x->loss_part;
-  int rc = launch_fm(a, train, x->stream);
+  int rc;
+  { ProfScope ps_(x, train ? PROF_FM : PROF_EVAL); rc = launch_fm(a, train, x->stream); }
   if (rc) return fail(rc, "fm kernel cannot be launched for this configuration");
   LAUNCHCHK();
+  ProfScope ps2_(x, PROF_REDUCE);
   launch_reduce_loss(x->loss_part, n / 16, d_loss, 0, x->stream);
   LAUNCHCHK();
   return MFM_OK;
@@ -286,8 +347,9 @@ extern "C" int mfm_fm_loss_grad(mfm_ctx* x, uint32_t k0, uint32_t k1, const floa
   WgradArgs w; memset(&w, 0, sizeof w);
   w.net = x->net; w.ws = x->ws; w.acts = x->acts; w.dzs = x->dzs; w.jobs = x->jobs; w.n_jobs = x->n_jobs;
   w.nbb = x->cfg.n_chain_local / 16; w.split = x->split; w.slabs = x->slabs;
-  launch_wgrad(w, x->stream);
+  { ProfScope ps_(x, PROF_WGRAD); launch_wgrad(w, x->stream); }
   LAUNCHCHK();
+  ProfScope ps2_(x, PROF_REDUCE);
   launch_reduce_slabs(x->slabs, x->split, x->net.n_params, d_grads, x->stream);
   LAUNCHCHK();
   return MFM_OK;
@@ -309,6 +371,7 @@ extern "C" int mfm_adamw_step(mfm_ctx* x, const float* d_grads) {
   a.lr0 = c.learning_rate; a.learning_iter = c.learning_iter; a.warmup = c.warmup_steps;
   a.b1 = c.adam_b1; a.b2 = c.adam_b2; a.eps = (float)c.adam_eps; a.wd = (float)c.weight_decay; a.clip = (float)c.update_clip;
   a.max_err = 10;
+  ProfScope ps_(x, PROF_ADAM);
   launch_adamw(a, x->stream);
   LAUNCHCHK();
   return MFM_OK;
@@ -363,6 +426,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
   f.mode = mode; f.key = Key2{k0, k1}; f.n_total = x->cfg.n_chain_total; f.chain_offset = x->cfg.chain_offset;
   f.beta = beta; f.pos = d_pos; f.logp = d_logp; f.grad = d_grad; f.acc_prob = d_acc; f.accepted = d_isacc;
   f.proposed = d_prop; f.nsteps = d_nsteps;
+  ProfScope ps_(x, PROF_FLOW);
   int rc = launch_flow_step(a, f, x->stream);
   if (rc) return fail(rc, "flow step cannot be launched for this configuration");
   LAUNCHCHK();
