@@ -75,7 +75,7 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB):
             raise MfmError(f"{LIB} not found: build it with `python -m mfm_amd.build` (hipcc, gfx950)")
-        lib = C.CDLL(LIB)
+        lib = C.CDLL(os.environ.get("MFM_LIB", LIB))      # MFM_LIB: development override (A/B of kernel variants)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args

@@ -158,7 +158,7 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
   NetDev& n = x->net;
   {
     const FmLds L = fm_lds_layout(n, true);
-    if ((size_t)L.total * 4 > 160 * 1024 || (n.dp / 16 + 3) / 4 > 4) {
+    if ((size_t)L.total * 4 > 160 * 1024 || (n.dp / 16 + MLP_WAVES_FM - 1) / MLP_WAVES_FM > 2) {
       delete x;
       return fail(MFM_ETOOLARGE, "network does not fit the fused 16-chain tile kernel (LDS %zu B, dim %d)", (size_t)L.total * 4, c.dim);
     }

@@ -53,7 +53,7 @@ __host__ __device__ inline FmLds fm_lds_layout(const NetDev& n, bool train) {
     L.dcat = take(16, L.ldcat);
   }
   L.gcs = take(16, 8);
-  L.red = take(1, 16);
+  L.red = take(1, 32);
   L.total = o;
   return L;
 }
@@ -71,7 +71,7 @@ __device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf
 }
 
 template <int TPW, bool TRAIN>
-__global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
+__global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const NetDev& n = a.net;
   const FmLds L = fm_lds_layout(n, TRAIN);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
   float* gcs = lds + L.gcs; double* red = reinterpret_cast<double*>(lds + L.red);
 
   // ---------------- prologue: K3 batch construction (exe_flow_matching.py:151-169 / :139-147) ----------------
-  for (int i = threadIdx.x; i < 16 * L.ldx; i += MLP_THREADS) bX[i] = 0.f;      // pads (incl. x[-1], x[d..])
+  for (int i = threadIdx.x; i < 16 * L.ldx; i += (MLP_WAVES_FM * 64)) bX[i] = 0.f;      // pads (incl. x[-1], x[d..])
   __syncthreads();
   float tt[4];
   Key2 kref[4];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
   float tgt[TPW][4];
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
-    const int nt = wave + 4 * q, col = nt * 16 + c;
+    const int nt = wave + MLP_WAVES_FM * q, col = nt * 16 + c;
     f32x4 cv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -127,25 +127,48 @@ __global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
     }
     if (TRAIN && nt * 16 < n.dp) store_packed(a.acts, a.ws.a_cond + nt, nbb, bb, lane, cv);
   }
-  // Fourier features of t (:70-71)
-  for (int nt = wave; nt * 16 < n.F2p; nt += 4) {
-    const int col = nt * 16 + c;
-    f32x4 fv = {0.f, 0.f, 0.f, 0.f};
-    if (col < 2 * n.F) {
-      const bool is_sin = col >= n.F;
-      const double f = n.fourier[is_sin ? col - n.F : col];
+  // Fourier features of t (:70-71): cos block then sin block
+  if (n.F % 16 == 0) {          // tile-aligned halves: one sincos per (row, frequency) feeds both
+    const int FT = n.F / 16;
+    for (int nt = wave; nt < FT; nt += MLP_WAVES_FM) {
+      const int col = nt * 16 + c;
+      const double f = n.fourier[col];
+      f32x4 cs, sn;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         double ft = f * (double)tt[i];
         ft -= rint(ft);
         float sv, cvv;
         sincospif(2.f * (float)ft, &sv, &cvv);
-        fv[i] = is_sin ? sv : cvv;
+        cs[i] = cvv; sn[i] = sv;
+        bFF[(4 * g + i) * L.ldff + col] = cvv;
+        bFF[(4 * g + i) * L.ldff + n.F + col] = sv;
+      }
+      if (TRAIN) {
+        store_packed(a.acts, a.ws.a_ffat + nt, nbb, bb, lane, cs);
+        store_packed(a.acts, a.ws.a_ffat + FT + nt, nbb, bb, lane, sn);
       }
     }
+  } else {
+    for (int nt = wave; nt * 16 < n.F2p; nt += MLP_WAVES_FM) {
+      const int col = nt * 16 + c;
+      f32x4 fv = {0.f, 0.f, 0.f, 0.f};
+      if (col < 2 * n.F) {
+        const bool is_sin = col >= n.F;
+        const double f = n.fourier[is_sin ? col - n.F : col];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bFF[(4 * g + i) * L.ldff + col] = fv[i];
-    if (TRAIN) store_packed(a.acts, a.ws.a_ffat + nt, nbb, bb, lane, fv);
+        for (int i = 0; i < 4; ++i) {
+          double ft = f * (double)tt[i];
+          ft -= rint(ft);
+          float sv, cvv;
+          sincospif(2.f * (float)ft, &sv, &cvv);
+          fv[i] = is_sin ? sv : cvv;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bFF[(4 * g + i) * L.ldff + col] = fv[i];
+      if (TRAIN) store_packed(a.acts, a.ws.a_ffat + nt, nbb, bb, lane, fv);
+    }
   }
   __syncthreads();
   if (n.T.kind == MFM_TARGET_GMM && threadIdx.x < 16) {
@@ -156,8 +179,7 @@ __global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
 
   // ---------------- forward ----------------------------------------------------------------------------------
   auto relu_store = [&](const LayerDesc& ld, float* out, int ldo, int coff, int a_tile) {
-    return [&, out, ldo, coff, a_tile](int q, int nt, int m, f32x4 acc) {
-      const float bias = n.bias[ld.b_off + nt * 16 + c];
+    return [&, out, ldo, coff, a_tile](int q, int nt, int m, f32x4 acc, float bias) {
       f32x4 v;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -167,34 +189,32 @@ __global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
       if (TRAIN) store_packed(a.acts, a_tile + nt, nbb, bb, lane, v);
     };
   };
-  layer_gemm<1, 2>(bFF, L.ldff, n.Wp + n.L[0].w_off, n.L[0].Kp / 16, n.L[0].Np / 16, wave, lane,
+  layer_gemm<1, MLP_WAVES_FM>(bFF, L.ldff, n.Wp + n.L[0].w_off, n.bias + n.L[0].b_off, n.L[0].Kp / 16, n.L[0].Np / 16, wave, lane,
                    relu_store(n.L[0], bT1, L.ldt1, 0, a.ws.a_t1));
-  layer_gemm<1, 2>(bX + 4, L.ldx, n.Wp + n.L[2].w_off, n.L[2].Kp / 16, n.L[2].Np / 16, wave, lane,
+  layer_gemm<1, MLP_WAVES_FM>(bX + 4, L.ldx, n.Wp + n.L[2].w_off, n.bias + n.L[2].b_off, n.L[2].Kp / 16, n.L[2].Np / 16, wave, lane,
                    relu_store(n.L[2], bX1, L.ldx1, 0, a.ws.a_x1));
   __syncthreads();
-  layer_gemm<1, 2>(bT1, L.ldt1, n.Wp + n.L[1].w_off, n.L[1].Kp / 16, n.L[1].Np / 16, wave, lane,
+  layer_gemm<1, MLP_WAVES_FM>(bT1, L.ldt1, n.Wp + n.L[1].w_off, n.bias + n.L[1].b_off, n.L[1].Kp / 16, n.L[1].Np / 16, wave, lane,
                    relu_store(n.L[1], bCat, L.ldcat, n.hx2, a.ws.a_st));
-  layer_gemm<1, 2>(bX1, L.ldx1, n.Wp + n.L[3].w_off, n.L[3].Kp / 16, n.L[3].Np / 16, wave, lane,
+  layer_gemm<1, MLP_WAVES_FM>(bX1, L.ldx1, n.Wp + n.L[3].w_off, n.bias + n.L[3].b_off, n.L[3].Kp / 16, n.L[3].Np / 16, wave, lane,
                    relu_store(n.L[3], bCat, L.ldcat, 0, a.ws.a_sx));
   __syncthreads();
-  layer_gemm<1, 2>(bCat + n.hx2, L.ldcat, n.Wp + n.L[4].w_off, n.L[4].Kp / 16, n.L[4].Np / 16, wave, lane,
-                   [&](int q, int nt, int m, f32x4 acc) {
-                     const float bias = n.bias[n.L[4].b_off + nt * 16 + c];
+  layer_gemm<1, MLP_WAVES_FM>(bCat + n.hx2, L.ldcat, n.Wp + n.L[4].w_off, n.bias + n.L[4].b_off, n.L[4].Kp / 16, n.L[4].Np / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc, float bias) {
 #pragma unroll
                      for (int i = 0; i < 4; ++i) bG[(4 * g + i) * L.ldg + nt * 16 + c] = acc[i] + bias;
                    });
-  layer_gemm<1, 2>(bCat, L.ldcat, n.Wp + n.L[5].w_off, n.L[5].Kp / 16, n.L[5].Np / 16, wave, lane,
+  layer_gemm<1, MLP_WAVES_FM>(bCat, L.ldcat, n.Wp + n.L[5].w_off, n.bias + n.L[5].b_off, n.L[5].Kp / 16, n.L[5].Np / 16, wave, lane,
                    relu_store(n.L[5], bJ1, L.ldj1, 0, a.ws.a_j1));
   __syncthreads();
-  layer_gemm<1, 2>(bJ1, L.ldj1, n.Wp + n.L[6].w_off, n.L[6].Kp / 16, n.L[6].Np / 16, wave, lane,
+  layer_gemm<1, MLP_WAVES_FM>(bJ1, L.ldj1, n.Wp + n.L[6].w_off, n.bias + n.L[6].b_off, n.L[6].Kp / 16, n.L[6].Np / 16, wave, lane,
                    relu_store(n.L[6], bJ2, L.ldj2, 0, a.ws.a_j2));
   __syncthreads();
   // output layer + loss (:88-90, :177-178); dv = 2 (v - target), dgate = dv * clip(grad log pi)
   float loss_loc = 0.f;
-  layer_gemm<1, 2>(bJ2, L.ldj2, n.Wp + n.L[7].w_off, n.L[7].Kp / 16, n.L[7].Np / 16, wave, lane,
-                   [&](int q, int nt, int m, f32x4 acc) {
+  layer_gemm<1, MLP_WAVES_FM>(bJ2, L.ldj2, n.Wp + n.L[7].w_off, n.bias + n.L[7].b_off, n.L[7].Kp / 16, n.L[7].Np / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc, float bias) {
                      const int col = nt * 16 + c;
-                     const float bias = n.bias[n.L[7].b_off + col];
                      f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                      for (int i = 0; i < 4; ++i) {
@@ -223,13 +243,17 @@ __global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
     if (lane == 0) red[wave] = lw;
   }
   __syncthreads();
-  if (threadIdx.x == 0) a.loss_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < MLP_WAVES_FM; ++w) tot += red[w];
+    a.loss_part[blockIdx.x] = tot;
+  }
   if (!TRAIN) return;
 
   // ---------------- backward (data gradients only; weight gradients: wgrad_kernel) -----------------------------
   // d j2
-  layer_gemm<1, 2>(bDV, L.lddv, n.WpT + n.L[7].w_off, n.L[7].Np / 16, n.L[7].Kp / 16, wave, lane,
-                   [&](int q, int nt, int m, f32x4 acc) {
+  layer_gemm<1, MLP_WAVES_FM>(bDV, L.lddv, n.WpT + n.L[7].w_off, nullptr, n.L[7].Np / 16, n.L[7].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
 #pragma unroll
                      for (int i = 0; i < 4; ++i) {
@@ -241,8 +265,8 @@ __global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
                    });
   __syncthreads();
   // d j1
-  layer_gemm<1, 2>(bD1, L.ldd1, n.WpT + n.L[6].w_off, n.L[6].Np / 16, n.L[6].Kp / 16, wave, lane,
-                   [&](int q, int nt, int m, f32x4 acc) {
+  layer_gemm<1, MLP_WAVES_FM>(bD1, L.ldd1, n.WpT + n.L[6].w_off, nullptr, n.L[6].Np / 16, n.L[6].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
 #pragma unroll
                      for (int i = 0; i < 4; ++i) {
@@ -254,8 +278,8 @@ __global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
                    });
   __syncthreads();
   // d [sx | st] through j1; the sx half is finished here (-> dz of x2), the st half waits for the gate path
-  layer_gemm<1, 2>(bD2, L.ldd2, n.WpT + n.L[5].w_off, n.L[5].Np / 16, n.L[5].Kp / 16, wave, lane,
-                   [&](int q, int nt, int m, f32x4 acc) {
+  layer_gemm<1, MLP_WAVES_FM>(bD2, L.ldd2, n.WpT + n.L[5].w_off, nullptr, n.L[5].Np / 16, n.L[5].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc, float) {
                      const int col = nt * 16 + c;
                      const bool is_sx = col < n.hx2;
                      f32x4 z;
@@ -269,8 +293,8 @@ __global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
                    });
   __syncthreads();
   // d st += dgate . W_gate^T ; then relu mask -> dz of t2
-  layer_gemm<1, 2>(bG, L.ldg, n.WpT + n.L[4].w_off, n.L[4].Np / 16, n.L[4].Kp / 16, wave, lane,
-                   [&](int q, int nt, int m, f32x4 acc) {
+  layer_gemm<1, MLP_WAVES_FM>(bG, L.ldg, n.WpT + n.L[4].w_off, nullptr, n.L[4].Np / 16, n.L[4].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
 #pragma unroll
                      for (int i = 0; i < 4; ++i) {
@@ -283,15 +307,15 @@ __global__ __launch_bounds__(MLP_THREADS) void fm_fwd_bwd_kernel(FmArgs a) {
                    });
   __syncthreads();
   // d x1 (only needed by wgrad) and d t1
-  layer_gemm<1, 2>(bDC, L.ldcat, n.WpT + n.L[3].w_off, n.L[3].Np / 16, n.L[3].Kp / 16, wave, lane,
-                   [&](int q, int nt, int m, f32x4 acc) {
+  layer_gemm<1, MLP_WAVES_FM>(bDC, L.ldcat, n.WpT + n.L[3].w_off, nullptr, n.L[3].Np / 16, n.L[3].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
 #pragma unroll
                      for (int i = 0; i < 4; ++i) z[i] = bX1[(4 * g + i) * L.ldx1 + nt * 16 + c] > 0.f ? acc[i] : 0.f;
                      store_packed(a.dzs, a.ws.z_x1 + nt, nbb, bb, lane, z);
                    });
-  layer_gemm<1, 2>(bDC + n.hx2, L.ldcat, n.WpT + n.L[1].w_off, n.L[1].Np / 16, n.L[1].Kp / 16, wave, lane,
-                   [&](int q, int nt, int m, f32x4 acc) {
+  layer_gemm<1, MLP_WAVES_FM>(bDC + n.hx2, L.ldcat, n.WpT + n.L[1].w_off, nullptr, n.L[1].Np / 16, n.L[1].Kp / 16, wave, lane,
+                   [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
 #pragma unroll
                      for (int i = 0; i < 4; ++i) z[i] = bT1[(4 * g + i) * L.ldt1 + nt * 16 + c] > 0.f ? acc[i] : 0.f;
@@ -423,17 +447,17 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
   const FmLds L = fm_lds_layout(a.net, train);
   const size_t sm = (size_t)L.total * sizeof(float);
   if (sm > 160 * 1024) return -3;
-  const int tpw = (a.net.dp / 16 + 3) / 4;
-  dim3 grid(a.B / 16), block(MLP_THREADS);
+  const int tpw = (a.net.dp / 16 + MLP_WAVES_FM - 1) / MLP_WAVES_FM;
+  dim3 grid(a.B / 16), block((MLP_WAVES_FM * 64));
 #define FM_LAUNCH(T, TR)                                                                                   \
   do {                                                                                                     \
     (void)hipFuncSetAttribute((const void*)fm_fwd_bwd_kernel<T, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
     hipLaunchKernelGGL((fm_fwd_bwd_kernel<T, TR>), grid, block, sm, stream, a);                           \
   } while (0)
   if (train) {
-    if (tpw <= 1) FM_LAUNCH(1, true); else if (tpw <= 4) FM_LAUNCH(4, true); else return -3;
+    if (tpw <= 1) FM_LAUNCH(1, true); else if (tpw <= 2) FM_LAUNCH(2, true); else return -3;
   } else {
-    if (tpw <= 1) FM_LAUNCH(1, false); else if (tpw <= 4) FM_LAUNCH(4, false); else return -3;
+    if (tpw <= 1) FM_LAUNCH(1, false); else if (tpw <= 2) FM_LAUNCH(2, false); else return -3;
   }
 #undef FM_LAUNCH
   return 0;

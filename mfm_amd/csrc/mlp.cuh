@@ -6,7 +6,7 @@
 //   4 gate (ht2 -> d, zero-init)   5 j1 (hx2 + ht2 -> hj1)   6 j2 (hj1 -> hj2)   7 out (hj2 -> d, zero-init)
 //   v = out + gate * clip(grad log pi(x))
 //
-// One workgroup = 4 wavefronts owns a tile of 16 chains (one MFMA M-tile; 32 rows when value + tangent are pushed
+// One workgroup = 8 wavefronts (2 per SIMD) owns a tile of 16 chains (one MFMA M-tile; 32 rows when value + tangent are pushed
 // together).  Activations of the tile stay in LDS between layers; weights are streamed L2 -> VGPR once per
 // workgroup as ready-made B operands of v_mfma_f32_16x16x4_f32 (exact f32, SURVEY.md "fp32 tolerance").
 //
@@ -23,8 +23,7 @@
 #include "targets.cuh"
 
 #define MLP_NLAYER 8
-#define MLP_WAVES 4
-#define MLP_THREADS (MLP_WAVES * 64)
+#define MLP_WAVES_FM 8            // waves per workgroup of the flow-matching kernels (2 per SIMD)
 #define MLP_ROWS 16
 
 struct LayerDesc {
@@ -60,43 +59,35 @@ __host__ __device__ __forceinline__ int pack_index_T(int k, int n, int NB) {
 }
 
 // ---- the tile GEMM -------------------------------------------------------------------------------------------
-// acc[m][j] (+)= A[m-tile rows][K] * W[K][tile nt], for the n-tiles nt = wave + 4 q owned by this wave.
+// acc[m] (+)= A[m-tile rows][K] * W[K][tile nt], for the n-tiles nt = wave + NW * q owned by this wave (NW waves per workgroup).
 // A: LDS, row-major, MT*16 rows, leading dimension lda (multiple of 4 floats).  Wp: packed weights of the layer.
-// epi(q, nt, m, acc): called once per finished tile; acc[i] is (row = 16 m + 4 g + i, col = 16 nt + c).
-template <int MT, int NTB, typename Epi>
-__device__ __forceinline__ void layer_gemm(const float* A, int lda, const float* __restrict__ Wp_, int KB, int NT,
-                                           int wave, int lane, Epi epi) {
+// epi(q, nt, m, acc, b): called once per finished tile; acc[i] is (row = 16 m + 4 g + i, col = 16 nt + c), b the
+// layer bias of that column (0 when `bias` is null).
+// 8 waves per workgroup = 2 per SIMD: while one wave sits in an epilogue / barrier / load wait the other keeps the
+// SIMD's matrix pipe busy; a wave's own chain of dependent MFMAs (40-cycle latency vs 32-cycle issue) is hidden too.
+template <int MT, int NW, typename Epi>
+__device__ __forceinline__ void layer_gemm(const float* A, int lda, const float* __restrict__ Wp_,
+                                           const float* __restrict__ bias, int KB, int NT, int wave, int lane, Epi epi) {
   const int r = lane & 15, g = lane >> 4;
-  const f32x4* Wp = reinterpret_cast<const f32x4*>(Wp_);
   const float* arow = A + r * lda + 4 * g;
-  for (int q0 = 0; wave + 4 * q0 < NT; q0 += NTB) {
-    f32x4 acc[MT][NTB];
-    const f32x4* wp[NTB];
-    bool ok[NTB];
+  for (int q = 0; wave + NW * q < NT; ++q) {
+    const int nt = wave + NW * q;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(Wp_) + (size_t)nt * KB * 64 + lane;
+    const float bv = bias ? bias[nt * 16 + (lane & 15)] : 0.f;   // issued ahead of the K loop: its latency hides there
+    f32x4 acc[MT];
 #pragma unroll
-    for (int j = 0; j < NTB; ++j) {
-      int nt = wave + 4 * (q0 + j);
-      ok[j] = nt < NT;
-      wp[j] = Wp + (size_t)(ok[j] ? nt : wave) * KB * 64 + lane;
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Software pipeline at 4-k-block granularity with two register sets: the next group's B fragments are issued
+    // right AFTER the first use of the current group, so the wait the compiler places before that use (it emits
+    // vmcnt(0) across the loop back-edge) only ever covers loads issued a whole group (>= 12 MT MFMAs) earlier.
+    f32x4 cur[4], nxt[4];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // software pipeline: B fragments two k-blocks ahead (ring of 3), A fragment one ahead
-    f32x4 bq[3][NTB];
+    for (int u = 0; u < 4; ++u) cur[u] = wp[(size_t)(u < KB ? u : 0) * 64];
+    for (int kb0 = 0; kb0 < KB; kb0 += 4) {
 #pragma unroll
-    for (int j = 0; j < NTB; ++j) {
-      bq[0][j] = wp[j][0];
-      if (KB > 1) bq[1][j] = wp[j][64];
-    }
-    for (int kb0 = 0; kb0 < KB; kb0 += 3) {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
+      for (int u = 0; u < 4; ++u) {
         const int kb = kb0 + u;
         if (kb < KB) {
-          if (kb + 2 < KB) {
-#pragma unroll
-            for (int j = 0; j < NTB; ++j) bq[(u + 2) % 3][j] = wp[j][(size_t)(kb + 2) * 64];
-          }
           f32x4 a[MT];
 #pragma unroll
           for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * lda + kb * 16);
@@ -104,18 +95,23 @@ __device__ __forceinline__ void layer_gemm(const float* A, int lda, const float*
           for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], cur[u][s], acc[m], 0, 0, 0);
+        }
+        if (u == 0) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-              for (int j = 0; j < NTB; ++j)
-                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], bq[u][j][s], acc[m][j], 0, 0, 0);
+          for (int v = 0; v < 4; ++v) {
+            const int kn = kb0 + 4 + v;
+            nxt[v] = wp[(size_t)(kn < KB ? kn : 0) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) cur[v] = nxt[v];
     }
 #pragma unroll
-    for (int j = 0; j < NTB; ++j)
-      if (ok[j]) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) epi(q0 + j, wave + 4 * (q0 + j), m, acc[m][j]);
-      }
+    for (int m = 0; m < MT; ++m) epi(q, nt, m, acc[m], bv);
   }
 }
 

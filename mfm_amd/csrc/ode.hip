@@ -52,7 +52,7 @@ static OdeArgs ode_args(const NetDev& n, const mfm_config& c, const OdeWs&) {
 struct OdeLds {   // float offsets
   int ff_j1, ldff, ldj1, x, ldx, z, cat, ldcat, x1, ldx1, j2_t1, ldj2, ldt1, red, gcs, total;
 };
-__host__ __device__ inline OdeLds ode_lds_layout(const NetDev& n) {
+__host__ __device__ inline OdeLds ode_lds_layout(const NetDev& n, int NW) {
   OdeLds L; int o = 0;
   auto take = [&](int cnt) { int r = o; o += cnt; return r; };
   L.ldff = n.F2p + 4; L.ldj1 = n.hj1 + 4;
@@ -62,7 +62,7 @@ __host__ __device__ inline OdeLds ode_lds_layout(const NetDev& n) {
   L.ldx1 = n.hx1 + 4; L.x1 = take(32 * L.ldx1);
   L.ldj2 = n.hj2 + 4; L.ldt1 = n.ht1 + 4;
   { int a = 32 * L.ldj2, b = 16 * L.ldt1; L.j2_t1 = take(a > b ? a : b); }
-  L.red = take(8 * 64);      // 8 reduction slots of [4 waves][16 rows]
+  L.red = take(8 * 16 * NW);      // 8 reduction slots of [NW][16 rows]
   L.gcs = take(16 * 24);     // small-d targets: grad[8], hvp[8], inside-mask[8] per row
   L.total = o;
   return L;
@@ -76,7 +76,7 @@ __device__ static const float DP_M[7] = {(float)(6025192743.0 / 30085553152.0 / 
                                          (float)(-2691868925.0 / 45128329728.0 / 2), (float)(187940372067.0 / 1594534317056.0 / 2),
                                          (float)(-1776094331.0 / 19743644256.0 / 2), (float)(11237099.0 / 235043384.0 / 2)};
 
-template <int TPW>
+template <int TPW, int NW>
 struct OdeTile {
   const NetDev* n;
   OdeLds L;
@@ -84,7 +84,8 @@ struct OdeTile {
   int lane, wave, g, c;
   bool hutch;
   int sign;                 // +1 forward (:208-218), -1 inverse (:225-239)
-  float tz1[2][4];          // z W_x1 for this lane's x1-layer tiles (hx1 <= 128 -> <= 2 tiles per wave)
+  float tz1[2][4];          // z W_x1 for this lane's x1-layer tiles (hx1 <= 256 -> <= 2 tiles per wave)
+  float gate[TPW][4];       // nn_t of the last evaluated stage time (kept for stages that share it)
 
   __device__ __forceinline__ float* bFF() { return lds + L.ff_j1; }
   __device__ __forceinline__ float* bJ1() { return lds + L.ff_j1; }
@@ -94,7 +95,7 @@ struct OdeTile {
   __device__ __forceinline__ float* bX1() { return lds + L.x1; }
   __device__ __forceinline__ float* bJ2() { return lds + L.j2_t1; }
   __device__ __forceinline__ float* bT1() { return lds + L.j2_t1; }
-  __device__ __forceinline__ float* red(int slot) { return lds + L.red + slot * 64; }
+  __device__ __forceinline__ float* red(int slot) { return lds + L.red + slot * 16 * NW; }
   __device__ __forceinline__ float* gcs() { return lds + L.gcs; }
 
   // sum over the tile's columns of per-lane partials (rows 4g..4g+3); uses reduction slot `slot`.
@@ -109,14 +110,20 @@ struct OdeTile {
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int row = 4 * g + i; p[i] = r[row] + r[16 + row] + r[32 + row] + r[48 + row]; }
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * g + i;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += r[w * 16 + row];
+      p[i] = t;
+    }
   }
 
   // z W_x1 (no bias), once per solve.  Requires bZ filled and a barrier before.
   __device__ __forceinline__ void precompute_tz1() {
     const LayerDesc& l2 = n->L[2];
-    layer_gemm<1, 2>(bZ() + 4, L.ldx, n->Wp + l2.w_off, l2.Kp / 16, l2.Np / 16, wave, lane,
-                     [&](int q, int nt, int m, f32x4 acc) {
+    layer_gemm<1, NW>(bZ() + 4, L.ldx, n->Wp + l2.w_off, nullptr, l2.Kp / 16, l2.Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                        for (int i = 0; i < 4; ++i) { if (q == 0) tz1[0][i] = acc[i]; else tz1[1][i] = acc[i]; }
                      });
@@ -126,26 +133,46 @@ struct OdeTile {
   // Outputs: kv[q][i] = dx/dt for (row 4g+i, col 16(wave+4q)+c); dl[i] = d(logdet)/dt for row 4g+i (all lanes agree).
   template <bool WANT_JZ = false>
   __device__ __forceinline__ void eval(const float (&tt)[4], float (&kv)[TPW][4], float (&dl)[4], int red_slot,
-                                       float (*jzo)[4] = nullptr) {
+                                       float (*jzo)[4] = nullptr, bool reuse_time = false) {
     const NetDev& N = *n;
     const int d = N.d;
-    // Fourier features (:70-71)
-    for (int nt = wave; nt * 16 < N.F2p; nt += 4) {
-      const int col = nt * 16 + c;
-      const bool is_sin = col >= N.F;
-      const double f = col < 2 * N.F ? (double)N.fourier[is_sin ? col - N.F : col] : 0.0;
+    // Fourier features (:70-71); skipped when this stage shares its time with the previous one (st and the gate
+    // output are still valid: Dopri5 stages 6 and 7 are both at t + dt)
+    if (!reuse_time) {
+      if (N.F % 16 == 0) {        // one sincos per (row, frequency) feeds the cos and the sin block
+        for (int nt = wave; nt < N.F / 16; nt += NW) {
+          const int col = nt * 16 + c;
+          const double f = (double)N.fourier[col];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = 0.f;
-        if (col < 2 * N.F) {
-          const double te = sign > 0 ? (double)tt[i] : 1.0 - (double)tt[i];          // :229
-          double ft = f * te;
-          ft -= rint(ft);
-          float sv, cv;
-          sincospif(2.f * (float)ft, &sv, &cv);
-          v = is_sin ? sv : cv;
+          for (int i = 0; i < 4; ++i) {
+            const double te = sign > 0 ? (double)tt[i] : 1.0 - (double)tt[i];          // :229
+            double ft = f * te;
+            ft -= rint(ft);
+            float sv, cv;
+            sincospif(2.f * (float)ft, &sv, &cv);
+            bFF()[(4 * g + i) * L.ldff + col] = cv;
+            bFF()[(4 * g + i) * L.ldff + N.F + col] = sv;
+          }
         }
-        bFF()[(4 * g + i) * L.ldff + col] = v;
+      } else {
+        for (int nt = wave; nt * 16 < N.F2p; nt += NW) {
+          const int col = nt * 16 + c;
+          const bool is_sin = col >= N.F;
+          const double f = col < 2 * N.F ? (double)N.fourier[is_sin ? col - N.F : col] : 0.0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = 0.f;
+            if (col < 2 * N.F) {
+              const double te = sign > 0 ? (double)tt[i] : 1.0 - (double)tt[i];          // :229
+              double ft = f * te;
+              ft -= rint(ft);
+              float sv, cv;
+              sincospif(2.f * (float)ft, &sv, &cv);
+              v = is_sin ? sv : cv;
+            }
+            bFF()[(4 * g + i) * L.ldff + col] = v;
+          }
+        }
       }
     }
     if (N.T.kind == MFM_TARGET_GMM && threadIdx.x < 16) {    // small-d target: grad / hvp per row by one thread
@@ -162,15 +189,14 @@ struct OdeTile {
     }
     __syncthreads();
     // t1 ; x1 (value rows; tangent rows = relu' * (z W_x1))
-    layer_gemm<1, 2>(bFF(), L.ldff, N.Wp + N.L[0].w_off, N.L[0].Kp / 16, N.L[0].Np / 16, wave, lane,
-                     [&](int q, int nt, int m, f32x4 acc) {
-                       const float b = N.bias[N.L[0].b_off + nt * 16 + c];
+    if (!reuse_time)
+    layer_gemm<1, NW>(bFF(), L.ldff, N.Wp + N.L[0].w_off, N.bias + N.L[0].b_off, N.L[0].Kp / 16, N.L[0].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                        for (int i = 0; i < 4; ++i) bT1()[(4 * g + i) * L.ldt1 + nt * 16 + c] = fmaxf(acc[i] + b, 0.f);
                      });
-    layer_gemm<1, 2>(bX() + 4, L.ldx, N.Wp + N.L[2].w_off, N.L[2].Kp / 16, N.L[2].Np / 16, wave, lane,
-                     [&](int q, int nt, int m, f32x4 acc) {
-                       const float b = N.bias[N.L[2].b_off + nt * 16 + c];
+    layer_gemm<1, NW>(bX() + 4, L.ldx, N.Wp + N.L[2].w_off, N.bias + N.L[2].b_off, N.L[2].Kp / 16, N.L[2].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                        for (int i = 0; i < 4; ++i) {
                          const float pre = acc[i] + b;
@@ -182,17 +208,16 @@ struct OdeTile {
                      });
     __syncthreads();
     // t2 -> st (value rows only) ; x2 on value + tangent rows
-    layer_gemm<1, 2>(bT1(), L.ldt1, N.Wp + N.L[1].w_off, N.L[1].Kp / 16, N.L[1].Np / 16, wave, lane,
-                     [&](int q, int nt, int m, f32x4 acc) {
-                       const float b = N.bias[N.L[1].b_off + nt * 16 + c];
+    if (!reuse_time)
+    layer_gemm<1, NW>(bT1(), L.ldt1, N.Wp + N.L[1].w_off, N.bias + N.L[1].b_off, N.L[1].Kp / 16, N.L[1].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                        for (int i = 0; i < 4; ++i) bCat()[(4 * g + i) * L.ldcat + N.hx2 + nt * 16 + c] = fmaxf(acc[i] + b, 0.f);
                      });
     {
       f32x4 keep = {0, 0, 0, 0};   // value pre-activation of the same tile, handed from m = 0 to m = 1
-      layer_gemm<2, 2>(bX1(), L.ldx1, N.Wp + N.L[3].w_off, N.L[3].Kp / 16, N.L[3].Np / 16, wave, lane,
-                       [&](int q, int nt, int m, f32x4 acc) {
-                         const float b = N.bias[N.L[3].b_off + nt * 16 + c];
+      layer_gemm<2, NW>(bX1(), L.ldx1, N.Wp + N.L[3].w_off, N.bias + N.L[3].b_off, N.L[3].Kp / 16, N.L[3].Np / 16, wave, lane,
+                       [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                          for (int i = 0; i < 4; ++i) {
                            const int o = (4 * g + i) * L.ldcat + nt * 16 + c;
@@ -203,10 +228,9 @@ struct OdeTile {
     }
     __syncthreads();
     // gate (registers) ; j1
-    float gate[TPW][4];
-    layer_gemm<1, 2>(bCat() + N.hx2, L.ldcat, N.Wp + N.L[4].w_off, N.L[4].Kp / 16, N.L[4].Np / 16, wave, lane,
-                     [&](int q, int nt, int m, f32x4 acc) {
-                       const float b = N.bias[N.L[4].b_off + nt * 16 + c];
+    if (!reuse_time)
+    layer_gemm<1, NW>(bCat() + N.hx2, L.ldcat, N.Wp + N.L[4].w_off, N.bias + N.L[4].b_off, N.L[4].Kp / 16, N.L[4].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                        for (int qq = 0; qq < TPW; ++qq)
                          if (qq == q) {
@@ -216,9 +240,8 @@ struct OdeTile {
                      });
     {
       f32x4 keep = {0, 0, 0, 0};
-      layer_gemm<2, 2>(bCat(), L.ldcat, N.Wp + N.L[5].w_off, N.L[5].Kp / 16, N.L[5].Np / 16, wave, lane,
-                       [&](int q, int nt, int m, f32x4 acc) {
-                         const float b = N.bias[N.L[5].b_off + nt * 16 + c];
+      layer_gemm<2, NW>(bCat(), L.ldcat, N.Wp + N.L[5].w_off, N.bias + N.L[5].b_off, N.L[5].Kp / 16, N.L[5].Np / 16, wave, lane,
+                       [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                          for (int i = 0; i < 4; ++i) {
                            const int o = (4 * g + i) * L.ldj1 + nt * 16 + c;
@@ -230,9 +253,8 @@ struct OdeTile {
     __syncthreads();
     {
       f32x4 keep = {0, 0, 0, 0};
-      layer_gemm<2, 2>(bJ1(), L.ldj1, N.Wp + N.L[6].w_off, N.L[6].Kp / 16, N.L[6].Np / 16, wave, lane,
-                       [&](int q, int nt, int m, f32x4 acc) {
-                         const float b = N.bias[N.L[6].b_off + nt * 16 + c];
+      layer_gemm<2, NW>(bJ1(), L.ldj1, N.Wp + N.L[6].w_off, N.bias + N.L[6].b_off, N.L[6].Kp / 16, N.L[6].Np / 16, wave, lane,
+                       [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                          for (int i = 0; i < 4; ++i) {
                            const int o = (4 * g + i) * L.ldj2 + nt * 16 + c;
@@ -245,37 +267,37 @@ struct OdeTile {
     // out: v = nn_xt + nn_t * clip(grad log pi(x)) (:88-90);  J z = d nn_xt . z + nn_t * 1[|g| <= clip] * (H z)
     float dpart[4] = {0.f, 0.f, 0.f, 0.f};
     {
-      f32x4 vkeep = {0, 0, 0, 0};
-      layer_gemm<2, 2>(bJ2(), L.ldj2, N.Wp + N.L[7].w_off, N.L[7].Kp / 16, N.L[7].Np / 16, wave, lane,
-                       [&](int q, int nt, int m, f32x4 acc) {
+      f32x4 hzk = {0, 0, 0, 0};      // masked Hessian-vector product of the tile, handed from m = 0 to m = 1
+      layer_gemm<2, NW>(bJ2(), L.ldj2, N.Wp + N.L[7].w_off, N.bias + N.L[7].b_off, N.L[7].Kp / 16, N.L[7].Np / 16, wave, lane,
+                       [&](int q, int nt, int m, f32x4 acc, float b) {
                          const int col = nt * 16 + c;
-                         const float b = N.bias[N.L[7].b_off + col];
 #pragma unroll
                          for (int i = 0; i < 4; ++i) {
                            const int row = 4 * g + i;
                            float gt = 0.f;
 #pragma unroll
                            for (int qq = 0; qq < TPW; ++qq) gt = (qq == q) ? gate[qq][i] : gt;
-                           float gc = 0.f, hz = 0.f;
-                           if (col < d) {
-                             if (N.T.kind == MFM_TARGET_PHI4) {
-                               const float* xr = bX() + row * L.ldx + 4;
-                               const float graw = phi4_grad(N.T, xr, col);
-                               gc = clipf(graw, N.grad_clip);
-                               const bool inside = !(N.grad_clip > 0.f) || fabsf(graw) <= N.grad_clip;
-                               if (m == 1 && inside) hz = phi4_hvp(N.T, xr, bZ() + row * L.ldx + 4, col);
-                             } else {
-                               gc = gcs()[row * 24 + col];
-                               hz = gcs()[row * 24 + 8 + col];
-                             }
-                           }
                            if (m == 0) {
+                             float gc = 0.f, hz = 0.f;
+                             if (col < d) {
+                               if (N.T.kind == MFM_TARGET_PHI4) {
+                                 const float* xr = bX() + row * L.ldx + 4;
+                                 const float graw = phi4_grad(N.T, xr, col);
+                                 gc = clipf(graw, N.grad_clip);
+                                 const bool inside = !(N.grad_clip > 0.f) || fabsf(graw) <= N.grad_clip;
+                                 if (hutch && inside) hz = phi4_hvp(N.T, xr, bZ() + row * L.ldx + 4, col);
+                               } else {
+                                 gc = gcs()[row * 24 + col];
+                                 hz = gcs()[row * 24 + 8 + col];
+                               }
+                             }
+                             hzk[i] = hz;
                              const float v = col < d ? acc[i] + b + gt * gc : 0.f;
 #pragma unroll
                              for (int qq = 0; qq < TPW; ++qq)
                                if (qq == q) kv[qq][i] = sign > 0 ? v : -v;
                            } else if (col < d) {
-                             const float jz = acc[i] + gt * hz;
+                             const float jz = acc[i] + gt * hzk[i];
                              dpart[i] += bZ()[row * L.ldx + 4 + col] * jz;
                              if (WANT_JZ) {
 #pragma unroll
@@ -309,13 +331,13 @@ __device__ static const float DP_TAB[8][7] = {   // [phase][j]: input = y + h * 
     {9017.f / 3168, -355.f / 33, 46732.f / 5247, 49.f / 176, -5103.f / 18656, 0, 1.f},
     {35.f / 384, 0, 500.f / 1113, 125.f / 192, -2187.f / 6784, 11.f / 84, 1.f}};
 
-template <int TPW>
-__device__ __forceinline__ void ode_solve(OdeTile<TPW>& T, float rtol, float atol, int max_attempts,
+template <int TPW, int NW>
+__device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float atol, int max_attempts,
                                           float (&y)[TPW][4], float (&ell)[4], int (&natt)[4]) {
   const NetDev& N = *T.n;
   const int d = N.d, g = T.g, c = T.c, wave = T.wave;
   const float inv_n = 1.f / (float)(d + 1);
-  auto colmask = [&](int q) { return (wave + 4 * q) * 16 + c < d; };
+  auto colmask = [&](int q) { return (wave + NW * q) * 16 + c < d; };
 
   float k[7][TPW][4], kl[7][4];
   float t[4], dt[4], h0[4], d1[4];
@@ -346,7 +368,7 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW>& T, float rtol, float ato
     for (int i = 0; i < 4; ++i) { hs[i] = phase == 1 ? h0[i] : dt[i]; ts[i] = t[i] + hs[i] * cf[6]; }
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-      const int col = (wave + 4 * q) * 16 + c;
+      const int col = (wave + NW * q) * 16 + c;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float acc = 0.f;
@@ -360,8 +382,12 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW>& T, float rtol, float ato
       }
     }
     __syncthreads();
-    float kv[TPW][4], dlv[4];
-    T.eval(ts, kv, dlv, phase & 1);
+    float kv[TPW][4], dlv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) kv[q][i] = 0.f;      // waves that own no output tile never write kv
+    T.eval(ts, kv, dlv, phase & 1, nullptr, phase == 7);
     // ---- route the result: phase 0 -> k[0], phase 1 -> k[1], phase p >= 2 -> k[p - 1] ----
     const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
 #pragma unroll
@@ -506,12 +532,12 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW>& T, float rtol, float ato
 }
 
 // fill bZ with the Hutchinson probe of each row (normal(key, (d,)), :212 / :232) or zero it
-template <int TPW>
-__device__ __forceinline__ void fill_probe(OdeTile<TPW>& T, const Key2 (&kz)[4], bool hutch) {
+template <int TPW, int NW>
+__device__ __forceinline__ void fill_probe(OdeTile<TPW, NW>& T, const Key2 (&kz)[4], bool hutch) {
   const NetDev& N = *T.n;
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
-    const int col = (T.wave + 4 * q) * 16 + T.c;
+    const int col = (T.wave + NW * q) * 16 + T.c;
     if (col < N.dp) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -520,21 +546,25 @@ __device__ __forceinline__ void fill_probe(OdeTile<TPW>& T, const Key2 (&kz)[4],
   }
 }
 
-template <int TPW>
-__device__ __forceinline__ void tile_init(OdeTile<TPW>& T, const NetDev* n, float* lds, bool hutch) {
-  T.n = n; T.L = ode_lds_layout(*n); T.lds = lds;
+template <int TPW, int NW>
+__device__ __forceinline__ void tile_init(OdeTile<TPW, NW>& T, const NetDev* n, float* lds, bool hutch) {
+  T.n = n; T.L = ode_lds_layout(*n, NW); T.lds = lds;
   T.lane = threadIdx.x & 63; T.wave = threadIdx.x >> 6; T.g = T.lane >> 4; T.c = T.lane & 15;
   T.hutch = hutch; T.sign = 1;
-  for (int i = threadIdx.x; i < T.L.total; i += MLP_THREADS) lds[i] = 0.f;     // pads, tangent rows of st, scratch
+  for (int i = threadIdx.x; i < T.L.total; i += (NW * 64)) lds[i] = 0.f;     // pads, tangent rows of st, scratch
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { T.tz1[0][i] = 0.f; T.tz1[1][i] = 0.f; }
+  for (int i = 0; i < 4; ++i) {
+    T.tz1[0][i] = 0.f; T.tz1[1][i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) T.gate[q][i] = 0.f;
+  }
   __syncthreads();
 }
 
-template <int TPW>
-__global__ __launch_bounds__(MLP_THREADS) void ode_transform_kernel(OdeArgs a) {
+template <int TPW, int NW>
+__global__ __launch_bounds__(NW * 64) void ode_transform_kernel(OdeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  OdeTile<TPW> T;
+  OdeTile<TPW, NW> T;
   tile_init(T, &a.net, lds, a.hutch != 0);
   T.sign = a.direction;
   const int b0 = blockIdx.x * 16, d = a.net.d;
@@ -548,14 +578,14 @@ __global__ __launch_bounds__(MLP_THREADS) void ode_transform_kernel(OdeArgs a) {
   float y[TPW][4], ell[4]; int natt[4];
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
-    const int col = (T.wave + 4 * q) * 16 + T.c;
+    const int col = (T.wave + NW * q) * 16 + T.c;
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[q][i] = col < d ? a.in[(size_t)(b0 + 4 * T.g + i) * d + col] : 0.f;
   }
-  ode_solve<TPW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
+  ode_solve<TPW, NW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
-    const int col = (T.wave + 4 * q) * 16 + T.c;
+    const int col = (T.wave + NW * q) * 16 + T.c;
     if (col < d) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) a.out[(size_t)(b0 + 4 * T.g + i) * d + col] = y[q][i];
@@ -571,11 +601,11 @@ __global__ __launch_bounds__(MLP_THREADS) void ode_transform_kernel(OdeArgs a) {
 }
 
 // v(x, t) and J z for n samples (mfm_vf_apply): one field evaluation per tile.
-template <int TPW>
-__global__ __launch_bounds__(MLP_THREADS) void vf_apply_kernel(NetDev net, const float* x, const float* t, const float* tan, int n,
+template <int TPW, int NW>
+__global__ __launch_bounds__(NW * 64) void vf_apply_kernel(NetDev net, const float* x, const float* t, const float* tan, int n,
                                                                float* v, float* jvp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  OdeTile<TPW> T;
+  OdeTile<TPW, NW> T;
   tile_init(T, &net, lds, tan != nullptr);
   const int b0 = blockIdx.x * 16, d = net.d;
   float tt[4];
@@ -583,7 +613,7 @@ __global__ __launch_bounds__(MLP_THREADS) void vf_apply_kernel(NetDev net, const
   for (int i = 0; i < 4; ++i) tt[i] = t[b0 + 4 * T.g + i];
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
-    const int col = (T.wave + 4 * q) * 16 + T.c;
+    const int col = (T.wave + NW * q) * 16 + T.c;
     if (col < d) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -603,7 +633,7 @@ __global__ __launch_bounds__(MLP_THREADS) void vf_apply_kernel(NetDev net, const
   T.template eval<true>(tt, kv, dl, 0, jz);
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
-    const int col = (T.wave + 4 * q) * 16 + T.c;
+    const int col = (T.wave + NW * q) * 16 + T.c;
     if (col < d) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -616,67 +646,71 @@ __global__ __launch_bounds__(MLP_THREADS) void vf_apply_kernel(NetDev net, const
 }
 
 // One flow-based MH step per chain (random-walk in latent space :264-278, or independent :246-260).
-template <int TPW>
-__global__ __launch_bounds__(MLP_THREADS) void flow_step_kernel(OdeArgs a, FlowArgs f) {
+template <int TPW, int NW>
+__global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  OdeTile<TPW> T;
+  OdeTile<TPW, NW> T;
   tile_init(T, &a.net, lds, a.hutch != 0);
   const NetDev& N = a.net;
   const int b0 = blockIdx.x * 16, d = N.d, g = T.g, c = T.c, wave = T.wave;
-  Key2 k_gen[4], k_acc[4], k_h1[4], k_h2[4];
+  Key2 kb[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const Key2 kb = split_at(f.key, f.n_total, f.chain_offset + (uint32_t)(b0 + 4 * g + i));     // :303
-    k_gen[i] = split_at(kb, 4, 0); k_acc[i] = split_at(kb, 4, 1);                                // :265 / :247
-    k_h1[i] = split_at(kb, 4, 2); k_h2[i] = split_at(kb, 4, 3);
-  }
-  float y[TPW][4], ell[4], vol0[4], lq_ref[4] = {0, 0, 0, 0};
-  int natt[4], natt_tot[4];
-  // ---- inverse solve from the current position (:267 / :251) ----
+  for (int i = 0; i < 4; ++i)
+    kb[i] = split_at(f.key, f.n_total, f.chain_offset + (uint32_t)(b0 + 4 * g + i));             // :303
+  // sub-keys of :265 / :247 are re-derived where they are used: key_gen 0, key_acc 1, key_hutch1 2, key_hutch2 3
+  float y[TPW][4], ell[4], vol0[4] = {0, 0, 0, 0}, lq_ref[4] = {0, 0, 0, 0};
+  int natt[4], natt_tot[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int q = 0; q < TPW; ++q) {
-    const int col = (wave + 4 * q) * 16 + c;
+  for (int ph = 0; ph < 2; ++ph) {       // fully unrolled: two inlined copies of the solver (ONE call site of the solver: inverse solve, then forward solve of the proposal
+    Key2 kz[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[q][i] = col < d ? f.pos[(size_t)(b0 + 4 * g + i) * d + col] : 0.f;
-  }
-  fill_probe(T, k_h2, T.hutch);
-  T.sign = -1;
-  ode_solve<TPW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
+    for (int i = 0; i < 4; ++i) kz[i] = split_at(kb[i], 4, ph == 0 ? 3 : 2);
+    if (ph == 0) {
+      // ---- inverse solve from the current position (:267 / :251) ----
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { vol0[i] = ell[i]; natt_tot[i] = natt[i]; }
-  // ---- proposal in latent space ----
-  {
-    float r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
-    const float scale = 2.38f / sqrtf((float)d);                                                  // :262
+      for (int q = 0; q < TPW; ++q) {
+        const int col = (wave + NW * q) * 16 + c;
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-      const int col = (wave + 4 * q) * 16 + c;
-      if (col < d) {
+        for (int i = 0; i < 4; ++i) y[q][i] = col < d ? f.pos[(size_t)(b0 + 4 * g + i) * d + col] : 0.f;
+      }
+    } else {
+      // ---- proposal in latent space ----
+      float r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
+      const float scale = 2.38f / sqrtf((float)d);                                                  // :262
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float nz = (float)normal64(k_gen[i], (uint32_t)col, (uint32_t)d);
-          if (f.mode == MFM_FLOW_RWMH) y[q][i] = y[q][i] + scale * nz;                            // :268
-          else { r0[i] += y[q][i] * y[q][i]; y[q][i] = nz; r1[i] += nz * nz; }                    // :249
+      for (int q = 0; q < TPW; ++q) {
+        const int col = (wave + NW * q) * 16 + c;
+        if (col < d) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float nz = (float)normal64(split_at(kb[i], 4, 0), (uint32_t)col, (uint32_t)d);
+            if (f.mode == MFM_FLOW_RWMH) y[q][i] = y[q][i] + scale * nz;                            // :268
+            else { r0[i] += y[q][i] * y[q][i]; y[q][i] = nz; r1[i] += nz * nz; }                    // :249
+          }
         }
       }
-    }
-    if (f.mode == MFM_FLOW_IMH) {     // ref.logprob(u0) - ref.logprob(up) = -(|u0|^2 - |up|^2) / 2   (:254-255)
-      __syncthreads();
-      T.row_reduce(r0, 5); T.row_reduce(r1, 6);
+      if (f.mode == MFM_FLOW_IMH) {     // ref.logprob(u0) - ref.logprob(up) = -(|u0|^2 - |up|^2) / 2   (:254-255)
+        __syncthreads();
+        T.row_reduce(r0, 5); T.row_reduce(r1, 6);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) lq_ref[i] = -0.5f * (r0[i] - r1[i]);
+        for (int i = 0; i < 4; ++i) lq_ref[i] = -0.5f * (r0[i] - r1[i]);
+      }
+      __syncthreads();
+    }
+    fill_probe(T, kz, T.hutch);
+    T.sign = ph == 0 ? -1 : 1;
+    ode_solve<TPW, NW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (ph == 0) vol0[i] = ell[i];
+      natt_tot[i] += natt[i];
     }
   }
-  // ---- forward solve of the proposal (:269 / :250) ----
-  __syncthreads();
-  fill_probe(T, k_h1, T.hutch);
-  T.sign = 1;
-  ode_solve<TPW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
   // ---- target at the proposal (:270 / :252), tempered: beta * loglik + logprior ----
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
-    const int col = (wave + 4 * q) * 16 + c;
+    const int col = (wave + NW * q) * 16 + c;
     if (col < N.dp) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) T.bX()[(4 * g + i) * T.L.ldx + 4 + col] = col < d ? y[q][i] : 0.f;
@@ -689,7 +723,7 @@ __global__ __launch_bounds__(MLP_THREADS) void flow_step_kernel(OdeArgs a, FlowA
     double part[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-      const int col = (wave + 4 * q) * 16 + c;
+      const int col = (wave + NW * q) * 16 + c;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         gnew[q][i] = 0.f;
@@ -700,7 +734,7 @@ __global__ __launch_bounds__(MLP_THREADS) void flow_step_kernel(OdeArgs a, FlowA
         }
       }
     }
-    double* rd = reinterpret_cast<double*>(T.red(0));      // slots 0..1 as [4 waves][16 rows] doubles
+    double* rd = reinterpret_cast<double*>(T.red(0));      // slots 0..1 as [NW][16 rows] doubles
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -709,7 +743,13 @@ __global__ __launch_bounds__(MLP_THREADS) void flow_step_kernel(OdeArgs a, FlowA
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int row = 4 * g + i; lpn[i] = f.beta * (rd[row] + rd[16 + row] + rd[32 + row] + rd[48 + row]); }
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * g + i;
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += rd[w * 16 + row];
+      lpn[i] = f.beta * t;
+    }
   } else {
     double* rd = reinterpret_cast<double*>(T.red(0));
     if (threadIdx.x < 16) {
@@ -723,7 +763,7 @@ __global__ __launch_bounds__(MLP_THREADS) void flow_step_kernel(OdeArgs a, FlowA
     for (int i = 0; i < 4; ++i) lpn[i] = f.beta * rd[4 * g + i];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-      const int col = (wave + 4 * q) * 16 + c;
+      const int col = (wave + NW * q) * 16 + c;
 #pragma unroll
       for (int i = 0; i < 4; ++i) gnew[q][i] = col < d ? (float)f.beta * T.gcs()[(4 * g + i) * 24 + col] : 0.f;
     }
@@ -737,13 +777,13 @@ __global__ __launch_bounds__(MLP_THREADS) void flow_step_kernel(OdeArgs a, FlowA
     const double lp_old = f.logp[b];
     const double la = lpn[i] - (double)ell[i] - lp_old - (double)vol0[i] + (double)lq_ref[i];
     const double ap = exp(la);
-    const double u = uniform01(k_acc[i], 0, 1);
+    const double u = uniform01(split_at(kb[i], 4, 1), 0, 1);
     acc[i] = u <= ap;                     // NaN compares false -> reject
     aprob[i] = (float)ap;
   }
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
-    const int col = (wave + 4 * q) * 16 + c;
+    const int col = (wave + NW * q) * 16 + c;
     if (col < d) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -760,34 +800,41 @@ __global__ __launch_bounds__(MLP_THREADS) void flow_step_kernel(OdeArgs a, FlowA
       if (acc[i]) f.logp[b] = lpn[i];
       if (f.acc_prob) f.acc_prob[b] = aprob[i];
       if (f.accepted) f.accepted[b] = acc[i] ? 1 : 0;
-      if (f.nsteps) f.nsteps[b] = natt_tot[i] + natt[i];
+      if (f.nsteps) f.nsteps[b] = natt_tot[i];
     }
   }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------
+// ODE_NW: waves per workgroup of the solver kernels.  4 = one wave per SIMD with a 512-register budget (the seven
+// Runge-Kutta stages stay in registers without spilling); 8 = two per SIMD with 256 registers each.
+#ifndef ODE_NW
+#define ODE_NW 4
+#endif
 static int ode_check(const NetDev& n, size_t& sm, int& tpw) {
-  const OdeLds L = ode_lds_layout(n);
+  const OdeLds L = ode_lds_layout(n, ODE_NW);
   sm = (size_t)L.total * sizeof(float);
-  tpw = (n.dp / 16 + 3) / 4;
-  if (sm > 160 * 1024 || tpw > 4 || n.hx1 > 128) return -3;
+  tpw = (n.dp / 16 + ODE_NW - 1) / ODE_NW;
+  if (sm > 160 * 1024 || tpw > 2 * (8 / ODE_NW) || n.hx1 > 16 * 2 * ODE_NW) return -3;
   return 0;
 }
-#define ODE_LAUNCH(KERN, GRID, ...)                                                                                    \
+#define ODE_LAUNCH_T(KERN, T, GRID, ...)                                                                               \
   do {                                                                                                                 \
-    if (tpw <= 1) {                                                                                                    \
-      (void)hipFuncSetAttribute((const void*)KERN<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                 \
-      hipLaunchKernelGGL(KERN<1>, GRID, dim3(MLP_THREADS), sm, stream, __VA_ARGS__);                                  \
-    } else {                                                                                                           \
-      (void)hipFuncSetAttribute((const void*)KERN<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                 \
-      hipLaunchKernelGGL(KERN<4>, GRID, dim3(MLP_THREADS), sm, stream, __VA_ARGS__);                                  \
-    }                                                                                                                  \
+    (void)hipFuncSetAttribute((const void*)KERN<T, ODE_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);      \
+    hipLaunchKernelGGL((KERN<T, ODE_NW>), GRID, dim3(ODE_NW * 64), sm, stream, __VA_ARGS__);                           \
   } while (0)
+#if ODE_NW == 8
+#define ODE_LAUNCH(KERN, GRID, ...)                                                                                    \
+  do { if (tpw <= 1) ODE_LAUNCH_T(KERN, 1, GRID, __VA_ARGS__); else ODE_LAUNCH_T(KERN, 2, GRID, __VA_ARGS__); } while (0)
+#else
+#define ODE_LAUNCH(KERN, GRID, ...)                                                                                    \
+  do { if (tpw <= 1) ODE_LAUNCH_T(KERN, 1, GRID, __VA_ARGS__); else ODE_LAUNCH_T(KERN, 4, GRID, __VA_ARGS__); } while (0)
+#endif
 
 int launch_ode_transform(const OdeArgs& a, hipStream_t stream) {
   size_t sm; int tpw;
   if (ode_check(a.net, sm, tpw)) return -3;
-  if (!a.hutch) return -2;   // exact trace: see launch_flow_step
+  if (!a.hutch) return -2;   // exact trace: not built yet
   ODE_LAUNCH(ode_transform_kernel, dim3(a.n / 16), a);
   return 0;
 }

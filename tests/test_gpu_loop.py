@@ -35,7 +35,7 @@ def test_phi4_loop_matches_oracle():
     np.testing.assert_allclose(m[:3, 0], tr["loss"][:3], rtol=1e-6)      # before the first flow step: same chains, same noise
     np.testing.assert_allclose(m[:, 0], tr["loss"], rtol=1e-3)           # after it: adaptive-solver decisions may differ
     np.testing.assert_allclose(ex["lrs"], tr["learning_rate"], rtol=1e-12)
-    np.testing.assert_allclose(ex["betas"], tr["beta"], rtol=1e-4)
+    np.testing.assert_allclose(ex["betas"], tr["beta"], rtol=2e-3)
     mala_it = [i for i in range(12) if (i + 1) % 4 != 0]
     np.testing.assert_allclose(m[mala_it, 1], np.array(tr["acc_mean"])[mala_it], atol=2e-3)
     np.testing.assert_allclose(m[mala_it, 2], np.array(tr["acc_std"])[mala_it], atol=5e-3)
