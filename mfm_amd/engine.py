@@ -31,6 +31,35 @@ def shard(n_total, rank, world):
     return n_local, rank * n_local
 
 
+def allreduce_sum_(*tensors):
+    """In-place SUM all-reduce of each tensor over the default process group (no-op without one)."""
+    td = _dist()
+    if td and td.get_world_size() > 1:
+        for t in tensors:
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+    return tensors
+
+
+def allgather_cat(t):
+    """Concatenate equally sized per-rank shards in rank order."""
+    import torch
+    td = _dist()
+    if td and td.get_world_size() > 1:
+        parts = [torch.empty_like(t) for _ in range(td.get_world_size())]
+        td.all_gather(parts, t)
+        return torch.cat(parts)
+    return t
+
+
+def global_mean_std(x, n_total):
+    """Mean / population std over ALL chains of a per-chain quantity held as per-rank shards."""
+    import torch
+    s = torch.stack([x.double().sum(), (x.double() ** 2).sum()])
+    allreduce_sum_(s)
+    mean = s[0] / n_total
+    return mean, (s[1] / n_total - mean * mean).clamp_min(0).sqrt()
+
+
 class Engine:
     def __init__(self, dist, args, fourier_random=None, max_eval_samples=0):
         import torch
@@ -91,21 +120,12 @@ class Engine:
         return out
 
     def all_logliks(self, pos):
-        ll = self.loglik(pos)
-        td = _dist()
-        if td and self.world > 1:
-            parts = [self.torch.empty_like(ll) for _ in range(self.world)]
-            td.all_gather(parts, ll)
-            ll = self.torch.cat(parts)
-        return ll
+        return allgather_cat(self.loglik(pos))
 
     # ---- one training step on the local chains (exe_flow_matching.py:362-368) -----------------------------------
     def train_step(self, key, positions):
         self.ctx.fm_loss_grad(key, positions, self.loss, self.grads)
-        td = _dist()
-        if td and self.world > 1:
-            td.all_reduce(self.grads, op=td.ReduceOp.SUM)        # the loss is a SUM over chains (:178)
-            td.all_reduce(self.loss, op=td.ReduceOp.SUM)
+        allreduce_sum_(self.grads, self.loss)                    # the loss is a SUM over chains (:178)
         self.ctx.adamw_step(self.grads)
         return self.loss
 
@@ -116,13 +136,7 @@ class Engine:
 
     def mean_std(self, x):
         """Global mean / population std of a per-chain quantity (acceptance rate, exe_flow_matching.py:442-443)."""
-        t = self.torch
-        s = t.stack([x.double().sum(), (x.double() ** 2).sum()])
-        td = _dist()
-        if td and self.world > 1:
-            td.all_reduce(s, op=td.ReduceOp.SUM)
-        mean = s[0] / self.n_total
-        return mean, (s[1] / self.n_total - mean * mean).clamp_min(0).sqrt()
+        return global_mean_std(x, self.n_total)
 
     def close(self):
         self.ctx.close()
