@@ -50,7 +50,7 @@ static OdeArgs ode_args(const NetDev& n, const mfm_config& c, const OdeWs&) {
 }
 
 struct OdeLds {   // float offsets
-  int ff_j1, ldff, ldj1, x, ldx, z, cat, ldcat, x1, ldx1, j2_t1, ldj2, ldt1, red, gcs, total;
+  int ff_j1, ldff, ldj1, x, ldx, z, cat, ldcat, x1, ldx1, j2_t1, ldj2, ldt1, red, gcs, rs, total;
 };
 __host__ __device__ inline OdeLds ode_lds_layout(const NetDev& n, int NW) {
   OdeLds L; int o = 0;
@@ -64,6 +64,7 @@ __host__ __device__ inline OdeLds ode_lds_layout(const NetDev& n, int NW) {
   { int a = 32 * L.ldj2, b = 16 * L.ldt1; L.j2_t1 = take(a > b ? a : b); }
   L.red = take(8 * 16 * NW);      // 8 reduction slots of [NW][16 rows]
   L.gcs = take(16 * 24);     // small-d targets: grad[8], hvp[8], inside-mask[8] per row
+  L.rs = take(16 * 16);      // per-row solver state (t, dt, h0, d1, ell, kl[7], natt, done): 16 arrays of 16 rows
   L.total = o;
   return L;
 }
@@ -84,7 +85,7 @@ struct OdeTile {
   int lane, wave, g, c;
   bool hutch;
   int sign;                 // +1 forward (:208-218), -1 inverse (:225-239)
-  float tz1[2][4];          // z W_x1 for this lane's x1-layer tiles (hx1 <= 256 -> <= 2 tiles per wave)
+  float tz1[2][4];          // z W_x1 for this lane's x1-layer tiles (<= 2 tiles per wave)
   float gate[TPW][4];       // nn_t of the last evaluated stage time (kept for stages that share it)
 
   __device__ __forceinline__ float* bFF() { return lds + L.ff_j1; }
@@ -97,6 +98,12 @@ struct OdeTile {
   __device__ __forceinline__ float* bT1() { return lds + L.j2_t1; }
   __device__ __forceinline__ float* red(int slot) { return lds + L.red + slot * 16 * NW; }
   __device__ __forceinline__ float* gcs() { return lds + L.gcs; }
+  // per-row solver state: every lane needs the values of its 4 rows (4g..4g+3) -> one ds_read_b128 per field;
+  // they are written by ONE lane per row group (wave 0, c == 0) and become visible at the next barrier
+  __device__ __forceinline__ f32x4 rs_get(int field) { return *reinterpret_cast<const f32x4*>(lds + L.rs + field * 16 + 4 * g); }
+  __device__ __forceinline__ void rs_put(int field, const float (&v)[4]) {
+    if (wave == 0 && c == 0) *reinterpret_cast<f32x4*>(lds + L.rs + field * 16 + 4 * g) = f32x4{v[0], v[1], v[2], v[3]};
+  }
 
   // sum over the tile's columns of per-lane partials (rows 4g..4g+3); uses reduction slot `slot`.
   // The caller guarantees a barrier between two uses of the same slot.
@@ -331,6 +338,8 @@ __device__ static const float DP_TAB[8][7] = {   // [phase][j]: input = y + h * 
     {9017.f / 3168, -355.f / 33, 46732.f / 5247, 49.f / 176, -5103.f / 18656, 0, 1.f},
     {35.f / 384, 0, 500.f / 1113, 125.f / 192, -2187.f / 6784, 11.f / 84, 1.f}};
 
+enum { RS_T = 0, RS_DT = 1, RS_H0 = 2, RS_D1 = 3, RS_ELL = 4, RS_KL = 5 /* ..11 */, RS_NATT = 12, RS_DONE = 13 };
+
 template <int TPW, int NW>
 __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float atol, int max_attempts,
                                           float (&y)[TPW][4], float (&ell)[4], int (&natt)[4]) {
@@ -339,19 +348,21 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
   const float inv_n = 1.f / (float)(d + 1);
   auto colmask = [&](int q) { return (wave + NW * q) * 16 + c < d; };
 
-  float k[7][TPW][4], kl[7][4];
-  float t[4], dt[4], h0[4], d1[4];
-  bool done[4];
+  // The seven stage derivatives of x stay in registers (accumulator layout).  Everything that is per ROW (time,
+  // step, log-det and its stage derivatives, counters) lives in the LDS row-state block: all lanes would compute
+  // identical copies, and at two waves per SIMD the registers are needed for the MFMA pipeline instead.
+  float k[7][TPW][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { t[i] = 0.f; dt[i] = 0.f; h0[i] = 0.f; d1[i] = 0.f; ell[i] = 0.f; natt[i] = 0; done[i] = false; }
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) kl[j][i] = 0.f;
+  for (int j = 0; j < 7; ++j)
 #pragma unroll
     for (int q = 0; q < TPW; ++q)
 #pragma unroll
       for (int i = 0; i < 4; ++i) k[j][q][i] = 0.f;
+  {
+    const float z4[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                       // previous users of the row-state block / bZ writers are done
+#pragma unroll
+    for (int fld = 0; fld < 14; ++fld) T.rs_put(fld, z4);
   }
   __syncthreads();
   if (T.hutch) T.precompute_tz1();      // reads bZ only
@@ -364,8 +375,11 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
     float cf[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) cf[j] = DP_TAB[phase][j];
+    {
+      const f32x4 t4 = T.rs_get(RS_T), h4 = T.rs_get(phase == 1 ? RS_H0 : RS_DT);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { hs[i] = phase == 1 ? h0[i] : dt[i]; ts[i] = t[i] + hs[i] * cf[6]; }
+      for (int i = 0; i < 4; ++i) { hs[i] = h4[i]; ts[i] = t4[i] + hs[i] * cf[6]; }
+    }
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
       const int col = (wave + NW * q) * 16 + c;
@@ -394,12 +408,11 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
     for (int j = 0; j < 7; ++j)
       if (j == dst) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) kl[j][i] = dlv[i];
-#pragma unroll
         for (int q = 0; q < TPW; ++q)
 #pragma unroll
           for (int i = 0; i < 4; ++i) k[j][q][i] = kv[q][i];
       }
+    T.rs_put(RS_KL + dst, dlv);            // read again only after later barriers (phases 1 and 7)
 
     if (phase == 0) {
       // ---- initial step size, part 1 (Hairer II.4, order 4) ----
@@ -415,12 +428,15 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
           }
         }
       T.row_reduce(p0, 2); T.row_reduce(p1, 3);
+      float h0[4], d1[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float a1 = kl[0][i] / atol;                              // ell0 = 0 -> scale = atol
+        const float a1 = dlv[i] / atol;                                // ell0 = 0 -> scale = atol
         const float d0 = sqrtf(p0[i]); d1[i] = sqrtf(p1[i] + a1 * a1);
         h0[i] = (d0 < 1e-5f || d1[i] < 1e-5f) ? 1e-6f : 0.01f * d0 / d1[i];
       }
+      T.rs_put(RS_H0, h0); T.rs_put(RS_D1, d1);
+      __syncthreads();
       phase = 1;
     } else if (phase == 1) {
       float p2[4] = {0, 0, 0, 0};
@@ -435,26 +451,31 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
           }
         }
       T.row_reduce(p2, 2);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float a2 = (kl[1][i] - kl[0][i]) / atol;
-        const float d2 = sqrtf(p2[i] + a2 * a2) / h0[i];
-        const float h1 = (d1[i] <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0[i] * 1e-3f)
-                                                           : powf(0.01f / fmaxf(d1[i], d2), 0.2f);
-        dt[i] = fminf(100.f * h0[i], h1);
-      }
-      phase = 2;
+      const f32x4 h04 = T.rs_get(RS_H0), d14 = T.rs_get(RS_D1), kl0 = T.rs_get(RS_KL + 0);
+      float dt[4];
       bool any = false;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) any |= (dt[i] > 0.f);
+      for (int i = 0; i < 4; ++i) {
+        const float a2 = (dlv[i] - kl0[i]) / atol;
+        const float d2 = sqrtf(p2[i] + a2 * a2) / h04[i];
+        const float h1 = (d14[i] <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h04[i] * 1e-3f)
+                                                            : powf(0.01f / fmaxf(d14[i], d2), 0.2f);
+        dt[i] = fminf(100.f * h04[i], h1);
+        any |= (dt[i] > 0.f);
+      }
+      T.rs_put(RS_DT, dt);
+      phase = 2;
       if (!__syncthreads_or(any ? 1 : 0)) break;
     } else if (phase < 7) {
       phase += 1;
     } else {
       // ---- end of an attempted step: xin holds y1 (row 7 of the table = 5th-order weights) ----
-      bool active[4];
+      const f32x4 t4 = T.rs_get(RS_T), ell4 = T.rs_get(RS_ELL);
+      const f32x4 na4 = T.rs_get(RS_NATT), dn4 = T.rs_get(RS_DONE);
+      f32x4 kl[7];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) active[i] = !done[i] && natt[i] < max_attempts && dt[i] > 0.f;
+      for (int j = 0; j < 6; ++j) kl[j] = T.rs_get(RS_KL + j);
+      kl[6] = f32x4{dlv[0], dlv[1], dlv[2], dlv[3]};
       float e2[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int q = 0; q < TPW; ++q)
@@ -464,7 +485,7 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
             float er = 0.f;
 #pragma unroll
             for (int j = 0; j < 7; ++j) er += DP_E[j] * k[j][q][i];
-            er *= dt[i];
+            er *= hs[i];
             const float tol = atol + rtol * fmaxf(fabsf(y[q][i]), fabsf(xin[q][i]));
             const float rr = er / tol;
             e2[i] += rr * rr;
@@ -472,62 +493,75 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
         }
       T.row_reduce(e2, 2);
       bool any = false;
+      float t_n[4], dt_n[4], ell_n[4], kl0_n[4], na_n[4], dn_n[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        const float dti = hs[i];
+        const bool was_done = dn4[i] != 0.f;
+        const bool active = !was_done && na4[i] < (float)max_attempts && dti > 0.f;
         float sl = 0.f, el = 0.f;
 #pragma unroll
         for (int j = 0; j < 6; ++j) sl += DP_TAB[7][j] * kl[j][i];
 #pragma unroll
         for (int j = 0; j < 7; ++j) el += DP_E[j] * kl[j][i];
-        const float l1 = ell[i] + dt[i] * sl;
-        el *= dt[i];
-        const float tol = atol + rtol * fmaxf(fabsf(ell[i]), fabsf(l1));
+        const float l1 = ell4[i] + dti * sl;
+        el *= dti;
+        const float tol = atol + rtol * fmaxf(fabsf(ell4[i]), fabsf(l1));
         const float rr = el / tol;
         const float ratio = sqrtf((e2[i] + rr * rr) * inv_n);
-        const bool acc = active[i] && ratio <= 1.f;
+        const bool acc = active && ratio <= 1.f;
         const float dfac = ratio < 1.f ? 1.f : 0.2f;
         const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
-        const float ndt = fmaxf(ratio == 0.f ? dt[i] * 10.f : dt[i] * fac, 0.f);
+        const float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+        t_n[i] = t4[i]; ell_n[i] = ell4[i]; kl0_n[i] = kl[0][i]; dn_n[i] = dn4[i];
         if (acc) {
-          const float tn = t[i] + dt[i];
+          const float tn = t4[i] + dti;
           if (tn >= 1.f) {
             // final output: 4th-order interpolant of this step evaluated at t = 1
-            const float sfrac = (1.f - t[i]) / (tn - t[i]);
+            const float sfrac = (1.f - t4[i]) / (tn - t4[i]);
             float lm = 0.f;
 #pragma unroll
             for (int j = 0; j < 7; ++j) lm += DP_M[j] * kl[j][i];
-            const float y0 = ell[i], y1 = l1, ym = y0 + dt[i] * lm, f0 = dt[i] * kl[0][i], f1 = dt[i] * kl[6][i];
+            const float y0 = ell4[i], y1 = l1, ym = y0 + dti * lm, f0 = dti * kl[0][i], f1 = dti * kl[6][i];
             const float pa = -2.f * f0 + 2.f * f1 - 8.f * y0 - 8.f * y1 + 16.f * ym;
             const float pb = 5.f * f0 - 3.f * f1 + 18.f * y0 + 14.f * y1 - 32.f * ym;
             const float pc = -4.f * f0 + f1 - 11.f * y0 - 5.f * y1 + 16.f * ym;
-            ell[i] = (((pa * sfrac + pb) * sfrac + pc) * sfrac + f0) * sfrac + y0;
+            ell_n[i] = (((pa * sfrac + pb) * sfrac + pc) * sfrac + f0) * sfrac + y0;
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
               float km = 0.f;
 #pragma unroll
               for (int j = 0; j < 7; ++j) km += DP_M[j] * k[j][q][i];
-              const float x0 = y[q][i], x1 = xin[q][i], xm = x0 + dt[i] * km, g0 = dt[i] * k[0][q][i], g1 = dt[i] * k[6][q][i];
+              const float x0 = y[q][i], x1 = xin[q][i], xm = x0 + dti * km, g0 = dti * k[0][q][i], g1 = dti * k[6][q][i];
               const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
               const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
               const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
               y[q][i] = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
             }
-            done[i] = true;
+            dn_n[i] = 1.f;
           } else {
-            ell[i] = l1;
+            ell_n[i] = l1;
 #pragma unroll
             for (int q = 0; q < TPW; ++q) { y[q][i] = xin[q][i]; k[0][q][i] = k[6][q][i]; }
-            kl[0][i] = kl[6][i];
+            kl0_n[i] = kl[6][i];
           }
-          t[i] = tn;
+          t_n[i] = tn;
         }
-        if (active[i]) { dt[i] = ndt; natt[i] += 1; }
-        any |= (!done[i] && natt[i] < max_attempts && dt[i] > 0.f);
+        dt_n[i] = active ? ndt : dti;
+        na_n[i] = active ? na4[i] + 1.f : na4[i];
+        any |= (dn_n[i] == 0.f && na_n[i] < (float)max_attempts && dt_n[i] > 0.f);
       }
+      T.rs_put(RS_T, t_n); T.rs_put(RS_DT, dt_n); T.rs_put(RS_ELL, ell_n); T.rs_put(RS_KL + 0, kl0_n);
+      T.rs_put(RS_NATT, na_n); T.rs_put(RS_DONE, dn_n);
       // the loop condition must be uniform over the workgroup: every lane only sees its own 4 rows
       if (!__syncthreads_or(any ? 1 : 0)) break;
       phase = 2;
     }
+  }
+  {
+    const f32x4 ell4 = T.rs_get(RS_ELL), na4 = T.rs_get(RS_NATT);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ell[i] = ell4[i]; natt[i] = (int)na4[i]; }
   }
 }
 
@@ -660,8 +694,8 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
   // sub-keys of :265 / :247 are re-derived where they are used: key_gen 0, key_acc 1, key_hutch1 2, key_hutch2 3
   float y[TPW][4], ell[4], vol0[4] = {0, 0, 0, 0}, lq_ref[4] = {0, 0, 0, 0};
   int natt[4], natt_tot[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int ph = 0; ph < 2; ++ph) {       // fully unrolled: two inlined copies of the solver (ONE call site of the solver: inverse solve, then forward solve of the proposal
+#pragma unroll 1
+  for (int ph = 0; ph < 2; ++ph) {       // (ONE call site of the solver: inverse solve, then forward solve of the proposal
     Key2 kz[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) kz[i] = split_at(kb[i], 4, ph == 0 ? 3 : 2);
@@ -809,7 +843,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
 // ODE_NW: waves per workgroup of the solver kernels.  4 = one wave per SIMD with a 512-register budget (the seven
 // Runge-Kutta stages stay in registers without spilling); 8 = two per SIMD with 256 registers each.
 #ifndef ODE_NW
-#define ODE_NW 4
+#define ODE_NW 8
 #endif
 static int ode_check(const NetDev& n, size_t& sm, int& tpw) {
   const OdeLds L = ode_lds_layout(n, ODE_NW);
