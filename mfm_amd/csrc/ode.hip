@@ -77,13 +77,21 @@ __device__ static const float DP_M[7] = {(float)(6025192743.0 / 30085553152.0 / 
                                          (float)(-2691868925.0 / 45128329728.0 / 2), (float)(187940372067.0 / 1594534317056.0 / 2),
                                          (float)(-1776094331.0 / 19743644256.0 / 2), (float)(11237099.0 / 235043384.0 / 2)};
 
+#ifdef MFM_STAMPS
+#define MFM_STAMP(id) do { if (stamps && lane == 0) stamps[(blockIdx.x * NW + wave) * 16 + (id)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MFM_STAMP(id) do {} while (0)
+#endif
+
 template <int TPW, int NW>
 struct OdeTile {
+  unsigned long long* stamps = nullptr;
   const NetDev* n;
   OdeLds L;
   float* lds;
   int lane, wave, g, c;
-  bool hutch;
+  bool hutch;               // tangent rows are pushed through the MLP (always on in the solver kernels)
+  bool exact;               // exact trace: d basis probes per RHS evaluation instead of one Hutchinson probe
   int sign;                 // +1 forward (:208-218), -1 inverse (:225-239)
   float tz1[2][4];          // z W_x1 for this lane's x1-layer tiles (<= 2 tiles per wave)
   float gate[TPW][4];       // nn_t of the last evaluated stage time (kept for stages that share it)
@@ -143,6 +151,7 @@ struct OdeTile {
                                        float (*jzo)[4] = nullptr, bool reuse_time = false) {
     const NetDev& N = *n;
     const int d = N.d;
+    MFM_STAMP(0);
     // Fourier features (:70-71); skipped when this stage shares its time with the previous one (st and the gate
     // output are still valid: Dopri5 stages 6 and 7 are both at t + dt)
     if (!reuse_time) {
@@ -194,7 +203,9 @@ struct OdeTile {
         o[8 + j] = (hutch && inside) ? hv[j] : 0.f;
       }
     }
+    MFM_STAMP(2);
     __syncthreads();
+    MFM_STAMP(3);
     // t1 ; x1 (value rows; tangent rows = relu' * (z W_x1))
     if (!reuse_time)
     layer_gemm<1, NW>(bFF(), L.ldff, N.Wp + N.L[0].w_off, N.bias + N.L[0].b_off, N.L[0].Kp / 16, N.L[0].Np / 16, wave, lane,
@@ -213,7 +224,9 @@ struct OdeTile {
                          bX1()[16 * L.ldx1 + o] = pre > 0.f ? tz : 0.f;
                        }
                      });
+    MFM_STAMP(4);
     __syncthreads();
+    MFM_STAMP(5);
     // t2 -> st (value rows only) ; x2 on value + tangent rows
     if (!reuse_time)
     layer_gemm<1, NW>(bT1(), L.ldt1, N.Wp + N.L[1].w_off, N.bias + N.L[1].b_off, N.L[1].Kp / 16, N.L[1].Np / 16, wave, lane,
@@ -233,7 +246,9 @@ struct OdeTile {
                          }
                        });
     }
+    MFM_STAMP(6);
     __syncthreads();
+    MFM_STAMP(7);
     // gate (registers) ; j1
     if (!reuse_time)
     layer_gemm<1, NW>(bCat() + N.hx2, L.ldcat, N.Wp + N.L[4].w_off, N.bias + N.L[4].b_off, N.L[4].Kp / 16, N.L[4].Np / 16, wave, lane,
@@ -257,7 +272,9 @@ struct OdeTile {
                          }
                        });
     }
+    MFM_STAMP(8);
     __syncthreads();
+    MFM_STAMP(9);
     {
       f32x4 keep = {0, 0, 0, 0};
       layer_gemm<2, NW>(bJ1(), L.ldj1, N.Wp + N.L[6].w_off, N.bias + N.L[6].b_off, N.L[6].Kp / 16, N.L[6].Np / 16, wave, lane,
@@ -270,7 +287,9 @@ struct OdeTile {
                          }
                        });
     }
+    MFM_STAMP(10);
     __syncthreads();
+    MFM_STAMP(11);
     // out: v = nn_xt + nn_t * clip(grad log pi(x)) (:88-90);  J z = d nn_xt . z + nn_t * 1[|g| <= clip] * (H z)
     float dpart[4] = {0.f, 0.f, 0.f, 0.f};
     {
@@ -315,7 +334,9 @@ struct OdeTile {
                          }
                        });
     }
+    MFM_STAMP(12);
     row_reduce(dpart, red_slot);
+    MFM_STAMP(13);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dl[i] = sign > 0 ? -dpart[i] : dpart[i];     // :218 / :239
   }
@@ -365,7 +386,7 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
     for (int fld = 0; fld < 14; ++fld) T.rs_put(fld, z4);
   }
   __syncthreads();
-  if (T.hutch) T.precompute_tz1();      // reads bZ only
+  if (!T.exact) T.precompute_tz1();     // Hutchinson probe: z W_x1 once per solve (reads bZ only)
 
   int phase = 0;
 #pragma unroll 1
@@ -401,7 +422,24 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
     for (int q = 0; q < TPW; ++q)
 #pragma unroll
       for (int i = 0; i < 4; ++i) kv[q][i] = 0.f;      // waves that own no output tile never write kv
-    T.eval(ts, kv, dlv, phase & 1, nullptr, phase == 7);
+    // Hutchinson: one probe z (drawn once per solve).  Exact trace (:216-217 / :236-237): trace J = sum_j e_j . J e_j,
+    // one tangent pass per basis vector; passes after the first reuse the time branch of the first.
+    const int nprobe = T.exact ? d : 1;
+#pragma unroll 1
+    for (int pj = 0; pj < nprobe; ++pj) {
+      if (T.exact) {
+        for (int idx = threadIdx.x; idx < 16 * N.dp; idx += NW * 64) {
+          const int row = idx / N.dp, col = idx - row * N.dp;
+          T.bZ()[row * T.L.ldx + 4 + col] = col == pj ? 1.f : 0.f;
+        }
+        __syncthreads();
+        T.precompute_tz1();
+      }
+      float dl1[4];
+      T.eval(ts, kv, dl1, (phase + pj) & 1, nullptr, phase == 7 || pj > 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dlv[i] += dl1[i];
+    }
     // ---- route the result: phase 0 -> k[0], phase 1 -> k[1], phase p >= 2 -> k[p - 1] ----
     const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
 #pragma unroll
@@ -584,7 +622,7 @@ template <int TPW, int NW>
 __device__ __forceinline__ void tile_init(OdeTile<TPW, NW>& T, const NetDev* n, float* lds, bool hutch) {
   T.n = n; T.L = ode_lds_layout(*n, NW); T.lds = lds;
   T.lane = threadIdx.x & 63; T.wave = threadIdx.x >> 6; T.g = T.lane >> 4; T.c = T.lane & 15;
-  T.hutch = hutch; T.sign = 1;
+  T.hutch = hutch; T.exact = false; T.sign = 1;
   for (int i = threadIdx.x; i < T.L.total; i += (NW * 64)) lds[i] = 0.f;     // pads, tangent rows of st, scratch
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -599,7 +637,8 @@ template <int TPW, int NW>
 __global__ __launch_bounds__(NW * 64) void ode_transform_kernel(OdeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   OdeTile<TPW, NW> T;
-  tile_init(T, &a.net, lds, a.hutch != 0);
+  tile_init(T, &a.net, lds, true);
+  T.exact = a.hutch == 0;
   T.sign = a.direction;
   const int b0 = blockIdx.x * 16, d = a.net.d;
   Key2 kz[4];
@@ -608,7 +647,7 @@ __global__ __launch_bounds__(NW * 64) void ode_transform_kernel(OdeArgs a) {
     const int b = b0 + 4 * T.g + i;
     kz[i] = a.per_chain_keys ? Key2{a.keys[2 * b], a.keys[2 * b + 1]} : a.key;
   }
-  fill_probe(T, kz, T.hutch);
+  fill_probe(T, kz, !T.exact);
   float y[TPW][4], ell[4]; int natt[4];
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
@@ -679,12 +718,52 @@ __global__ __launch_bounds__(NW * 64) void vf_apply_kernel(NetDev net, const flo
   }
 }
 
+#ifdef MFM_STAMPS
+template <int TPW, int NW>
+__global__ __launch_bounds__(NW * 64) void eval_stamps_kernel(NetDev net, const float* x, const float* t, const float* tan, int reps,
+                                                              unsigned long long* stamps) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  OdeTile<TPW, NW> T;
+  tile_init(T, &net, lds, true);
+  const int b0 = blockIdx.x * 16, d = net.d;
+  float tt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tt[i] = t[b0 + 4 * T.g + i];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int col = (T.wave + NW * q) * 16 + T.c;
+    if (col < d) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t o = (size_t)(b0 + 4 * T.g + i) * d + col;
+        T.bX()[(4 * T.g + i) * T.L.ldx + 4 + col] = x[o];
+        T.bZ()[(4 * T.g + i) * T.L.ldx + 4 + col] = tan[o];
+      }
+    }
+  }
+  __syncthreads();
+  T.precompute_tz1();
+  float kv[TPW][4], dl[4];
+#pragma unroll 1
+  for (int r = 0; r < reps; ++r) {
+    if (r == reps - 1) T.stamps = stamps;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tt[i] += 1e-3f;
+    __syncthreads();
+    T.eval(tt, kv, dl, r & 1);
+  }
+  if (T.lane == 0) stamps[(blockIdx.x * NW + T.wave) * 16 + 15] = (unsigned long long)(kv[0][0] + dl[0]);   // keep results live
+}
+int launch_eval_stamps(const NetDev& n, const float* x, const float* t, const float* tan, int cnt, int reps, unsigned long long* stamps, hipStream_t stream);
+#endif
+
 // One flow-based MH step per chain (random-walk in latent space :264-278, or independent :246-260).
 template <int TPW, int NW>
 __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   OdeTile<TPW, NW> T;
-  tile_init(T, &a.net, lds, a.hutch != 0);
+  tile_init(T, &a.net, lds, true);
+  T.exact = a.hutch == 0;
   const NetDev& N = a.net;
   const int b0 = blockIdx.x * 16, d = N.d, g = T.g, c = T.c, wave = T.wave;
   Key2 kb[4];
@@ -731,7 +810,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
       }
       __syncthreads();
     }
-    fill_probe(T, kz, T.hutch);
+    fill_probe(T, kz, !T.exact);
     T.sign = ph == 0 ? -1 : 1;
     ode_solve<TPW, NW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
 #pragma unroll
@@ -868,7 +947,6 @@ static int ode_check(const NetDev& n, size_t& sm, int& tpw) {
 int launch_ode_transform(const OdeArgs& a, hipStream_t stream) {
   size_t sm; int tpw;
   if (ode_check(a.net, sm, tpw)) return -3;
-  if (!a.hutch) return -2;   // exact trace: not built yet
   ODE_LAUNCH(ode_transform_kernel, dim3(a.n / 16), a);
   return 0;
 }
@@ -881,7 +959,15 @@ int launch_vf_apply(const NetDev& n, const float* x, const float* t, const float
 int launch_flow_step(const OdeArgs& a, const FlowArgs& f, hipStream_t stream) {
   size_t sm; int tpw;
   if (ode_check(a.net, sm, tpw)) return -3;
-  if (!a.hutch) return -2;
   ODE_LAUNCH(flow_step_kernel, dim3(a.n / 16), a, f);
   return 0;
 }
+
+#ifdef MFM_STAMPS
+int launch_eval_stamps(const NetDev& n, const float* x, const float* t, const float* tan, int cnt, int reps, unsigned long long* stamps, hipStream_t stream) {
+  size_t sm; int tpw;
+  if (ode_check(n, sm, tpw)) return -3;
+  ODE_LAUNCH(eval_stamps_kernel, dim3(cnt / 16), n, x, t, tan, reps, stamps);
+  return 0;
+}
+#endif

@@ -11,10 +11,10 @@ def _args(**kw):
     return loop.default_args(**kw)
 
 
-def _run_both(example, d, B, iters, K, **kw):
+def _run_both(example, d, B, iters, K, hutch=True, **kw):
     from mfm_amd import distributions as D, exe_flow_matching as E
     from oracle import loop, targets
-    common = dict(example=example, dim=d, num_chain=B, learning_iter=iters, mcmc_per_flow_steps=float(K), hutchs=True,
+    common = dict(example=example, dim=d, num_chain=B, learning_iter=iters, mcmc_per_flow_steps=float(K), hutchs=hutch,
                   fourier_dim=16, hidden_x=[32, 32], hidden_t=[32, 32], hidden_xt=[32, 32], seed=1024, eval_iter=1, **kw)
     if example == "phi-four":
         dg, do = D.PhiFour(d), targets.PhiFour(d)
@@ -55,8 +55,10 @@ def test_phi4_loop_matches_oracle():
     ex["engine"].close()
 
 
-def test_four_mode_loop_matches_oracle():
-    out, res, ex = _run_both("4-mode", 2, 64, 8, 3, step_size=0.2)
+@pytest.mark.parametrize("hutch", [True, False])
+def test_four_mode_loop_matches_oracle(hutch):
+    """BASELINE configs[0] in miniature; hutch=False is the reference's default (exact trace)."""
+    out, res, ex = _run_both("4-mode", 2, 64, 8, 3, hutch=hutch, step_size=0.2)
     tr, m = out["trace"], ex["metrics"]
     np.testing.assert_allclose(m[:, 0], tr["loss"], rtol=5e-3)
     np.testing.assert_allclose(m[:, 3], tr["target_loss"], rtol=1e-3)          # eval_step on the exact samples

@@ -106,3 +106,51 @@ def test_flow_rwmh_step_matches_oracle(d, hidden, F):
     dn = np.abs(ns.cpu().numpy() - tot)
     assert (dn == 0).mean() >= 0.5 and abs(ns.float().mean().item() - tot.mean()) < 0.1 * tot.mean()
     ctx.close()
+
+
+def test_exact_trace_transform_matches_oracle_on_mixture():
+    """No --hutch (the default of the two mixture examples): trace(jacfwd(v)) by d basis probes per RHS evaluation."""
+    import torch
+    from tests import gpu_util as gu
+    B, d = 32, 2
+    args, dist, k, model, state = gu.gmm4_setup(B=B, hutchs=False)
+    params = gu.rand_params(model, seed=9, out_scale=0.3)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+    x32 = dist.init_params.astype(np.float32)
+    for direction, fn in ((1, ode.transform_and_logdet), (-1, ode.inverse_and_logdet)):
+        st = {}
+        y_o, l_o = fn(model, params, None, x32.astype(np.float64), False, args.rtol, args.atol, args.mxstep, stats=st)
+        out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
+        ctx.ode_transform(direction, _dev(x32), out, ldj, key=prng.PRNGKey(0), nsteps=ns)
+        assert np.abs(out.cpu().numpy() - y_o).max() < 2e-3 * max(1.0, np.abs(y_o).max())
+        assert np.abs(ldj.cpu().numpy() - l_o).max() < 1e-2 * max(1.0, np.abs(l_o).max())
+        assert abs(ns.float().mean().item() - st["n_attempted"].mean()) < 0.1 * st["n_attempted"].mean()
+    ctx.close()
+
+
+def test_flow_imh_step_matches_oracle():
+    """Independent MH in latent space (num_importance_samples < 0, exe_flow_matching.py:246-260)."""
+    import torch
+    from mfm_amd import _lib
+    d, B = 64, 32
+    args, dist, model, params, ctx = _setup(d, B, 32, 16, out_scale=0.05)
+    beta = 1.0
+    vg = targets.Tempered(dist, beta).value_and_grad
+    x32 = dist.init_params.astype(np.float32)
+    pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+    ctx.mala_init(pos, beta, logp, grad)
+    st = mala.MALAState(x32.astype(np.float64), logp.cpu().numpy(), grad.cpu().numpy().astype(np.float64))
+    key = prng.PRNGKey(77)
+    new, info = flow.imh_step(prng.split(key, B), st, vg, model, params, args)
+    acc = torch.empty(B, device="cuda"); isacc = torch.empty(B, dtype=torch.uint8, device="cuda"); prop = torch.empty(B, d, device="cuda")
+    ctx.flow_step(_lib.FLOW_IMH, key, beta, pos, logp, grad, acc, isacc, prop, None)
+    p = prop.cpu().numpy()
+    assert np.abs(p - info.proposed_position).max() < 5e-3 and np.abs(p - info.proposed_position).mean() < 2e-4
+    with np.errstate(divide="ignore"):
+        la_g, la_o = np.log(acc.cpu().numpy().astype(np.float64)), np.log(info.acceptance_rate)
+    fin = np.isfinite(la_g) & np.isfinite(la_o)
+    if fin.any():
+        assert np.abs(la_g[fin] - la_o[fin]).max() < 0.5
+    sure = ~fin | (np.abs(la_o) > 1)
+    np.testing.assert_array_equal(isacc.cpu().numpy().astype(bool)[sure], info.is_accepted[sure])
+    ctx.close()
