@@ -405,6 +405,7 @@ extern "C" int mfm_ode_transform(mfm_ctx* x, int direction, int per_chain, const
   if (!d_in || !d_out || !d_ldj || (per_chain && !d_keys)) return fail(MFM_EINVAL, "null device pointer");
   if (direction != 1 && direction != -1) return fail(MFM_EINVAL, "direction must be +1 or -1");
   if (n <= 0 || n % 16) return fail(MFM_EUNSUPPORTED, "n must be a positive multiple of 16");
+  if ((size_t)n > x->ode.rows) return fail(MFM_ETOOLARGE, "n=%d exceeds max_eval_samples given at mfm_create", n);
   OdeArgs a = ode_args(x->net, x->cfg, x->ode);
   a.direction = direction; a.per_chain_keys = per_chain; a.keys = d_keys; a.key = Key2{k0, k1};
   a.in = d_in; a.out = d_out; a.ldj = d_ldj; a.nsteps = d_nsteps; a.n = n;

@@ -65,7 +65,10 @@ __host__ __device__ __forceinline__ int pack_index_T(int k, int n, int NB) {
 // layer bias of that column (0 when `bias` is null).
 // 8 waves per workgroup = 2 per SIMD: while one wave sits in an epilogue / barrier / load wait the other keeps the
 // SIMD's matrix pipe busy; a wave's own chain of dependent MFMAs (40-cycle latency vs 32-cycle issue) is hidden too.
-template <int MT, int NW, typename Epi>
+// PIPE selects the weight-streaming schedule: 2 = ping-pong register sets, counted waits, no copies (fastest when the
+// kernel has registers to spare: the flow-matching kernels); 1 = single look-ahead set (smaller live range: the solver
+// kernels, which keep seven Runge-Kutta stages in registers).
+template <int MT, int NW, int PIPE = 2, typename Epi>
 __device__ __forceinline__ void layer_gemm(const float* A, int lda, const float* __restrict__ Wp_,
                                            const float* __restrict__ bias, int KB, int NT, int wave, int lane, Epi epi) {
   const int r = lane & 15, g = lane >> 4;
@@ -77,6 +80,54 @@ __device__ __forceinline__ void layer_gemm(const float* A, int lda, const float*
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PIPE == 2) {
+    // Software pipeline over groups of 4 k-blocks with two PING-PONG register sets (no register copies at the loop
+    // back-edge: a copy of a load destination would wait for that load).  The next group's B fragments are issued
+    // before the current group's MFMAs, so the compiler's counted wait (vmcnt(4)) only covers loads issued a whole
+    // group earlier.
+    auto group = [&](const f32x4 (&bf)[4], int kb0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * lda + (kb0 + u) * 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], bf[u][s], acc[m], 0, 0, 0);
+      }
+    };
+    const int KG = KB >> 2;                 // full groups
+    f32x4 ba[4], bb[4];
+    if (KG > 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ba[u] = wp[(size_t)u * 64];
+    }
+    int gi = 0;
+    for (; gi + 1 < KG; gi += 2) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bb[u] = wp[(size_t)(4 * gi + 4 + u) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      group(ba, 4 * gi);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gi + 2 < KG) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ba[u] = wp[(size_t)(4 * gi + 8 + u) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      group(bb, 4 * gi + 4);
+    }
+    if (gi < KG) group(ba, 4 * gi);
+    for (int kb = 4 * KG; kb < KB; ++kb) {          // tail (KB not a multiple of 4: tiny layers only)
+      const f32x4 bf = wp[(size_t)kb * 64];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + m * 16 * lda + kb * 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bf[s], acc[m], 0, 0, 0);
+      }
+    }
+    } else {
     // Software pipeline at 4-k-block granularity with two register sets: the next group's B fragments are issued
     // right AFTER the first use of the current group, so the wait the compiler places before that use (it emits
     // vmcnt(0) across the loop back-edge) only ever covers loads issued a whole group (>= 12 MT MFMAs) earlier.
@@ -109,6 +160,7 @@ __device__ __forceinline__ void layer_gemm(const float* A, int lda, const float*
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) cur[v] = nxt[v];
+    }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) epi(q, nt, m, acc[m], bv);

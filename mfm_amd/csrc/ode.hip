@@ -20,9 +20,15 @@
 #include "mlp.cuh"
 #include "prng.cuh"
 
-struct OdeWs { int unused; };
-static int ode_ws_alloc(const NetDev&, const mfm_config&, OdeWs&) { return 0; }
-static void ode_ws_free(OdeWs&) {}
+// Gaussian draws the solver kernels consume (Hutchinson probes of both solves, latent random-walk noise) are
+// produced by a small separate kernel into this workspace: the float64 erfinv code would otherwise sit inside the
+// persistent solver kernel and cost it ~200 spilled registers.
+struct OdeWs { float* noise; size_t rows; };
+static int ode_ws_alloc(const NetDev& n, const mfm_config& c, OdeWs& w) {
+  w.rows = (size_t)(c.max_eval_samples > c.n_chain_local ? c.max_eval_samples : c.n_chain_local);
+  return hipMalloc((void**)&w.noise, 3 * w.rows * n.d * sizeof(float)) == hipSuccess ? 0 : -4;
+}
+static void ode_ws_free(OdeWs& w) { if (w.noise) (void)hipFree(w.noise); w.noise = nullptr; }
 
 struct OdeArgs {
   NetDev net;
@@ -33,6 +39,9 @@ struct OdeArgs {
   const uint32_t* keys; Key2 key;
   const float* in; float* out; float* ldj; int* nsteps;
   int n;
+  const float* z1;          // probe of the (first / only) solve, [n][d]
+  const float* z2;          // probe of the second solve (flow step)
+  const float* zgen;        // latent proposal noise (flow step)
 };
 
 struct FlowArgs {
@@ -42,8 +51,9 @@ struct FlowArgs {
   float* acc_prob; uint8_t* accepted; float* proposed; int* nsteps;
 };
 
-static OdeArgs ode_args(const NetDev& n, const mfm_config& c, const OdeWs&) {
+static OdeArgs ode_args(const NetDev& n, const mfm_config& c, const OdeWs& w) {
   OdeArgs a; memset(&a, 0, sizeof a);
+  a.z1 = w.noise; a.z2 = w.noise + w.rows * n.d; a.zgen = w.noise + 2 * w.rows * n.d;
   a.net = n; a.hutch = c.hutch; a.rtol = (float)c.rtol; a.atol = (float)c.atol;
   a.max_attempts = c.mxstep * (c.n_ts > 1 ? c.n_ts - 1 : 1);
   return a;
@@ -137,7 +147,7 @@ struct OdeTile {
   // z W_x1 (no bias), once per solve.  Requires bZ filled and a barrier before.
   __device__ __forceinline__ void precompute_tz1() {
     const LayerDesc& l2 = n->L[2];
-    layer_gemm<1, NW>(bZ() + 4, L.ldx, n->Wp + l2.w_off, nullptr, l2.Kp / 16, l2.Np / 16, wave, lane,
+    layer_gemm<1, NW, 1>(bZ() + 4, L.ldx, n->Wp + l2.w_off, nullptr, l2.Kp / 16, l2.Np / 16, wave, lane,
                      [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                        for (int i = 0; i < 4; ++i) { if (q == 0) tz1[0][i] = acc[i]; else tz1[1][i] = acc[i]; }
@@ -208,12 +218,12 @@ struct OdeTile {
     MFM_STAMP(3);
     // t1 ; x1 (value rows; tangent rows = relu' * (z W_x1))
     if (!reuse_time)
-    layer_gemm<1, NW>(bFF(), L.ldff, N.Wp + N.L[0].w_off, N.bias + N.L[0].b_off, N.L[0].Kp / 16, N.L[0].Np / 16, wave, lane,
+    layer_gemm<1, NW, 1>(bFF(), L.ldff, N.Wp + N.L[0].w_off, N.bias + N.L[0].b_off, N.L[0].Kp / 16, N.L[0].Np / 16, wave, lane,
                      [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                        for (int i = 0; i < 4; ++i) bT1()[(4 * g + i) * L.ldt1 + nt * 16 + c] = fmaxf(acc[i] + b, 0.f);
                      });
-    layer_gemm<1, NW>(bX() + 4, L.ldx, N.Wp + N.L[2].w_off, N.bias + N.L[2].b_off, N.L[2].Kp / 16, N.L[2].Np / 16, wave, lane,
+    layer_gemm<1, NW, 1>(bX() + 4, L.ldx, N.Wp + N.L[2].w_off, N.bias + N.L[2].b_off, N.L[2].Kp / 16, N.L[2].Np / 16, wave, lane,
                      [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                        for (int i = 0; i < 4; ++i) {
@@ -229,14 +239,14 @@ struct OdeTile {
     MFM_STAMP(5);
     // t2 -> st (value rows only) ; x2 on value + tangent rows
     if (!reuse_time)
-    layer_gemm<1, NW>(bT1(), L.ldt1, N.Wp + N.L[1].w_off, N.bias + N.L[1].b_off, N.L[1].Kp / 16, N.L[1].Np / 16, wave, lane,
+    layer_gemm<1, NW, 1>(bT1(), L.ldt1, N.Wp + N.L[1].w_off, N.bias + N.L[1].b_off, N.L[1].Kp / 16, N.L[1].Np / 16, wave, lane,
                      [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                        for (int i = 0; i < 4; ++i) bCat()[(4 * g + i) * L.ldcat + N.hx2 + nt * 16 + c] = fmaxf(acc[i] + b, 0.f);
                      });
     {
       f32x4 keep = {0, 0, 0, 0};   // value pre-activation of the same tile, handed from m = 0 to m = 1
-      layer_gemm<2, NW>(bX1(), L.ldx1, N.Wp + N.L[3].w_off, N.bias + N.L[3].b_off, N.L[3].Kp / 16, N.L[3].Np / 16, wave, lane,
+      layer_gemm<2, NW, 1>(bX1(), L.ldx1, N.Wp + N.L[3].w_off, N.bias + N.L[3].b_off, N.L[3].Kp / 16, N.L[3].Np / 16, wave, lane,
                        [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                          for (int i = 0; i < 4; ++i) {
@@ -251,7 +261,7 @@ struct OdeTile {
     MFM_STAMP(7);
     // gate (registers) ; j1
     if (!reuse_time)
-    layer_gemm<1, NW>(bCat() + N.hx2, L.ldcat, N.Wp + N.L[4].w_off, N.bias + N.L[4].b_off, N.L[4].Kp / 16, N.L[4].Np / 16, wave, lane,
+    layer_gemm<1, NW, 1>(bCat() + N.hx2, L.ldcat, N.Wp + N.L[4].w_off, N.bias + N.L[4].b_off, N.L[4].Kp / 16, N.L[4].Np / 16, wave, lane,
                      [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                        for (int qq = 0; qq < TPW; ++qq)
@@ -262,7 +272,7 @@ struct OdeTile {
                      });
     {
       f32x4 keep = {0, 0, 0, 0};
-      layer_gemm<2, NW>(bCat(), L.ldcat, N.Wp + N.L[5].w_off, N.bias + N.L[5].b_off, N.L[5].Kp / 16, N.L[5].Np / 16, wave, lane,
+      layer_gemm<2, NW, 1>(bCat(), L.ldcat, N.Wp + N.L[5].w_off, N.bias + N.L[5].b_off, N.L[5].Kp / 16, N.L[5].Np / 16, wave, lane,
                        [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                          for (int i = 0; i < 4; ++i) {
@@ -277,7 +287,7 @@ struct OdeTile {
     MFM_STAMP(9);
     {
       f32x4 keep = {0, 0, 0, 0};
-      layer_gemm<2, NW>(bJ1(), L.ldj1, N.Wp + N.L[6].w_off, N.bias + N.L[6].b_off, N.L[6].Kp / 16, N.L[6].Np / 16, wave, lane,
+      layer_gemm<2, NW, 1>(bJ1(), L.ldj1, N.Wp + N.L[6].w_off, N.bias + N.L[6].b_off, N.L[6].Kp / 16, N.L[6].Np / 16, wave, lane,
                        [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
                          for (int i = 0; i < 4; ++i) {
@@ -294,7 +304,7 @@ struct OdeTile {
     float dpart[4] = {0.f, 0.f, 0.f, 0.f};
     {
       f32x4 hzk = {0, 0, 0, 0};      // masked Hessian-vector product of the tile, handed from m = 0 to m = 1
-      layer_gemm<2, NW>(bJ2(), L.ldj2, N.Wp + N.L[7].w_off, N.bias + N.L[7].b_off, N.L[7].Kp / 16, N.L[7].Np / 16, wave, lane,
+      layer_gemm<2, NW, 1>(bJ2(), L.ldj2, N.Wp + N.L[7].w_off, N.bias + N.L[7].b_off, N.L[7].Kp / 16, N.L[7].Np / 16, wave, lane,
                        [&](int q, int nt, int m, f32x4 acc, float b) {
                          const int col = nt * 16 + c;
 #pragma unroll
@@ -603,9 +613,25 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
   }
 }
 
-// fill bZ with the Hutchinson probe of each row (normal(key, (d,)), :212 / :232) or zero it
+// Gaussian draws for the solver kernels.  mode 0: per-sample keys (uint32[n][2]); 1: ONE shared key (:455);
+// 2: flow step -- chain b uses split(split(key, n_total)[chain_offset + b], 4)[sub] (:265 / :247).
+__global__ __launch_bounds__(256) void probe_kernel(int mode, const uint32_t* keys, Key2 key, uint32_t n_total, uint32_t chain_offset,
+                                                   int sub, int n, int d, float* out) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= n) return;
+  Key2 k = key;
+  if (mode == 0) k = Key2{keys[2 * b], keys[2 * b + 1]};
+  else if (mode == 2) k = split_at(split_at(key, n_total, chain_offset + (uint32_t)b), 4, (uint32_t)sub);
+  for (int j = lane; j < d; j += 64) out[(size_t)b * d + j] = (float)normal64(k, (uint32_t)j, (uint32_t)d);   // :212 / :232 / :268
+}
+static void launch_probe(int mode, const uint32_t* keys, Key2 key, uint32_t n_total, uint32_t chain_offset, int sub, int n, int d,
+                         float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(probe_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, mode, keys, key, n_total, chain_offset, sub, n, d, out);
+}
+
+// fill bZ with the Hutchinson probe of each row (normal(key, (d,)), :212 / :232), drawn by probe_kernel, or zero it
 template <int TPW, int NW>
-__device__ __forceinline__ void fill_probe(OdeTile<TPW, NW>& T, const Key2 (&kz)[4], bool hutch) {
+__device__ __forceinline__ void fill_probe(OdeTile<TPW, NW>& T, const float* z, int b0, bool hutch) {
   const NetDev& N = *T.n;
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
@@ -613,7 +639,7 @@ __device__ __forceinline__ void fill_probe(OdeTile<TPW, NW>& T, const Key2 (&kz)
     if (col < N.dp) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        T.bZ()[(4 * T.g + i) * T.L.ldx + 4 + col] = (hutch && col < N.d) ? (float)normal64(kz[i], (uint32_t)col, (uint32_t)N.d) : 0.f;
+        T.bZ()[(4 * T.g + i) * T.L.ldx + 4 + col] = (hutch && col < N.d) ? z[(size_t)(b0 + 4 * T.g + i) * N.d + col] : 0.f;
     }
   }
 }
@@ -641,13 +667,7 @@ __global__ __launch_bounds__(NW * 64) void ode_transform_kernel(OdeArgs a) {
   T.exact = a.hutch == 0;
   T.sign = a.direction;
   const int b0 = blockIdx.x * 16, d = a.net.d;
-  Key2 kz[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int b = b0 + 4 * T.g + i;
-    kz[i] = a.per_chain_keys ? Key2{a.keys[2 * b], a.keys[2 * b + 1]} : a.key;
-  }
-  fill_probe(T, kz, !T.exact);
+  fill_probe(T, a.z1, b0, !T.exact);
   float y[TPW][4], ell[4]; int natt[4];
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
@@ -775,9 +795,6 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
   int natt[4], natt_tot[4] = {0, 0, 0, 0};
 #pragma unroll 1
   for (int ph = 0; ph < 2; ++ph) {       // (ONE call site of the solver: inverse solve, then forward solve of the proposal
-    Key2 kz[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) kz[i] = split_at(kb[i], 4, ph == 0 ? 3 : 2);
     if (ph == 0) {
       // ---- inverse solve from the current position (:267 / :251) ----
 #pragma unroll
@@ -796,7 +813,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
         if (col < d) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float nz = (float)normal64(split_at(kb[i], 4, 0), (uint32_t)col, (uint32_t)d);
+            const float nz = a.zgen[(size_t)(b0 + 4 * g + i) * d + col];
             if (f.mode == MFM_FLOW_RWMH) y[q][i] = y[q][i] + scale * nz;                            // :268
             else { r0[i] += y[q][i] * y[q][i]; y[q][i] = nz; r1[i] += nz * nz; }                    // :249
           }
@@ -810,7 +827,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
       }
       __syncthreads();
     }
-    fill_probe(T, kz, !T.exact);
+    fill_probe(T, ph == 0 ? a.z1 : a.z2, b0, !T.exact);       // key_hutch2 for the inverse, key_hutch1 for the forward solve
     T.sign = ph == 0 ? -1 : 1;
     ode_solve<TPW, NW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
 #pragma unroll
@@ -947,6 +964,7 @@ static int ode_check(const NetDev& n, size_t& sm, int& tpw) {
 int launch_ode_transform(const OdeArgs& a, hipStream_t stream) {
   size_t sm; int tpw;
   if (ode_check(a.net, sm, tpw)) return -3;
+  if (a.hutch) launch_probe(a.per_chain_keys ? 0 : 1, a.keys, a.key, 0, 0, 0, a.n, a.net.d, const_cast<float*>(a.z1), stream);
   ODE_LAUNCH(ode_transform_kernel, dim3(a.n / 16), a);
   return 0;
 }
@@ -959,6 +977,11 @@ int launch_vf_apply(const NetDev& n, const float* x, const float* t, const float
 int launch_flow_step(const OdeArgs& a, const FlowArgs& f, hipStream_t stream) {
   size_t sm; int tpw;
   if (ode_check(a.net, sm, tpw)) return -3;
+  launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 0, a.n, a.net.d, const_cast<float*>(a.zgen), stream);     // key_gen
+  if (a.hutch) {
+    launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 3, a.n, a.net.d, const_cast<float*>(a.z1), stream);     // key_hutch2
+    launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 2, a.n, a.net.d, const_cast<float*>(a.z2), stream);     // key_hutch1
+  }
   ODE_LAUNCH(flow_step_kernel, dim3(a.n / 16), a, f);
   return 0;
 }

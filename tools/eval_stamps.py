@@ -3,6 +3,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MFM_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mfm_amd/lib/libmfm_hip_stamps.so")
 import numpy as np, torch
+np.set_printoptions(suppress=True, linewidth=250)
 from tests import gpu_util as gu
 from mfm_amd import _lib
 B, d = 4096, 256
@@ -25,6 +26,8 @@ for reps in (20,):
     print("median cycles since eval start, per wave (rows) / stamp (cols):")
     print("stamps:", [n for i, n in enumerate(names) if i != 1])
     for w in range(NW):
-        print("wave", w, np.array2string(np.delete(med[w], 1), precision=0, max_line_width=200))
+        print("wave", w, np.delete(med[w], 1).astype(int))
     tot = np.median(rel[:, :, 13].max(1))
+    dur = np.diff(np.delete(med, 1, axis=1), axis=1).astype(int)
+    print("phase durations wave0:", dur[0], "\nphase durations wave4:", dur[4])
     print("median eval cycles (last wave):", tot, " ideal MFMA cycles/SIMD: 38912")
