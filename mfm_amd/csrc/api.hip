@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "mala.hip"
+#include "lgcp.hip"
 #include "fm.hip"
 #include "optim.hip"
 #include "ode.hip"
@@ -45,7 +46,7 @@ struct mfm_ctx {
   double* loss_part; int loss_cap;
   WgradJob* jobs; int n_jobs, split;
   OptState* opt; int* flag;
-  float *gmm_mode, *gmm_std, *gmm_logw, *counts, *Kinv;
+  float *gmm_mode, *gmm_std, *gmm_logw, *counts, *Kinv, *kbias;
   OdeWs ode;
   double* beta_out;
 };
@@ -195,7 +196,7 @@ extern "C" int mfm_destroy(mfm_ctx* x) {
   if (!x) return MFM_OK;
   hipDeviceSynchronize();
   void* ps[] = {x->master, x->mu, x->nu, x->Wp, x->WpT, x->bias, x->fourier, x->acts, x->dzs, x->slabs, x->loss_part,
-                x->jobs, x->opt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->beta_out};
+                x->jobs, x->opt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->beta_out};
   for (void* p : ps) if (p) hipFree(p);
   ode_ws_free(x->ode);
   if (x->prof) { for (auto& e : x->prof->ev) (void)hipEventDestroy(e); delete x->prof; }
@@ -234,7 +235,34 @@ extern "C" int mfm_set_target(mfm_ctx* x, int kind, const double* p, size_t np) 
     HIPCHK(hipMemcpy(x->gmm_logw, lw.data(), K * 4, hipMemcpyHostToDevice));
     T.n_modes = K; T.gmm_mode = x->gmm_mode; T.gmm_std = x->gmm_std; T.gmm_logw = x->gmm_logw;
   } else if (kind == MFM_LGCP) {
-    return fail(MFM_EUNSUPPORTED, "LGCP target: not built yet (SURVEY.md section 8a row T3)");
+    // {mu, poisson_a, log_norm, counts[d], Kinv[d*d]} (distributions.py:249-274; Kinv = inverse of the Gram matrix :265)
+    if (np != (size_t)(3 + d + (size_t)d * d)) return fail(MFM_EINVAL, "bad LGCP parameter block");
+    const int dp = x->net.dp, KB = dp / 16;
+    std::vector<float> cnt(dp, 0.f), kb(dp, 0.f), kp((size_t)dp * dp, 0.f);
+    const double mu = p[0];
+    const double* Kinv = p + 3 + d;
+    for (int j = 0; j < d; ++j) cnt[j] = (float)p[3 + j];
+    for (int k = 0; k < d; ++k)
+      for (int j = 0; j < d; ++j) kp[pack_index(k, j, KB)] = (float)Kinv[(size_t)k * d + j];
+    for (int j = 0; j < d; ++j) {
+      double rs = 0.0;
+      for (int k = 0; k < d; ++k) rs += Kinv[(size_t)k * d + j];
+      kb[j] = (float)(-mu * rs);
+    }
+    for (float** q : {&x->counts, &x->Kinv, &x->kbias}) if (*q) { hipFree(*q); *q = nullptr; }
+    ALLOC(x->counts, dp); ALLOC(x->kbias, dp); ALLOC(x->Kinv, (size_t)dp * dp);
+    HIPCHK(hipMemcpy(x->counts, cnt.data(), dp * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(x->kbias, kb.data(), dp * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(x->Kinv, kp.data(), (size_t)dp * dp * 4, hipMemcpyHostToDevice));
+    T.counts = x->counts; T.KinvP = x->Kinv; T.kbias = x->kbias;
+    T.mu = (float)mu; T.poisson_a = (float)p[1]; T.log_norm = (float)p[2];
+    // the K^-1 tile buffers must fit next to the MLP tiles
+    const FmLds Lf = fm_lds_layout(x->net, true);
+    const OdeLds Lo = ode_lds_layout(x->net, ODE_NW);
+    if ((size_t)Lf.total * 4 > 160 * 1024 || (size_t)Lo.total * 4 > 160 * 1024) {
+      memset(&T, 0, sizeof T);
+      return fail(MFM_ETOOLARGE, "LGCP target with dim %d does not fit the 16-chain LDS tile next to this network", d);
+    }
   } else {
     return fail(MFM_EINVAL, "unknown target kind %d", kind);
   }
@@ -282,6 +310,14 @@ static MalaArgs mala_args(mfm_ctx* x, double beta) {
 extern "C" int mfm_mala_init(mfm_ctx* x, const float* d_pos, double beta, double* d_logp, float* d_grad) {
   NEED_TARGET();
   if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
+  if (x->net.T.kind == MFM_TARGET_LGCP) {
+    LgcpArgs l; memset(&l, 0, sizeof l);
+    l.T = x->net.T; l.dp = x->net.dp; l.mode = 0; l.n_total = x->cfg.n_chain_total; l.chain_offset = x->cfg.chain_offset;
+    l.B = x->cfg.n_chain_local; l.beta = beta; l.eps = 1.0; l.pos = const_cast<float*>(d_pos); l.logp = d_logp; l.grad = d_grad;
+    if (launch_mala_lgcp(l, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large for the LGCP MALA kernel", x->cfg.dim);
+    LAUNCHCHK();
+    return MFM_OK;
+  }
   MalaArgs a = mala_args(x, beta);
   a.pos = const_cast<float*>(d_pos); a.logp = d_logp; a.grad = d_grad;
   if (launch_mala_init(a, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large for the MALA kernel", x->cfg.dim);
@@ -294,6 +330,16 @@ extern "C" int mfm_mala_step(mfm_ctx* x, uint32_t k0, uint32_t k1, double beta, 
   NEED_TARGET();
   if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
   if (!(step > 0)) return fail(MFM_EINVAL, "step_size must be positive");
+  if (x->net.T.kind == MFM_TARGET_LGCP) {
+    LgcpArgs l; memset(&l, 0, sizeof l);
+    l.T = x->net.T; l.dp = x->net.dp; l.mode = 1; l.key = Key2{k0, k1}; l.n_total = x->cfg.n_chain_total;
+    l.chain_offset = x->cfg.chain_offset; l.B = x->cfg.n_chain_local; l.beta = beta; l.eps = step; l.textbook = textbook;
+    l.pos = d_pos; l.logp = d_logp; l.grad = d_grad; l.acc_prob = d_acc; l.accepted = d_isacc; l.proposed = d_prop; l.prop_weight = d_pw;
+    ProfScope ps_(x, PROF_MALA);
+    if (launch_mala_lgcp(l, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large for the LGCP MALA kernel", x->cfg.dim);
+    LAUNCHCHK();
+    return MFM_OK;
+  }
   MalaArgs a = mala_args(x, beta);
   a.key = Key2{k0, k1}; a.eps = step; a.textbook = textbook;
   a.pos = d_pos; a.logp = d_logp; a.grad = d_grad;

@@ -29,7 +29,7 @@ struct FmArgs {
 
 struct FmLds {           // float offsets into dynamic LDS
   int ff, ldff, x, ldx, t1, ldt1, cat, ldcat, x1, ldx1, j1, ldj1, j2, ldj2, g, ldg;
-  int dv, lddv, d1, ldd1, d2, ldd2, dcat, gcs, red, total;
+  int dv, lddv, d1, ldd1, d2, ldd2, dcat, gcs, red, gc, total;
 };
 
 __host__ __device__ inline FmLds fm_lds_layout(const NetDev& n, bool train) {
@@ -54,6 +54,7 @@ __host__ __device__ inline FmLds fm_lds_layout(const NetDev& n, bool train) {
   }
   L.gcs = take(16, 8);
   L.red = take(1, 32);
+  L.gc = n.T.kind == MFM_TARGET_LGCP ? take(16, L.ldg) : 0;      // grad log pi of the tile (needs the K^-1 GEMM)
   L.total = o;
   return L;
 }
@@ -63,9 +64,11 @@ __device__ __forceinline__ void store_packed(float* base, int tile_row, int nbb,
 }
 
 // grad log pi(x)[row][col], clipped, for the tile whose positions sit in LDS `xrow0` (row stride ldx, data at +4)
-__device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf, int ldx, const float* gcs, int row, int col) {
+__device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf, int ldx, const float* gcs, const float* gcl, int ldg,
+                                              int row, int col) {
   float gv;
   if (n.T.kind == MFM_TARGET_PHI4) gv = phi4_grad(n.T, xbuf + row * ldx + 4, col);
+  else if (n.T.kind == MFM_TARGET_LGCP) gv = gcl[row * ldg + col];
   else gv = gcs[row * 8 + col];
   return clipf(gv, n.grad_clip);
 }
@@ -82,7 +85,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   float* bFF = lds + L.ff;  float* bX = lds + L.x;   float* bT1 = lds + L.t1; float* bCat = lds + L.cat;
   float* bX1 = lds + L.x1;  float* bJ1 = lds + L.j1; float* bJ2 = lds + L.j2; float* bG = lds + L.g;
   float* bDV = lds + L.dv;  float* bD1 = lds + L.d1; float* bD2 = lds + L.d2; float* bDC = lds + L.dcat;
-  float* gcs = lds + L.gcs; double* red = reinterpret_cast<double*>(lds + L.red);
+  float* gcs = lds + L.gcs; double* red = reinterpret_cast<double*>(lds + L.red); float* bGC = lds + L.gc;
 
   // ---------------- prologue: K3 batch construction (exe_flow_matching.py:151-169 / :139-147) ----------------
   for (int i = threadIdx.x; i < 16 * L.ldx; i += (MLP_WAVES_FM * 64)) bX[i] = 0.f;      // pads (incl. x[-1], x[d..])
@@ -189,6 +192,17 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
       if (TRAIN) store_packed(a.acts, a_tile + nt, nbb, bb, lane, v);
     };
   };
+  if (n.T.kind == MFM_TARGET_LGCP)      // grad log pi(cond) = c - a exp(cond) - K^-1 (cond - mu)
+    layer_gemm<1, MLP_WAVES_FM>(bX + 4, L.ldx, n.T.KinvP, n.T.kbias, n.dp / 16, n.dp / 16, wave, lane,
+                                [&](int q, int nt, int m, f32x4 acc, float kb) {
+                                  const int col = nt * 16 + c;
+#pragma unroll
+                                  for (int i = 0; i < 4; ++i) {
+                                    const int row = 4 * g + i;
+                                    const float xv = bX[row * L.ldx + 4 + col];
+                                    bGC[row * L.ldg + col] = col < d ? n.T.counts[col] - n.T.poisson_a * expf(xv) - (acc[i] + kb) : 0.f;
+                                  }
+                                });
   layer_gemm<1, MLP_WAVES_FM>(bFF, L.ldff, n.Wp + n.L[0].w_off, n.bias + n.L[0].b_off, n.L[0].Kp / 16, n.L[0].Np / 16, wave, lane,
                    relu_store(n.L[0], bT1, L.ldt1, 0, a.ws.a_t1));
   layer_gemm<1, MLP_WAVES_FM>(bX + 4, L.ldx, n.Wp + n.L[2].w_off, n.bias + n.L[2].b_off, n.L[2].Kp / 16, n.L[2].Np / 16, wave, lane,
@@ -220,7 +234,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                      for (int i = 0; i < 4; ++i) {
                        const int row = 4 * g + i;
                        if (col < d) {
-                         const float gc = target_gclip(n, bX, L.ldx, gcs, row, col);
+                         const float gc = target_gclip(n, bX, L.ldx, gcs, bGC, L.ldg, row, col);
                          const float v = acc[i] + bias + bG[row * L.ldg + col] * gc;
                          // tgt is indexed by the static slot q: select without dynamic register indexing
                          float tg = 0.f;

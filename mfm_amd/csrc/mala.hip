@@ -44,6 +44,13 @@ __device__ __forceinline__ double row_value_grad(const TargetDev& T, double beta
       }
     }
     return beta * wave_sum(acc);
+  } else if (T.kind == MFM_TARGET_LGCP) {   // likelihood part only (loglik_kernel); value/grad with the prior: lgcp.hip
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      int j = lane + 64 * it;
+      if (j < d) { acc += (double)xs[j] * (double)T.counts[j] - (double)T.poisson_a * (double)expf(xs[j]); gout[it] = 0.f; }
+    }
+    return beta * wave_sum(acc);
   } else {  // GMM: lane 0 evaluates the row, gradient broadcast through LDS scratch
     double lp = 0.0;
     if (lane == 0) {

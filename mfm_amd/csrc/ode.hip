@@ -60,7 +60,7 @@ static OdeArgs ode_args(const NetDev& n, const mfm_config& c, const OdeWs& w) {
 }
 
 struct OdeLds {   // float offsets
-  int ff_j1, ldff, ldj1, x, ldx, z, cat, ldcat, x1, ldx1, j2_t1, ldj2, ldt1, red, gcs, rs, total;
+  int ff_j1, ldff, ldj1, x, ldx, z, cat, ldcat, x1, ldx1, j2_t1, ldj2, ldt1, red, gcs, rs, gc, hz, kz, ldgc, total;
 };
 __host__ __device__ inline OdeLds ode_lds_layout(const NetDev& n, int NW) {
   OdeLds L; int o = 0;
@@ -74,7 +74,9 @@ __host__ __device__ inline OdeLds ode_lds_layout(const NetDev& n, int NW) {
   { int a = 32 * L.ldj2, b = 16 * L.ldt1; L.j2_t1 = take(a > b ? a : b); }
   L.red = take(8 * 16 * NW);      // 8 reduction slots of [NW][16 rows]
   L.gcs = take(16 * 24);     // small-d targets: grad[8], hvp[8], inside-mask[8] per row
-  L.rs = take(16 * 16);      // per-row solver state (t, dt, h0, d1, ell, kl[7], natt, done): 16 arrays of 16 rows
+  L.rs = take(16 * 16);
+  L.ldgc = n.dp + 4; L.gc = L.hz = L.kz = 0;
+  if (n.T.kind == MFM_TARGET_LGCP) { L.gc = take(16 * L.ldgc); L.hz = take(16 * L.ldgc); L.kz = take(16 * L.ldgc); }   // grad, masked H z, K^-1 z      // per-row solver state (t, dt, h0, d1, ell, kl[7], natt, done): 16 arrays of 16 rows
   L.total = o;
   return L;
 }
@@ -144,8 +146,15 @@ struct OdeTile {
     }
   }
 
-  // z W_x1 (no bias), once per solve.  Requires bZ filled and a barrier before.
+  // z W_x1 (no bias), once per solve.  Requires bZ filled and a barrier before.  LGCP: also K^-1 z (the dense part of
+  // the Hessian-vector product), read back by the SAME lanes in eval.
   __device__ __forceinline__ void precompute_tz1() {
+    if (n->T.kind == MFM_TARGET_LGCP)
+      layer_gemm<1, NW, 1>(bZ() + 4, L.ldx, n->T.KinvP, nullptr, n->dp / 16, n->dp / 16, wave, lane,
+                           [&](int q, int nt, int m, f32x4 acc, float b) {
+#pragma unroll
+                             for (int i = 0; i < 4; ++i) lds[L.kz + (4 * g + i) * L.ldgc + nt * 16 + c] = acc[i];
+                           });
     const LayerDesc& l2 = n->L[2];
     layer_gemm<1, NW, 1>(bZ() + 4, L.ldx, n->Wp + l2.w_off, nullptr, l2.Kp / 16, l2.Np / 16, wave, lane,
                      [&](int q, int nt, int m, f32x4 acc, float b) {
@@ -213,6 +222,25 @@ struct OdeTile {
         o[8 + j] = (hutch && inside) ? hv[j] : 0.f;
       }
     }
+    if (N.T.kind == MFM_TARGET_LGCP)      // grad log pi(x) = c - a exp(x) - K^-1 (x - mu);  H z = -a exp(x) z - K^-1 z
+      layer_gemm<1, NW, 1>(bX() + 4, L.ldx, N.T.KinvP, N.T.kbias, N.dp / 16, N.dp / 16, wave, lane,
+                           [&](int q, int nt, int m, f32x4 acc, float kb) {
+                             const int col = nt * 16 + c;
+#pragma unroll
+                             for (int i = 0; i < 4; ++i) {
+                               const int row = 4 * g + i;
+                               float gcv = 0.f, hzv = 0.f;
+                               if (col < d) {
+                                 const float ex = N.T.poisson_a * expf(bX()[row * L.ldx + 4 + col]);
+                                 const float graw = N.T.counts[col] - ex - (acc[i] + kb);
+                                 gcv = clipf(graw, N.grad_clip);
+                                 const bool inside = !(N.grad_clip > 0.f) || fabsf(graw) <= N.grad_clip;
+                                 if (hutch && inside) hzv = -ex * bZ()[row * L.ldx + 4 + col] - lds[L.kz + row * L.ldgc + col];
+                               }
+                               lds[L.gc + row * L.ldgc + col] = gcv;
+                               lds[L.hz + row * L.ldgc + col] = hzv;
+                             }
+                           });
     MFM_STAMP(2);
     __syncthreads();
     MFM_STAMP(3);
@@ -322,6 +350,9 @@ struct OdeTile {
                                  gc = clipf(graw, N.grad_clip);
                                  const bool inside = !(N.grad_clip > 0.f) || fabsf(graw) <= N.grad_clip;
                                  if (hutch && inside) hz = phi4_hvp(N.T, xr, bZ() + row * L.ldx + 4, col);
+                               } else if (N.T.kind == MFM_TARGET_LGCP) {
+                                 gc = lds[L.gc + row * L.ldgc + col];
+                                 hz = lds[L.hz + row * L.ldgc + col];
                                } else {
                                  gc = gcs()[row * 24 + col];
                                  hz = gcs()[row * 24 + 8 + col];
@@ -880,6 +911,42 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
       for (int w = 0; w < NW; ++w) t += rd[w * 16 + row];
       lpn[i] = f.beta * t;
     }
+  } else if (N.T.kind == MFM_TARGET_LGCP) {
+    double lik[4] = {0, 0, 0, 0}, quad[4] = {0, 0, 0, 0};
+    layer_gemm<1, NW, 1>(T.bX() + 4, T.L.ldx, N.T.KinvP, N.T.kbias, N.dp / 16, N.dp / 16, wave, T.lane,
+                         [&](int q, int nt, int m, f32x4 acc, float kb) {
+                           const int col = nt * 16 + c;
+#pragma unroll
+                           for (int i = 0; i < 4; ++i) {
+                             float gv = 0.f;
+                             if (col < d) {
+                               const float xv = T.bX()[(4 * g + i) * T.L.ldx + 4 + col], yv = acc[i] + kb, ex = expf(xv);
+                               gv = (float)f.beta * (N.T.counts[col] - N.T.poisson_a * ex) - yv;
+                               lik[i] += (double)xv * (double)N.T.counts[col] - (double)N.T.poisson_a * (double)ex;
+                               quad[i] += (double)(xv - N.T.mu) * (double)yv;
+                             }
+#pragma unroll
+                             for (int qq = 0; qq < TPW; ++qq)
+                               if (qq == q) gnew[qq][i] = gv;
+                           }
+                         });
+    double* rd = reinterpret_cast<double*>(T.red(0));      // slots 0..1: lik, 2..3: quad, as [NW][16] doubles
+    double* rq = reinterpret_cast<double*>(T.red(2));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { lik[i] += __shfl_xor(lik[i], o, 64); quad[i] += __shfl_xor(quad[i], o, 64); }
+      if (c == 0) { rd[wave * 16 + 4 * g + i] = lik[i]; rq[wave * 16 + 4 * g + i] = quad[i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * g + i;
+      double sl = 0.0, sq = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { sl += rd[w * 16 + row]; sq += rq[w * 16 + row]; }
+      lpn[i] = f.beta * sl - 0.5 * sq + (double)N.T.log_norm;
+    }
   } else {
     double* rd = reinterpret_cast<double*>(T.red(0));
     if (threadIdx.x < 16) {
@@ -911,6 +978,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
     acc[i] = u <= ap;                     // NaN compares false -> reject
     aprob[i] = (float)ap;
   }
+  __syncthreads();      // every wave has read the OLD log-densities before wave 0 publishes the accepted ones
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     const int col = (wave + NW * q) * 16 + c;

@@ -23,9 +23,10 @@ struct TargetDev {
   const float* gmm_mode;   // [K, d]
   const float* gmm_std;    // [K, d]
   const float* gmm_logw;   // [K]  log w_k - sum_j log s_kj - d/2 log 2pi
-  // lgcp
-  const float* counts;     // [d]
-  const float* Kinv;       // [d, d] (symmetric)
+  // lgcp (unwhitened): loglik = sum(x c - a e^x), logprior = -1/2 (x-mu)^T K^-1 (x-mu) + log_norm
+  const float* counts;     // [dp] (zero padded)
+  const float* KinvP;      // K^-1 packed like an MLP layer (K = N = d; symmetric, so one packing serves both uses)
+  const float* kbias;      // [dp]: -mu * rowsum(K^-1), so that x . K^-1 + kbias = K^-1 (x - mu)
   float mu, poisson_a, log_norm;
 };
 

@@ -300,15 +300,19 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
 
 
 def _logprob_any(eng, x):
-    """vmap(dist.logprob) for any sample count (pads to the engine's chain count; targets built so far have no prior)."""
+    """vmap(dist.logprob) for any sample count: the MALA init kernel at beta = 1 returns loglik + logprior for every
+    built target; samples are processed in chunks of the engine's chain count (zero padded)."""
     t = eng.torch
     out = t.empty(x.shape[0], device=eng.dev, dtype=t.float64)
     n = eng.n_local
+    lp = t.empty(n, device=eng.dev, dtype=t.float64)
+    gr = t.empty(n, x.shape[1], device=eng.dev, dtype=t.float32)
     for s in range(0, x.shape[0], n):
         chunk = x[s:s + n]
-        if chunk.shape[0] < n:
-            pad = t.zeros(n, x.shape[1], device=eng.dev, dtype=x.dtype); pad[:chunk.shape[0]] = chunk
-            out[s:s + chunk.shape[0]] = eng.loglik(pad)[:chunk.shape[0]]
-        else:
-            out[s:s + n] = eng.loglik(chunk.contiguous())
+        m = chunk.shape[0]
+        if m < n:
+            pad = t.zeros(n, x.shape[1], device=eng.dev, dtype=x.dtype); pad[:m] = chunk
+            chunk = pad
+        eng.ctx.mala_init(chunk.contiguous(), 1.0, lp, gr)
+        out[s:s + m] = lp[:m]
     return out

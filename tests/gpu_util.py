@@ -37,6 +37,8 @@ def target_block(dist):
     if dist.kind == "gmm":
         K = len(dist.weights)
         return _lib.GMM, np.concatenate([[K], dist.modes.reshape(-1), dist.chol_covs.reshape(-1), dist.weights])
+    if dist.kind == "lgcp":
+        return _lib.LGCP, np.concatenate([[dist.mu, dist.poisson_a, dist.log_norm], dist.counts, dist.Kinv.reshape(-1)])
     raise NotImplementedError(dist.kind)
 
 
@@ -73,5 +75,16 @@ def gmm4_setup(B=64, seed=1, hidden=32, F=16, **kw):
     args = loop.default_args(example="4-mode", dim=2, num_chain=B, step_size=0.2, seed=seed, fourier_dim=F,
                              hidden_x=[hidden, hidden], hidden_t=[hidden, hidden], hidden_xt=[hidden, hidden], **kw)
     dist = targets.GaussianMixture(8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4)
+    k, model, state, lr_fn, _, _ = loop.setup(dist, args)
+    return args, dist, k, model, state
+
+
+def lgcp_setup(n=8, B=32, seed=1, hidden=32, F=16, hutch=True, **kw):
+    import os
+    d = n * n
+    counts = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mfm_amd", "data", "pines_counts.npz"))[f"counts_{n}"]
+    args = loop.default_args(example="pines", dim=d, num_chain=B, hutchs=hutch, step_size=0.01, seed=seed, fourier_dim=F,
+                             hidden_x=[hidden, hidden], hidden_t=[hidden, hidden], hidden_xt=[hidden, hidden], **kw)
+    dist = targets.LogGaussianCoxPines(d, counts)
     k, model, state, lr_fn, _, _ = loop.setup(dist, args)
     return args, dist, k, model, state

@@ -17,12 +17,14 @@ def _relerr(a, b):
 
 
 @pytest.mark.parametrize("setup,d,B,hidden,F", [("phi4", 256, 64, 128, 128), ("phi4", 64, 32, 32, 16), ("phi4", 40, 16, 48, 10),
-                                               ("gmm", 2, 64, 32, 16)])
+                                               ("gmm", 2, 64, 32, 16), ("lgcp", 64, 32, 32, 16)])
 def test_fm_loss_and_grad_match_oracle(setup, d, B, hidden, F):
     import torch
     from tests import gpu_util as gu
     if setup == "phi4":
         args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=hidden, F=F)
+    elif setup == "lgcp":
+        args, dist, k, model, state = gu.lgcp_setup(n=int(np.sqrt(d)), B=B, hidden=hidden, F=F)
     else:
         args, dist, k, model, state = gu.gmm4_setup(B=B, hidden=hidden, F=F)
     params = gu.rand_params(model, seed=3)
@@ -106,13 +108,15 @@ def test_adamw_chain_matches_oracle():
     ctx.close()
 
 
-@pytest.mark.parametrize("setup,d,hidden,F", [("phi4", 256, 128, 128), ("phi4", 40, 32, 10), ("gmm", 2, 32, 16)])
+@pytest.mark.parametrize("setup,d,hidden,F", [("phi4", 256, 128, 128), ("phi4", 40, 32, 10), ("gmm", 2, 32, 16), ("lgcp", 64, 32, 16)])
 def test_vector_field_and_jvp_match_oracle(setup, d, hidden, F):
     import torch
     from tests import gpu_util as gu
     B = 32
     if setup == "phi4":
         args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=hidden, F=F)
+    elif setup == "lgcp":
+        args, dist, k, model, state = gu.lgcp_setup(n=int(np.sqrt(d)), B=B, hidden=hidden, F=F)
     else:
         args, dist, k, model, state = gu.gmm4_setup(B=B, hidden=hidden, F=F)
     params = gu.rand_params(model, seed=6)

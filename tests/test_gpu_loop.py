@@ -19,6 +19,10 @@ def _run_both(example, d, B, iters, K, hutch=True, **kw):
     if example == "phi-four":
         dg, do = D.PhiFour(d), targets.PhiFour(d)
         tg = to = None
+    elif example == "pines":
+        dg = D.LogGaussianCoxPines(d)
+        do = targets.LogGaussianCoxPines(d, dg.counts)
+        tg = to = None
     else:
         modes, covs, w = 8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4
         dg, do = D.GaussianMixture(modes, covs, w), targets.GaussianMixture(modes, covs, w)
@@ -63,4 +67,20 @@ def test_four_mode_loop_matches_oracle(hutch):
     np.testing.assert_allclose(m[:, 0], tr["loss"], rtol=5e-3)
     np.testing.assert_allclose(m[:, 3], tr["target_loss"], rtol=1e-3)          # eval_step on the exact samples
     np.testing.assert_allclose(ex["betas"], tr["beta"], rtol=1e-3)
+    ex["engine"].close()
+
+
+def test_pines_loop_matches_oracle():
+    """Log-Gaussian Cox process on a 16 x 16 grid (dim > 128, so the +-1 clip of grad log pi is active as in the
+    reference's 40 x 40 example, whose hidden width of 1024 does not fit the 16-chain LDS tile): annealing with a prior
+    term, MALA through the K^-1 kernel, flow steps."""
+    out, res, ex = _run_both("pines", 256, 32, 9, 3, step_size=0.01)
+    tr, m = out["trace"], ex["metrics"]
+    np.testing.assert_allclose(m[:3, 0], tr["loss"][:3], rtol=1e-5)
+    np.testing.assert_allclose(m[:, 0], tr["loss"], rtol=5e-3)
+    np.testing.assert_allclose(ex["betas"], tr["beta"], rtol=2e-3)
+    g = ex["states"].position.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(g.mean(0), out["states"].position.mean(0), atol=2e-2)
+    np.testing.assert_allclose(ex["states"].logdensity.cpu().numpy().mean(), out["states"].logdensity.mean(), rtol=2e-3)
+    assert np.isfinite(res[0])
     ex["engine"].close()

@@ -12,7 +12,7 @@ def _dev(x, dtype=None):
     return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda()
 
 
-@pytest.mark.parametrize("setup,d", [("phi4", 256), ("phi4", 64), ("phi4", 40), ("gmm", 2)])
+@pytest.mark.parametrize("setup,d", [("phi4", 256), ("phi4", 64), ("phi4", 40), ("gmm", 2), ("lgcp", 64), ("lgcp", 256)])
 def test_mala_init_and_step_match_oracle(setup, d):
     import torch
     from tests import gpu_util as gu
@@ -20,6 +20,9 @@ def test_mala_init_and_step_match_oracle(setup, d):
     if setup == "phi4":
         args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=32, F=16)
         eps, beta = 1e-4, 0.37
+    elif setup == "lgcp":
+        args, dist, k, model, state = gu.lgcp_setup(n=int(np.sqrt(d)), B=B)
+        eps, beta = 0.01, 0.45
     else:
         args, dist, k, model, state = gu.gmm4_setup(B=B)
         eps, beta = 0.2, 0.6

@@ -154,3 +154,47 @@ def test_flow_imh_step_matches_oracle():
     sure = ~fin | (np.abs(la_o) > 1)
     np.testing.assert_array_equal(isacc.cpu().numpy().astype(bool)[sure], info.is_accepted[sure])
     ctx.close()
+
+
+def test_lgcp_transform_and_flow_step_match_oracle():
+    """Log-Gaussian Cox target (8 x 8 grid): grad log pi and its Hessian-vector product need the K^-1 contraction
+    inside every RHS evaluation and in the MH target evaluation."""
+    import torch
+    from mfm_amd import _lib
+    from tests import gpu_util as gu
+    B, d = 32, 64
+    args, dist, k, model, state = gu.lgcp_setup(n=8, B=B)
+    params = gu.rand_params(model, seed=9, out_scale=0.3)
+    params[4]["kernel"] *= 0.05; params[4]["bias"] *= 0.05
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+    x32 = dist.init_params.astype(np.float32)
+    keys = prng.split(prng.PRNGKey(21), B)
+    for direction, fn in ((1, ode.transform_and_logdet), (-1, ode.inverse_and_logdet)):
+        st = {}
+        y_o, l_o = fn(model, params, keys, x32.astype(np.float64), True, args.rtol, args.atol, args.mxstep, stats=st)
+        out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
+        ctx.ode_transform(direction, _dev(x32), out, ldj, keys=_dev(keys.astype(np.uint32).view(np.int32)), nsteps=ns)
+        assert np.abs(out.cpu().numpy() - y_o).max() < 2e-3 * max(1.0, np.abs(y_o).max())
+        assert np.abs(ldj.cpu().numpy() - l_o).max() < 5e-2 * max(1.0, np.abs(l_o).max())
+        assert abs(ns.float().mean().item() - st["n_attempted"].mean()) < 0.1 * st["n_attempted"].mean()
+    beta = 0.7
+    vg = targets.Tempered(dist, beta).value_and_grad
+    pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+    ctx.mala_init(pos, beta, logp, grad)
+    st = mala.MALAState(x32.astype(np.float64), logp.cpu().numpy(), grad.cpu().numpy().astype(np.float64))
+    key = prng.PRNGKey(31)
+    new, info = flow.rwmh_step(prng.split(key, B), st, vg, model, params, args)
+    acc = torch.empty(B, device="cuda"); isacc = torch.empty(B, dtype=torch.uint8, device="cuda"); prop = torch.empty(B, d, device="cuda")
+    ctx.flow_step(_lib.FLOW_RWMH, key, beta, pos, logp, grad, acc, isacc, prop, None)
+    p = prop.cpu().numpy()
+    assert np.abs(p - info.proposed_position).max() < 5e-3 * max(1.0, np.abs(p).max())
+    with np.errstate(divide="ignore"):
+        la_g, la_o = np.log(acc.cpu().numpy().astype(np.float64)), np.log(info.acceptance_rate)
+    fin = np.isfinite(la_g) & np.isfinite(la_o)
+    assert fin.any() and np.abs(la_g[fin] - la_o[fin]).max() < 0.5
+    sure = ~fin | (np.abs(la_o) > 1)
+    np.testing.assert_array_equal(isacc.cpu().numpy().astype(bool)[sure], info.is_accepted[sure])
+    same = isacc.cpu().numpy().astype(bool) == info.is_accepted
+    np.testing.assert_allclose(logp.cpu().numpy()[same], new.logdensity[same], rtol=1e-4, atol=5e-2)
+    np.testing.assert_allclose(grad.cpu().numpy()[same], new.logdensity_grad[same], rtol=1e-3, atol=5e-2)
+    ctx.close()
