@@ -491,6 +491,9 @@ extern "C" int mfm_beta_update(mfm_ctx* x, double prev_beta, const double* d_ll,
 }
 
 #ifdef MFM_STAMPS
+extern "C" int mfm_debug_flow_buffer(unsigned long long* d_buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_flow_dbg), &d_buf, sizeof d_buf) == hipSuccess ? 0 : MFM_EHIP;
+}
 extern "C" int mfm_debug_eval_stamps(mfm_ctx* x, const float* d_x, const float* d_t, const float* d_tan, int n, int reps, unsigned long long* d_stamps) {
   int rc = launch_eval_stamps(x->net, d_x, d_t, d_tan, n, reps, d_stamps, x->stream);
   if (rc) return fail(rc, "eval_stamps cannot be launched");

@@ -90,6 +90,7 @@ __device__ static const float DP_M[7] = {(float)(6025192743.0 / 30085553152.0 / 
                                          (float)(-1776094331.0 / 19743644256.0 / 2), (float)(11237099.0 / 235043384.0 / 2)};
 
 #ifdef MFM_STAMPS
+__device__ unsigned long long* g_flow_dbg = nullptr;     // [WG][8]: cycles, realtime ticks, field evaluations, ...
 #define MFM_STAMP(id) do { if (stamps && lane == 0) stamps[(blockIdx.x * NW + wave) * 16 + (id)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define MFM_STAMP(id) do {} while (0)
@@ -98,6 +99,7 @@ __device__ static const float DP_M[7] = {(float)(6025192743.0 / 30085553152.0 / 
 template <int TPW, int NW>
 struct OdeTile {
   unsigned long long* stamps = nullptr;
+  unsigned long long n_eval = 0, cyc_eval = 0;
   const NetDev* n;
   OdeLds L;
   float* lds;
@@ -477,7 +479,13 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
         T.precompute_tz1();
       }
       float dl1[4];
+#ifdef MFM_STAMPS
+      const unsigned long long c0_ = __builtin_amdgcn_s_memtime();
+#endif
       T.eval(ts, kv, dl1, (phase + pj) & 1, nullptr, phase == 7 || pj > 0);
+#ifdef MFM_STAMPS
+      T.cyc_eval += __builtin_amdgcn_s_memtime() - c0_; T.n_eval += 1;
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) dlv[i] += dl1[i];
     }
@@ -813,6 +821,9 @@ template <int TPW, int NW>
 __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   OdeTile<TPW, NW> T;
+#ifdef MFM_STAMPS
+  const unsigned long long fc0_ = __builtin_amdgcn_s_memtime(), fr0_ = __builtin_amdgcn_s_memrealtime();
+#endif
   tile_init(T, &a.net, lds, true);
   T.exact = a.hutch == 0;
   const NetDev& N = a.net;
@@ -1001,6 +1012,13 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
       if (f.nsteps) f.nsteps[b] = natt_tot[i];
     }
   }
+#ifdef MFM_STAMPS
+  if (g_flow_dbg && threadIdx.x == 0) {
+    unsigned long long* o = g_flow_dbg + blockIdx.x * 8;
+    o[0] = __builtin_amdgcn_s_memtime() - fc0_; o[1] = __builtin_amdgcn_s_memrealtime() - fr0_;
+    o[2] = T.n_eval; o[3] = T.cyc_eval; o[4] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // XCC_ID
+  }
+#endif
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------

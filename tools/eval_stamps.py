@@ -11,7 +11,7 @@ args, dist, k, model, state = gu.phi4_setup(d=d, B=B)
 params = gu.rand_params(model, seed=1, out_scale=0.05)
 ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
 x = torch.from_numpy(dist.init_params.astype(np.float32)).cuda(); t = torch.rand(B, device="cuda"); z = torch.randn(B, d, device="cuda")
-NW = 8
+NW = int(os.environ.get("ODE_NW", "8"))
 st = torch.zeros(B // 16 * NW * 16, dtype=torch.int64, device="cuda")
 fn = ctx.lib.mfm_debug_eval_stamps
 fn.restype = C.c_int; fn.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]

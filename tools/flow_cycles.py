@@ -1,0 +1,46 @@
+"""Development aid: in-situ cycle accounting of the flow-MH step (stamps build): cycles per executed field evaluation,
+share of the solver loop outside the field evaluation, shader clock, attempt statistics."""
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["MFM_LIB"] = os.path.join(ROOT, "mfm_amd/lib/libmfm_hip_stamps.so")
+import numpy as np, torch
+import bench
+from mfm_amd import exe_flow_matching as E, random as jr
+from mfm_amd._lib import FLOW_RWMH
+from mfm_amd.distributions import PhiFour
+from mfm_amd.engine import Engine
+B = 4096
+args = bench.make_args(B, 10000)
+dist = PhiFour(256)
+k = jr.split(jr.PRNGKey(1), 6)
+dist.initialize_model(k[3], B)
+fourier = jr.normal(k[4], (128,))
+eng = Engine(dist, args, fourier)
+model = E.VectorFieldNet(fourier, dist.grad_logprob, args.hidden_x, args.hidden_t, args.hidden_xt).attach(eng)
+eng.ctx.set_params(E.flatten_params(model.init(k[2])))
+ctx = eng.ctx
+dbg = torch.zeros(B // 16 * 8, dtype=torch.int64, device="cuda")
+fn = ctx.lib.mfm_debug_flow_buffer; fn.restype = C.c_int; fn.argtypes = [C.c_void_p]
+assert fn(dbg.data_ptr()) == 0
+pos = eng.local(dist.init_params); logp = torch.empty(B, device="cuda", dtype=torch.float64); grad = torch.empty_like(pos)
+acc = torch.empty(B, device="cuda", dtype=torch.float32); nst = torch.zeros(B, device="cuda", dtype=torch.int32)
+ctx.mala_init(pos, 1.0, logp, grad)
+ks = k[1]
+for count in range(1, 304):
+    ks, kg, kt = jr.split(ks, 3)
+    if count % 101 == 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ctx.flow_step(FLOW_RWMH, kg, 1.0, pos, logp, grad, acc, None, None, nst); e1.record()
+        torch.cuda.synchronize()
+        n = nst.cpu().numpy().astype(float); t = n.reshape(-1, 16)
+        d = dbg.cpu().numpy().reshape(-1, 8).astype(float)
+        cyc, rt, nev, cev = d[:, 0], d[:, 1], d[:, 2], d[:, 3]
+        ms = e0.elapsed_time(e1)
+        print(f"flow step @ {count}: {ms:.1f} ms | natt mean {n.mean():.1f} p50 {np.median(n):.0f} p99 {np.percentile(n,99):.0f} max {n.max():.0f} | tile-max mean {t.max(1).mean():.1f} max {t.max(1).max():.0f}")
+        print(f"   per WG: evals mean {nev.mean():.0f} max {nev.max():.0f} | cycles mean {cyc.mean()/1e6:.1f}M max {cyc.max()/1e6:.1f}M | clock {np.median(cyc/rt)*0.1:.3f} GHz "
+              f"| cycles/eval in eval {np.median(cev/nev):.0f}, total/eval {np.median(cyc/nev):.0f} -> outside-eval share {1-np.median(cev/cyc):.3f}")
+        print(f"   WG time: mean/max {cyc.mean()/cyc.max():.3f}; alg evals (4+6 natt) mean {4+6*n.mean():.0f}; executed/alg {nev.mean()/(4+6*n.mean()):.3f}; max-WG/alg {nev.max()/(4+6*n.mean()):.3f}")
+    else:
+        ctx.mala_step(kg, 1.0, args.step_size, pos, logp, grad, acc)
+    eng.train_step(kt, pos)
