@@ -23,12 +23,22 @@
 // Gaussian draws the solver kernels consume (Hutchinson probes of both solves, latent random-walk noise) are
 // produced by a small separate kernel into this workspace: the float64 erfinv code would otherwise sit inside the
 // persistent solver kernel and cost it ~200 spilled registers.
-struct OdeWs { float* noise; size_t rows; };
+struct OdeWs { float* noise; size_t rows; f32x4* fast_scr; size_t fast_wgs; };
+#define ODE_FAST_MAX_WGS 1024                 // grid cap of the shape-specialised transform kernel (it loops over tiles)
+#define ODE_FAST_SCR_F4 (5 * 8 * 3 * 64)      // float4 of time-branch scratch per workgroup (ode_fast.hip)
 static int ode_ws_alloc(const NetDev& n, const mfm_config& c, OdeWs& w) {
   w.rows = (size_t)(c.max_eval_samples > c.n_chain_local ? c.max_eval_samples : c.n_chain_local);
-  return hipMalloc((void**)&w.noise, 3 * w.rows * n.d * sizeof(float)) == hipSuccess ? 0 : -4;
+  if (hipMalloc((void**)&w.noise, 3 * w.rows * n.d * sizeof(float)) != hipSuccess) return -4;
+  const size_t t_all = w.rows / 16, t_chain = (size_t)c.n_chain_local / 16;
+  w.fast_wgs = t_all < ODE_FAST_MAX_WGS ? t_all : ODE_FAST_MAX_WGS;
+  if (w.fast_wgs < t_chain) w.fast_wgs = t_chain;        // the flow step runs one workgroup per tile of 16 chains
+  return hipMalloc((void**)&w.fast_scr, w.fast_wgs * ODE_FAST_SCR_F4 * sizeof(f32x4)) == hipSuccess ? 0 : -4;
 }
-static void ode_ws_free(OdeWs& w) { if (w.noise) (void)hipFree(w.noise); w.noise = nullptr; }
+static void ode_ws_free(OdeWs& w) {
+  if (w.noise) (void)hipFree(w.noise);
+  if (w.fast_scr) (void)hipFree(w.fast_scr);
+  w.noise = nullptr; w.fast_scr = nullptr;
+}
 
 struct OdeArgs {
   NetDev net;
@@ -42,6 +52,7 @@ struct OdeArgs {
   const float* z1;          // probe of the (first / only) solve, [n][d]
   const float* z2;          // probe of the second solve (flow step)
   const float* zgen;        // latent proposal noise (flow step)
+  f32x4* fast_scr;          // time-branch scratch of the shape-specialised kernels (ode_fast.hip)
 };
 
 struct FlowArgs {
@@ -53,7 +64,7 @@ struct FlowArgs {
 
 static OdeArgs ode_args(const NetDev& n, const mfm_config& c, const OdeWs& w) {
   OdeArgs a; memset(&a, 0, sizeof a);
-  a.z1 = w.noise; a.z2 = w.noise + w.rows * n.d; a.zgen = w.noise + 2 * w.rows * n.d;
+  a.z1 = w.noise; a.z2 = w.noise + w.rows * n.d; a.zgen = w.noise + 2 * w.rows * n.d; a.fast_scr = w.fast_scr;
   a.net = n; a.hutch = c.hutch; a.rtol = (float)c.rtol; a.atol = (float)c.atol;
   a.max_attempts = c.mxstep * (c.n_ts > 1 ? c.n_ts - 1 : 1);
   return a;
@@ -1021,6 +1032,8 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
 #endif
 }
 
+#include "ode_fast.hip"
+
 // ---- launchers -----------------------------------------------------------------------------------------------
 // ODE_NW: waves per workgroup of the solver kernels.  4 = one wave per SIMD with a 512-register budget (the seven
 // Runge-Kutta stages stay in registers without spilling); 8 = two per SIMD with 256 registers each.
@@ -1051,6 +1064,8 @@ int launch_ode_transform(const OdeArgs& a, hipStream_t stream) {
   size_t sm; int tpw;
   if (ode_check(a.net, sm, tpw)) return -3;
   if (a.hutch) launch_probe(a.per_chain_keys ? 0 : 1, a.keys, a.key, 0, 0, 0, a.n, a.net.d, const_cast<float*>(a.z1), stream);
+  if (fast::shape_ok(a.net, a.hutch) && !getenv("MFM_GENERIC_ODE"))
+    return a.net.d == 256 ? fast::launch_transform_t<256>(a, a.fast_scr, stream) : fast::launch_transform_t<128>(a, a.fast_scr, stream);
   ODE_LAUNCH(ode_transform_kernel, dim3(a.n / 16), a);
   return 0;
 }
@@ -1068,6 +1083,8 @@ int launch_flow_step(const OdeArgs& a, const FlowArgs& f, hipStream_t stream) {
     launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 3, a.n, a.net.d, const_cast<float*>(a.z1), stream);     // key_hutch2
     launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 2, a.n, a.net.d, const_cast<float*>(a.z2), stream);     // key_hutch1
   }
+  if (fast::shape_ok(a.net, a.hutch) && !getenv("MFM_GENERIC_ODE"))
+    return a.net.d == 256 ? fast::launch_flow_t<256>(a, f, a.fast_scr, stream) : fast::launch_flow_t<128>(a, f, a.fast_scr, stream);
   ODE_LAUNCH(flow_step_kernel, dim3(a.n / 16), a, f);
   return 0;
 }
