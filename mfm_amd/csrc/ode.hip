@@ -413,7 +413,7 @@ __device__ static const float DP_TAB[8][7] = {   // [phase][j]: input = y + h * 
     {9017.f / 3168, -355.f / 33, 46732.f / 5247, 49.f / 176, -5103.f / 18656, 0, 1.f},
     {35.f / 384, 0, 500.f / 1113, 125.f / 192, -2187.f / 6784, 11.f / 84, 1.f}};
 
-enum { RS_T = 0, RS_DT = 1, RS_H0 = 2, RS_D1 = 3, RS_ELL = 4, RS_KL = 5 /* ..11 */, RS_NATT = 12, RS_DONE = 13 };
+enum { RS_T = 0, RS_DT = 1, RS_H0 = 2, RS_D1 = 3, RS_ELL = 4, RS_KL = 5 /* ..11 */, RS_NATT = 12, RS_DONE = 13, RS_FLAG = 14, RS_SFRAC = 15 };
 
 template <int TPW, int NW>
 __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float atol, int max_attempts,

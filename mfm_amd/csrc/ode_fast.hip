@@ -31,11 +31,16 @@ template <int D>
 struct FS {                                         // float offsets (LDS, packed weights, biases)
   static constexpr int TPW = D / 128;
   static constexpr int LDX = D + 8, LDH = H + 4;
-  static constexpr int XB0 = 0, XB1 = 16 * LDX, ZB = 32 * LDX, R = 48 * LDX;
-  static constexpr int A1 = R, SX = R + 32 * LDH, J1 = R + 64 * LDH, J2 = R + 96 * LDH;     // x branch (32 rows each)
-  static constexpr int FH = R, T1 = R + 80 * LDH;                                             // time batch (80 rows each); ST = FH
-  static constexpr int RS = R + 160 * LDH, RED = RS + 256, DLP = RED + 4 * 128, BIAS = DLP + 8 * 128;
-  static constexpr int BTOT = 6 * H + 2 * D, TOTAL = BIAS + BTOT;
+  // Small, often-addressed structures first: every LDS access below is (one of a handful of per-lane base registers) +
+  // a constant that fits the 16-bit DS offset field.  (Constants beyond 64 KB each cost a register, and the compiler
+  // hoists all of them out of the solver loop: with the row state at 135 KB that alone spilled ~250 registers.)
+  static constexpr int BTOT = 6 * H + 2 * D;
+  static constexpr int RS = 0, RED = RS + 256, DLP = RED + 4 * 128, BIAS = DLP + 8 * 128;
+  static constexpr int XB0 = BIAS + BTOT, XB1 = XB0 + 16 * LDX, ZB = XB1 + 16 * LDX, R = ZB + 16 * LDX;
+  // region R, x branch (32 rows each): A1 (x1 out), SX at R; J1, J2 at R2 = R + 64 LDH.  Time batch (80 rows each):
+  // FH (Fourier features, later st) at R, T1 at R2 + 16 LDH
+  static constexpr int R2 = R + 64 * LDH, TOTAL = R + 160 * LDH;
+  static_assert((ZB + 16 * LDX) * 4 <= 65536 && 96 * LDH * 4 + 16 * LDH * 4 <= 65536, "DS offset field");
   static constexpr int W0 = 0, W1 = W0 + 2 * F * H, W2 = W1 + H * H, W3 = W2 + D * H, W4 = W3 + H * H, W5 = W4 + H * D,
                        W6 = W5 + 2 * H * H, W7 = W6 + H * H, WTOT = W7 + H * D;
   static constexpr int B0 = 0, B1 = H, B2 = 2 * H, B3 = 3 * H, B4 = 4 * H, B5 = 4 * H + D, B6 = 5 * H + D, B7 = 6 * H + D;
@@ -52,8 +57,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// Stores keep the scalar offset OUT of the soffset field (it is added into the per-lane offset instead): a
+// buffer_store_dwordx4 with an SGPR soffset followed at once by a VALU write of one of its data registers stored the
+// NEW value of that register on gfx950 (one element of the float4 wrong, which element depending on register
+// allocation).  hipcc only pads that write-after-read hazard when soffset is not a register, so that is the form used.
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + soff, 0, 0);
 }
 template <int NTL, int T1OFF>
 __device__ __forceinline__ void load_group(f32x4 (&bf)[4], __amdgpu_buffer_rsrc_t r, int soff, int lane) {
@@ -65,25 +74,27 @@ __device__ __forceinline__ void load_group(f32x4 (&bf)[4], __amdgpu_buffer_rsrc_
 template <int MT, int NTL, int LDA>
 __device__ __forceinline__ void exec_group(const float* arow, const f32x4 (&bf)[4], f32x4 (&acc)[NTL][MT]) {
   constexpr int KPG = 4 / NTL;
-  // A fragments one k-block ahead (two register sets, statically renamed by the unroll): the LDS latency of block u + 1
-  // hides behind the MFMAs of block u, and the scheduler cannot hoist a whole group's reads (MT = 5: 80 registers)
-  f32x4 a[2][MT];
+  // ONE set of A fragments, refreshed in place: a[m] is reloaded for k-block u + 1 right after its last use in block u
+  // (k-step 3), i.e. MT - 1 MFMAs (>= 128 cycles with the SIMD partner) before block u + 1 needs it.  The scheduling
+  // barriers pin that order: left alone, the scheduler hoists a whole group's reads (MT = 5: 80 registers).
+  f32x4 a[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * LDA);
+  for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * LDA);
 #pragma unroll
   for (int u = 0; u < KPG; ++u) {
-    if (u + 1 < KPG) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[(u + 1) & 1][m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * LDA + (u + 1) * 16);
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) acc[t][m] = mfma4(a[m][s], bf[u * NTL + t][s], acc[t][m]);
+        if (s == 3 && u + 1 < KPG) {
+          __builtin_amdgcn_sched_barrier(0);
+          a[m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * LDA + (u + 1) * 16);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int t = 0; t < NTL; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[t][m] = mfma4(a[u & 1][m][s], bf[u * NTL + t][s], acc[t][m]);
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 // single tile, single row block: two accumulators (even / odd k-blocks) so the 40-cycle dependent latency never stalls
@@ -131,39 +142,47 @@ struct FTile {
   int lane, wave, g, c, sign;
   float ffreq, coef, tbeta, clip;
   float tz1[4];
+  // per-lane LDS base offsets in BYTES, opaque to the optimiser (see FS): row state / partial-sum reads (rows 4g..),
+  // partial-sum writes, bias column, A-fragment reads and owned-element accesses in the X / Z buffers, A-fragment reads
+  // and epilogue writes in region R and in R2 = R + 64 LDH
+  int o_rs, o_pg, o_pp, o_bias, o_xa, o_xo, o_ha, o_ha2, o_he, o_he2, o_l8, o_l1;    // o_l8 / o_l1: row leaders (row = lane)
+  __device__ __forceinline__ float* at(int off_bytes, int cfloats) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + off_bytes) + cfloats; }
+#ifdef MFM_STAMPS
+  unsigned long long n_eval = 0, cyc_eval = 0, n_tb = 0, cyc_tb = 0;
+#endif
 
   __device__ __forceinline__ int W(int off_floats, int nt, int KB, int kb = 0) const { return off_floats * 4 + (nt * KB + kb) * 1024; }   // byte offset of a fragment
-  __device__ __forceinline__ float bias(int off) const { return lds[S::BIAS + off]; }
-  __device__ __forceinline__ f32x4 rs_get(int field) const { return *reinterpret_cast<const f32x4*>(lds + S::RS + field * 16 + 4 * g); }
+  __device__ __forceinline__ float bias(int off) const { return *at(o_bias, S::BIAS + off); }      // column 16 wave + c (+ 128 q) of a layer
+  __device__ __forceinline__ f32x4 rs_get(int field) const { return *reinterpret_cast<const f32x4*>(at(o_rs, S::RS + field * 16)); }
   __device__ __forceinline__ void rs_put(int field, const float (&v)[4]) {
-    if (wave == 0 && c == 0) *reinterpret_cast<f32x4*>(lds + S::RS + field * 16 + 4 * g) = f32x4{v[0], v[1], v[2], v[3]};
+    if (wave == 0 && c == 0) *reinterpret_cast<f32x4*>(at(o_rs, S::RS + field * 16)) = f32x4{v[0], v[1], v[2], v[3]};
   }
   // partial sums of this lane's 4 rows over its 16 columns -> LDS [slot][row][wave]; totals after a barrier
-  __device__ __forceinline__ void part_put(float* base, float (&p)[4]) {
+  __device__ __forceinline__ void part_put(int base, float (&p)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) p[i] = group16_sum(p[i]);
     if (c == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) base[(4 * g + i) * 8 + wave] = p[i];
+      for (int i = 0; i < 4; ++i) *at(o_pp, base + i * 8) = p[i];
     }
   }
-  __device__ __forceinline__ void part_get(const float* base, float (&p)[4]) const {
+  __device__ __forceinline__ void part_get(int base, float (&p)[4]) const {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(base + (4 * g + i) * 8), b = *reinterpret_cast<const f32x4*>(base + (4 * g + i) * 8 + 4);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(at(o_pg, base + i * 8)), b = *reinterpret_cast<const f32x4*>(at(o_pg, base + i * 8 + 4));
       p[i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
     }
   }
   __device__ __forceinline__ void row_reduce(float (&p)[4], int slot) {
-    part_put(lds + S::RED + slot * 128, p);
+    part_put(S::RED + slot * 128, p);
     __syncthreads();
-    part_get(lds + S::RED + slot * 128, p);
+    part_get(S::RED + slot * 128, p);
   }
 
   // z W_x1 (no bias), once per solve.  Entry: P = first group of W2 tile `wave`; exit: P = first group of W0 tile `wave`.
   __device__ __forceinline__ void precompute_tz1(f32x4 (&P)[4], f32x4 (&Q)[4]) {
     f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(lds + S::ZB + 4 + (lane & 15) * LDX + 4 * g, wr, W(S::W2, wave, D / 16), W(S::W0, wave, 2 * F / 16), lane, P, Q, acc);
+    run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(at(o_xa, S::ZB), wr, W(S::W2, wave, D / 16), W(S::W0, wave, 2 * F / 16), lane, P, Q, acc);
 #pragma unroll
     for (int i = 0; i < 4; ++i) tz1[i] = acc[0][i] + acc[1][i];
   }
@@ -173,9 +192,8 @@ struct FTile {
   // barrier has passed since every LDS access of this routine (region R is free for the x branch; a stage input written
   // by the caller BEFORE this call is visible).
   __device__ __forceinline__ void tbatch(int phase, f32x4 (&P)[4], f32x4 (&Q)[4]) {
-    const int r = lane & 15;
-    float sv[5][4];
     {
+      float sv[5][4];
       const f32x4 t4 = rs_get(RS_T), h4 = rs_get(phase == 1 ? RS_H0 : RS_DT);
       const double f = (double)ffreq;
 #pragma unroll
@@ -189,40 +207,44 @@ struct FTile {
           ft -= rint(ft);
           float cv;
           sincospif(2.f * (float)ft, &sv[s][i], &cv);                          // :70-71
-          lds[S::FH + (s * 16 + 4 * g + i) * LDH + 16 * wave + c] = cv;
+          *at(o_he, (s * 16 + i) * LDH) = cv;
         }
+        // the sine block waits in this lane's scratch slot of the stage (rewritten by the gate epilogue afterwards)
+        bstore(sr, lane * 16, ((s * NW + wave) * 3 + 0) * 1024, f32x4{sv[s][0], sv[s][1], sv[s][2], sv[s][3]});
       }
     }
     __syncthreads();
     f32x4 acc[1][5];
 #pragma unroll
     for (int m = 0; m < 5; ++m) acc[0][m] = f32x4{0, 0, 0, 0};
-    const float* afh = lds + S::FH + r * LDH + 4 * g;
+    const float* afh = at(o_ha, 0);
     run_job<5, 1, 8, LDH, 0, 1, 0>(afh, wr, W(S::W0, wave, 16, 0), W(S::W0, wave, 16, 8), lane, P, Q, acc);      // cos half
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 5; ++s)
+    for (int s = 0; s < 5; ++s) {
+      const f32x4 sn = bload(sr, lane * 16, ((s * NW + wave) * 3 + 0) * 1024);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) lds[S::FH + (s * 16 + 4 * g + i) * LDH + 16 * wave + c] = sv[s][i];
+      for (int i = 0; i < 4; ++i) *at(o_he, (s * 16 + i) * LDH) = sn[i];
+    }
     __syncthreads();
     run_job<5, 1, 8, LDH, 0, 1, 0>(afh, wr, W(S::W0, wave, 16, 8), W(S::W1, wave, 8), lane, P, Q, acc);           // sin half
     {
-      const float b = bias(S::B0 + 16 * wave + c);
+      const float b = bias(S::B0);
 #pragma unroll
       for (int m = 0; m < 5; ++m)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lds[S::T1 + (m * 16 + 4 * g + i) * LDH + 16 * wave + c] = fmaxf(acc[0][m][i] + b, 0.f);
+        for (int i = 0; i < 4; ++i) *at(o_he2, (16 + m * 16 + i) * LDH) = fmaxf(acc[0][m][i] + b, 0.f);
     }
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < 5; ++m) acc[0][m] = f32x4{0, 0, 0, 0};
-    run_job<5, 1, 8, LDH, 0, 1, 0>(lds + S::T1 + r * LDH + 4 * g, wr, W(S::W1, wave, 8), W(S::W4, wave, 8), lane, P, Q, acc);
+    run_job<5, 1, 8, LDH, 0, 1, 0>(at(o_ha2, 16 * LDH), wr, W(S::W1, wave, 8), W(S::W4, wave, 8), lane, P, Q, acc);
     {
-      const float b = bias(S::B1 + 16 * wave + c);
+      const float b = bias(S::B1);
 #pragma unroll
       for (int m = 0; m < 5; ++m)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lds[S::FH + (m * 16 + 4 * g + i) * LDH + 16 * wave + c] = fmaxf(acc[0][m][i] + b, 0.f);   // st
+        for (int i = 0; i < 4; ++i) *at(o_he, (m * 16 + i) * LDH) = fmaxf(acc[0][m][i] + b, 0.f);   // st
     }
     __syncthreads();
     const float* ast = afh;
@@ -235,10 +257,10 @@ struct FTile {
       if (q < 2) {
         const int nxt = (q == 0 && TPW == 2) ? W(S::W4, wave + 8, 8) : W(S::W5, wave, 16, 8);
         run_job<5, 1, 8, LDH, 0, 1, 0>(ast, wr, W(S::W4, wave + 8 * q, 8), nxt, lane, P, Q, acc);
-        b = bias(S::B4 + 16 * (wave + 8 * q) + c);
+        b = bias(S::B4 + 128 * q);
       } else {
         run_job<5, 1, 8, LDH, 0, 1, 0>(ast, wr, W(S::W5, wave, 16, 8), W(S::W2, wave, D / 16), lane, P, Q, acc);
-        b = bias(S::B5 + 16 * wave + c);
+        b = bias(S::B5);
       }
 #pragma unroll
       for (int m = 0; m < 5; ++m) bstore(sr, lane * 16, ((m * NW + wave) * 3 + q) * 1024, f32x4{acc[0][m][0] + b, acc[0][m][1] + b, acc[0][m][2] + b, acc[0][m][3] + b});
@@ -251,8 +273,7 @@ struct FTile {
   // elements (row 4g+i, col 16 (wave + 8 q) + c); this wave's divergence partials in DLP[dst]; P = first group of
   // `wnext` (W2: another evaluation follows, W0: a time batch follows).
   __device__ __forceinline__ void eval(int slot, int cur, int dst, bool next_is_tbatch, f32x4 (&P)[4], f32x4 (&Q)[4], float (&kv)[TPW][4]) {
-    const int r = lane & 15;
-    const float* xb = lds + (cur ? S::XB1 : S::XB0);
+    const int xsel = cur ? S::XB1 * 4 : S::XB0 * 4;
     // stage-time inputs of this lane, written by itself in tbatch
     f32x4 gt[TPW];
 #pragma unroll
@@ -260,93 +281,86 @@ struct FTile {
     const f32x4 j1t = bload(sr, lane * 16, ((slot * NW + wave) * 3 + 2) * 1024);
     {   // x1: value rows; tangent rows = relu' * (z W_x1)
       f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-      run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(xb + 4 + r * LDX + 4 * g, wr, W(S::W2, wave, D / 16), W(S::W3, wave, 8), lane, P, Q, acc);
-      const float b = bias(S::B2 + 16 * wave + c);
+      run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(at(o_xa + xsel, 0), wr, W(S::W2, wave, D / 16), W(S::W3, wave, 8), lane, P, Q, acc);
+      const float b = bias(S::B2);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float pre = (acc[0][i] + acc[1][i]) + b;
-        const int o = S::A1 + (4 * g + i) * LDH + 16 * wave + c;
-        lds[o] = fmaxf(pre, 0.f);
-        lds[o + 16 * LDH] = pre > 0.f ? tz1[i] : 0.f;
+        *at(o_he, i * LDH) = fmaxf(pre, 0.f);
+        *at(o_he, (16 + i) * LDH) = pre > 0.f ? tz1[i] : 0.f;
       }
     }
     __syncthreads();
     {   // x2
       f32x4 acc[1][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}};
-      run_job<2, 1, 8, LDH, 0, 1, 0>(lds + S::A1 + r * LDH + 4 * g, wr, W(S::W3, wave, 8), W(S::W5, wave, 16, 0), lane, P, Q, acc);
-      const float b = bias(S::B3 + 16 * wave + c);
+      run_job<2, 1, 8, LDH, 0, 1, 0>(at(o_ha, 0), wr, W(S::W3, wave, 8), W(S::W5, wave, 16, 0), lane, P, Q, acc);
+      const float b = bias(S::B3);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float pre = acc[0][0][i] + b;
-        const int o = S::SX + (4 * g + i) * LDH + 16 * wave + c;
-        lds[o] = fmaxf(pre, 0.f);
-        lds[o + 16 * LDH] = pre > 0.f ? acc[0][1][i] : 0.f;
+        *at(o_he, (32 + i) * LDH) = fmaxf(pre, 0.f);
+        *at(o_he, (48 + i) * LDH) = pre > 0.f ? acc[0][1][i] : 0.f;
       }
     }
     __syncthreads();
     {   // j1: sx half of the concatenated input (:83); the st half + bias arrive as the initial accumulator
       f32x4 acc[1][2] = {{j1t, {0, 0, 0, 0}}};
-      run_job<2, 1, 8, LDH, 0, 1, 0>(lds + S::SX + r * LDH + 4 * g, wr, W(S::W5, wave, 16, 0), W(S::W6, wave, 8), lane, P, Q, acc);
+      run_job<2, 1, 8, LDH, 0, 1, 0>(at(o_ha, 32 * LDH), wr, W(S::W5, wave, 16, 0), W(S::W6, wave, 8), lane, P, Q, acc);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float pre = acc[0][0][i];
-        const int o = S::J1 + (4 * g + i) * LDH + 16 * wave + c;
-        lds[o] = fmaxf(pre, 0.f);
-        lds[o + 16 * LDH] = pre > 0.f ? acc[0][1][i] : 0.f;
+        *at(o_he2, i * LDH) = fmaxf(pre, 0.f);
+        *at(o_he2, (16 + i) * LDH) = pre > 0.f ? acc[0][1][i] : 0.f;
       }
     }
     __syncthreads();
     {   // j2
       f32x4 acc[1][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}};
-      run_job<2, 1, 8, LDH, 0, TPW, OUT_T1OFF>(lds + S::J1 + r * LDH + 4 * g, wr, W(S::W6, wave, 8), W(S::W7, wave, 8), lane, P, Q, acc);
-      const float b = bias(S::B6 + 16 * wave + c);
+      run_job<2, 1, 8, LDH, 0, TPW, OUT_T1OFF>(at(o_ha2, 0), wr, W(S::W6, wave, 8), W(S::W7, wave, 8), lane, P, Q, acc);
+      const float b = bias(S::B6);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float pre = acc[0][0][i] + b;
-        const int o = S::J2 + (4 * g + i) * LDH + 16 * wave + c;
-        lds[o] = fmaxf(pre, 0.f);
-        lds[o + 16 * LDH] = pre > 0.f ? acc[0][1][i] : 0.f;
+        *at(o_he2, (32 + i) * LDH) = fmaxf(pre, 0.f);
+        *at(o_he2, (48 + i) * LDH) = pre > 0.f ? acc[0][1][i] : 0.f;
       }
     }
     __syncthreads();
     {   // out: v = nn_xt + nn_t * clip(grad log pi(x)) (:88-90);  J z = d nn_xt . z + nn_t * 1[|g| <= clip] * (H z)
-      float gc[TPW][4], hz[TPW][4], zz[TPW][4];
-      const float* zb = lds + S::ZB;
+      float gc[TPW][4], hz[TPW][4];
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
-        const int col = 16 * (wave + NW * q) + c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float* xr = xb + (4 * g + i) * LDX + 4 + col;
-          const float* zr = zb + (4 * g + i) * LDX + 4 + col;
+          const float* xr = at(o_xo + xsel, i * LDX + 128 * q);
+          const float* zr = at(o_xo, S::ZB + i * LDX + 128 * q);
           const float x = xr[0], z = zr[0];
           const float graw = -tbeta * (coef * (2.f * x - xr[-1] - xr[1]) - x * (1.f - x * x) / coef);
           const float hv = -tbeta * (coef * (2.f * z - zr[-1] - zr[1]) - (1.f - 3.f * x * x) * z / coef);
           gc[q][i] = clip > 0.f ? fminf(fmaxf(graw, -clip), clip) : graw;
           hz[q][i] = (!(clip > 0.f) || fabsf(graw) <= clip) ? hv : 0.f;
-          zz[q][i] = z;
         }
       }
       f32x4 acc[TPW][2];
 #pragma unroll
       for (int q = 0; q < TPW; ++q) { acc[q][0] = f32x4{0, 0, 0, 0}; acc[q][1] = f32x4{0, 0, 0, 0}; }
       const int wnext = next_is_tbatch ? W(S::W0, wave, 16) : W(S::W2, wave, D / 16);
-      run_job<2, TPW, 8, LDH, OUT_T1OFF, 1, 0>(lds + S::J2 + r * LDH + 4 * g, wr, W(S::W7, wave, 8), wnext, lane, P, Q, acc);
+      run_job<2, TPW, 8, LDH, OUT_T1OFF, 1, 0>(at(o_ha2, 32 * LDH), wr, W(S::W7, wave, 8), wnext, lane, P, Q, acc);
       float dp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
-        const float b = bias(S::B7 + 16 * (wave + NW * q) + c);
+        const float b = bias(S::B7 + 128 * q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float v = acc[q][0][i] + b + gt[q][i] * gc[q][i];
           const float jz = acc[q][1][i] + gt[q][i] * hz[q][i];
-          dp[i] += zz[q][i] * jz;
+          dp[i] += *at(o_xo, S::ZB + i * LDX + 128 * q) * jz;
           kv[q][i] = sign > 0 ? v : -v;
         }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) dp[i] = sign > 0 ? -dp[i] : dp[i];          // :218 / :239
-      part_put(lds + S::DLP + dst * 128, dp);
+      part_put(S::DLP + dst * 128, dp);
     }
   }
 };
@@ -372,7 +386,7 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
     const float z4[4] = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();                       // previous users of the row state / Z writers are done
 #pragma unroll
-    for (int fld = 0; fld < 14; ++fld) T.rs_put(fld, z4);
+    for (int fld = 0; fld < 16; ++fld) T.rs_put(fld, z4);
   }
   f32x4 P[4], Q[4];
   load_group<1, 0>(P, T.wr, T.W(S::W2, wave, D / 16), T.lane);
@@ -391,23 +405,32 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
       const f32x4 h4 = T.rs_get(phase == 1 ? RS_H0 : RS_DT);
 #pragma unroll
       for (int i = 0; i < 4; ++i) hs[i] = h4[i];
-      float* xw = lds + (cur ? S::XB1 : S::XB0);
+      const int xsel = cur ? S::XB1 * 4 : S::XB0 * 4;
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
-        const int col = 16 * (wave + NW * q) + c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float acc = 0.f;
 #pragma unroll
           for (int j = 0; j < 6; ++j) acc += cf[j] * k[j][q][i];
-          xw[(4 * g + i) * LDX + 4 + col] = y[q][i] + hs[i] * acc;
+          *T.at(T.o_xo + xsel, i * LDX + 128 * q) = y[q][i] + hs[i] * acc;
         }
       }
     }
+#ifdef MFM_STAMPS
+    const unsigned long long c0_ = __builtin_amdgcn_s_memtime();
+#endif
     if (phase <= 2) T.tbatch(phase, P, Q); else __syncthreads();
+#ifdef MFM_STAMPS
+    const unsigned long long c1_ = __builtin_amdgcn_s_memtime();
+    if (phase <= 2) { T.cyc_tb += c1_ - c0_; T.n_tb += 1; }
+#endif
     float kv[TPW][4];
     const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
     T.eval(phase < 2 ? 0 : (phase == 7 ? 4 : phase - 2), cur, dst, phase == 7 || phase < 2, P, Q, kv);
+#ifdef MFM_STAMPS
+    T.cyc_eval += __builtin_amdgcn_s_memtime() - c1_; T.n_eval += 1;
+#endif
     cur ^= 1;
     // ---- route the result: phase 0 -> k[0], phase 1 -> k[1], phase p >= 2 -> k[p - 1] ----
 #pragma unroll
@@ -430,19 +453,20 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
           const float a0 = y[q][i] / sc, a1 = k[0][q][i] / sc;
           p0[i] += a0 * a0; p1[i] += a1 * a1;
         }
-      T.part_put(lds + S::RED + 0 * 128, p0); T.part_put(lds + S::RED + 1 * 128, p1);
+      T.part_put(S::RED + 0 * 128, p0); T.part_put(S::RED + 1 * 128, p1);
       __syncthreads();
-      T.part_get(lds + S::RED + 0 * 128, p0); T.part_get(lds + S::RED + 1 * 128, p1);
-      float dlv[4];
-      T.part_get(lds + S::DLP + 0 * 128, dlv);
-      float h0[4], d1[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float a1 = dlv[i] / atol;                                // ell0 = 0 -> scale = atol
-        const float d0 = sqrtf(p0[i]); d1[i] = sqrtf(p1[i] + a1 * a1);
-        h0[i] = (d0 < 1e-5f || d1[i] < 1e-5f) ? 1e-6f : 0.01f * d0 / d1[i];
+      if (wave == 0 && T.lane < 16) {          // row leaders (see the end-of-step block below)
+        auto sum8 = [&](int base) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(T.at(T.o_l8, base)), b = *reinterpret_cast<const f32x4*>(T.at(T.o_l8, base + 4));
+          return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+        };
+        auto R1 = [&](int field) -> float& { return *T.at(T.o_l1, S::RS + field * 16); };
+        const float dl0 = sum8(S::DLP + 0 * 128);
+        const float a1 = dl0 / atol;                                   // ell0 = 0 -> scale = atol
+        const float d0 = sqrtf(sum8(S::RED + 0 * 128)), d1 = sqrtf(sum8(S::RED + 1 * 128) + a1 * a1);
+        R1(RS_H0) = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+        R1(RS_D1) = d1; R1(RS_KL + 0) = dl0;
       }
-      T.rs_put(RS_H0, h0); T.rs_put(RS_D1, d1); T.rs_put(RS_KL + 0, dlv);
       __syncthreads();
       phase = 1;
     } else if (phase == 1) {
@@ -455,118 +479,125 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
           const float a2 = (k[1][q][i] - k[0][q][i]) / sc;
           p2[i] += a2 * a2;
         }
-      T.part_put(lds + S::RED + 2 * 128, p2);
+      T.part_put(S::RED + 2 * 128, p2);
       __syncthreads();
-      T.part_get(lds + S::RED + 2 * 128, p2);
-      float dlv[4];
-      T.part_get(lds + S::DLP + 1 * 128, dlv);
-      const f32x4 h04 = T.rs_get(RS_H0), d14 = T.rs_get(RS_D1), kl0 = T.rs_get(RS_KL + 0);
-      float dt[4];
-      bool any = false;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float a2 = (dlv[i] - kl0[i]) / atol;
-        const float d2 = sqrtf(p2[i] + a2 * a2) / h04[i];
-        const float h1 = (d14[i] <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h04[i] * 1e-3f)
-                                                            : powf(0.01f / fmaxf(d14[i], d2), 0.2f);
-        dt[i] = fminf(100.f * h04[i], h1);
-        any |= (dt[i] > 0.f);
+      int any = 0;
+      if (wave == 0 && T.lane < 16) {
+        auto sum8 = [&](int base) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(T.at(T.o_l8, base)), b = *reinterpret_cast<const f32x4*>(T.at(T.o_l8, base + 4));
+          return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+        };
+        auto R1 = [&](int field) -> float& { return *T.at(T.o_l1, S::RS + field * 16); };
+        const float h0 = R1(RS_H0), d1 = R1(RS_D1);
+        const float a2 = (sum8(S::DLP + 1 * 128) - R1(RS_KL + 0)) / atol;
+        const float d2 = sqrtf(sum8(S::RED + 2 * 128) + a2 * a2) / h0;
+        const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
+        const float dt = fminf(100.f * h0, h1);
+        R1(RS_DT) = dt;
+        any = dt > 0.f ? 1 : 0;
       }
-      T.rs_put(RS_DT, dt);
       phase = 2;
-      if (!__syncthreads_or(any ? 1 : 0)) break;
+      if (!__syncthreads_or(any)) break;
     } else if (phase < 7) {
       phase += 1;
     } else {
       // ---- end of an attempted step ----
-      float y1[TPW][4], e2[4] = {0, 0, 0, 0};
+      // every lane: this wave's share of the squared error norm of its rows
+      {
+        float e2[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int q = 0; q < TPW; ++q)
+        for (int q = 0; q < TPW; ++q)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float acc = 0.f, er = 0.f;
+          for (int i = 0; i < 4; ++i) {
+            float acc = 0.f, er = 0.f;
 #pragma unroll
-          for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * k[j][q][i];
-          y1[q][i] = y[q][i] + hs[i] * acc;                    // the stage-7 input (5th-order solution), same arithmetic
+            for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * k[j][q][i];
+            const float y1 = y[q][i] + hs[i] * acc;               // the stage-7 input (5th-order solution), same arithmetic
 #pragma unroll
-          for (int j = 0; j < 7; ++j) er += DP_E[j] * k[j][q][i];
-          er *= hs[i];
-          const float tol = atol + rtol * fmaxf(fabsf(y[q][i]), fabsf(y1[q][i]));
-          const float rr = er / tol;
-          e2[i] += rr * rr;
-        }
-      T.part_put(lds + S::RED + 3 * 128, e2);
+            for (int j = 0; j < 7; ++j) er += DP_E[j] * k[j][q][i];
+            er *= hs[i];
+            const float tol = atol + rtol * fmaxf(fabsf(y[q][i]), fabsf(y1));
+            const float rr = er / tol;
+            e2[i] += rr * rr;
+          }
+        T.part_put(S::RED + 3 * 128, e2);
+      }
       __syncthreads();
-      T.part_get(lds + S::RED + 3 * 128, e2);
-      const f32x4 t4 = T.rs_get(RS_T), ell4 = T.rs_get(RS_ELL);
-      const f32x4 na4 = T.rs_get(RS_NATT), dn4 = T.rs_get(RS_DONE), kl04 = T.rs_get(RS_KL + 0);
-      float kl[7][4];
+      // ONE lane per row (the row leaders: lanes 0..15 of wave 0) totals the partials and runs the step-size controller;
+      // it publishes the new row state, a decision flag (0 keep, 1 advance, 2 finish) and the interpolation abscissa
+      int any = 0;
+      if (wave == 0 && T.lane < 16) {
+        auto sum8 = [&](int base) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(T.at(T.o_l8, base)), b = *reinterpret_cast<const f32x4*>(T.at(T.o_l8, base + 4));
+          return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+        };
+        auto R1 = [&](int field) -> float& { return *T.at(T.o_l1, S::RS + field * 16); };
+        float kl[7];
+        kl[0] = R1(RS_KL + 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) kl[0][i] = kl04[i];
+        for (int j = 1; j < 7; ++j) kl[j] = sum8(S::DLP + j * 128);
+        const float e2 = sum8(S::RED + 3 * 128);
+        const float t0 = R1(RS_T), dti = R1(RS_DT), ell0 = R1(RS_ELL), na = R1(RS_NATT), dn = R1(RS_DONE);
+        const bool active = !(dn != 0.f) && na < (float)max_attempts && dti > 0.f;
+        float sl = 0.f, el = 0.f, lm = 0.f;
 #pragma unroll
-      for (int j = 1; j < 7; ++j) T.part_get(lds + S::DLP + j * 128, kl[j]);
-      bool any = false;
-      float t_n[4], dt_n[4], ell_n[4], kl0_n[4], na_n[4], dn_n[4];
+        for (int j = 0; j < 6; ++j) sl += DP_TAB[7][j] * kl[j];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float dti = hs[i];
-        const bool was_done = dn4[i] != 0.f;
-        const bool active = !was_done && na4[i] < (float)max_attempts && dti > 0.f;
-        float sl = 0.f, el = 0.f;
+        for (int j = 0; j < 7; ++j) el += DP_E[j] * kl[j];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) sl += DP_TAB[7][j] * kl[j][i];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) el += DP_E[j] * kl[j][i];
-        const float l1 = ell4[i] + dti * sl;
+        for (int j = 0; j < 7; ++j) lm += DP_M[j] * kl[j];
+        const float l1 = ell0 + dti * sl;
         el *= dti;
-        const float tol = atol + rtol * fmaxf(fabsf(ell4[i]), fabsf(l1));
+        const float tol = atol + rtol * fmaxf(fabsf(ell0), fabsf(l1));
         const float rr = el / tol;
-        const float ratio = sqrtf((e2[i] + rr * rr) * inv_n);
+        const float ratio = sqrtf((e2 + rr * rr) * inv_n);
         const bool acc = active && ratio <= 1.f;
         const float dfac = ratio < 1.f ? 1.f : 0.2f;
         const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
         const float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
-        t_n[i] = t4[i]; ell_n[i] = ell4[i]; kl0_n[i] = kl[0][i]; dn_n[i] = dn4[i];
-        if (acc) {
-          const float tn = t4[i] + dti;
-          if (tn >= 1.f) {
-            // final output: 4th-order interpolant of this step evaluated at t = 1
-            const float sfrac = (1.f - t4[i]) / (tn - t4[i]);
-            float lm = 0.f;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) lm += DP_M[j] * kl[j][i];
-            const float y0 = ell4[i], yy1 = l1, ym = y0 + dti * lm, f0 = dti * kl[0][i], f1 = dti * kl[6][i];
-            const float pa = -2.f * f0 + 2.f * f1 - 8.f * y0 - 8.f * yy1 + 16.f * ym;
-            const float pb = 5.f * f0 - 3.f * f1 + 18.f * y0 + 14.f * yy1 - 32.f * ym;
-            const float pc = -4.f * f0 + f1 - 11.f * y0 - 5.f * yy1 + 16.f * ym;
-            ell_n[i] = (((pa * sfrac + pb) * sfrac + pc) * sfrac + f0) * sfrac + y0;
-#pragma unroll
-            for (int q = 0; q < TPW; ++q) {
-              float km = 0.f;
-#pragma unroll
-              for (int j = 0; j < 7; ++j) km += DP_M[j] * k[j][q][i];
-              const float x0 = y[q][i], x1 = y1[q][i], xm = x0 + dti * km, g0 = dti * k[0][q][i], g1 = dti * k[6][q][i];
-              const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
-              const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
-              const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
-              y[q][i] = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
-            }
-            dn_n[i] = 1.f;
-          } else {
-            ell_n[i] = l1;
-#pragma unroll
-            for (int q = 0; q < TPW; ++q) { y[q][i] = y1[q][i]; k[0][q][i] = k[6][q][i]; }
-            kl0_n[i] = kl[6][i];
-          }
-          t_n[i] = tn;
-        }
-        dt_n[i] = active ? ndt : dti;
-        na_n[i] = active ? na4[i] + 1.f : na4[i];
-        any |= (dn_n[i] == 0.f && na_n[i] < (float)max_attempts && dt_n[i] > 0.f);
+        const float tn = t0 + dti;
+        const bool fin = acc && tn >= 1.f, adv = acc && !(tn >= 1.f);
+        const float sfrac = (1.f - t0) / (tn - t0);
+        // log-det: 4th-order interpolant of this step evaluated at t = 1 when the step reaches the end
+        const float y0 = ell0, ym = y0 + dti * lm, f0 = dti * kl[0], f1 = dti * kl[6];
+        const float pa = -2.f * f0 + 2.f * f1 - 8.f * y0 - 8.f * l1 + 16.f * ym;
+        const float pb = 5.f * f0 - 3.f * f1 + 18.f * y0 + 14.f * l1 - 32.f * ym;
+        const float pc = -4.f * f0 + f1 - 11.f * y0 - 5.f * l1 + 16.f * ym;
+        const float li = (((pa * sfrac + pb) * sfrac + pc) * sfrac + f0) * sfrac + y0;
+        const float dt_n = active ? ndt : dti, na_n = active ? na + 1.f : na, dn_n = fin ? 1.f : dn;
+        R1(RS_T) = acc ? tn : t0; R1(RS_DT) = dt_n; R1(RS_ELL) = fin ? li : (adv ? l1 : ell0);
+        R1(RS_KL + 0) = adv ? kl[6] : kl[0]; R1(RS_NATT) = na_n; R1(RS_DONE) = dn_n;
+        R1(RS_FLAG) = fin ? 2.f : (adv ? 1.f : 0.f); R1(RS_SFRAC) = sfrac;
+        any = (dn_n == 0.f && na_n < (float)max_attempts && dt_n > 0.f) ? 1 : 0;
       }
-      T.rs_put(RS_T, t_n); T.rs_put(RS_DT, dt_n); T.rs_put(RS_ELL, ell_n); T.rs_put(RS_KL + 0, kl0_n);
-      T.rs_put(RS_NATT, na_n); T.rs_put(RS_DONE, dn_n);
-      if (!__syncthreads_or(any ? 1 : 0)) break;
+      const int go = __syncthreads_or(any);
+      // every lane: apply the decision to its elements (branch-free selects)
+      {
+        const f32x4 fl4 = T.rs_get(RS_FLAG), sf4 = T.rs_get(RS_SFRAC);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float dti = hs[i], sfrac = sf4[i];
+          const bool fin = fl4[i] == 2.f, adv = fl4[i] == 1.f;
+#pragma unroll
+          for (int q = 0; q < TPW; ++q) {
+            float acc = 0.f, km = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * k[j][q][i];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) km += DP_M[j] * k[j][q][i];
+            const float x0 = y[q][i], x1 = x0 + dti * acc, xm = x0 + dti * km, g0 = dti * k[0][q][i], g1 = dti * k[6][q][i];
+            const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
+            const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
+            const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
+            const float xi = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
+            y[q][i] = fin ? xi : (adv ? x1 : x0);
+            k[0][q][i] = adv ? k[6][q][i] : k[0][q][i];
+          }
+        }
+      }
+      if (!go) break;
+      // the next attempt's stage input is built at the top of the loop from the row state the leaders wrote: make sure
+      // every lane has passed the reads above before a leader can overwrite the flags again (next barrier is in tbatch)
       phase = 2;
     }
   }
@@ -587,7 +618,19 @@ __device__ __forceinline__ void tile_init(FTile<D>& T, const NetDev& n, float* l
   T.sign = 1;
   T.ffreq = n.fourier[16 * T.wave + T.c];
   T.coef = n.T.coef; T.tbeta = n.T.tbeta; T.clip = n.grad_clip;
-  for (int i = threadIdx.x; i < S::BIAS; i += NW * 64) lds[i] = 0.f;          // halo pads, row state, scratch
+  {
+    const int r = T.lane & 15, g = T.g, c = T.c, w = T.wave;
+    T.o_rs = 16 * g; T.o_pg = 128 * g; T.o_pp = (32 * g + w) * 4; T.o_bias = (16 * w + c) * 4;
+    T.o_xa = (r * S::LDX + 4 * g + 4) * 4; T.o_xo = (4 * g * S::LDX + 4 + 16 * w + c) * 4;
+    T.o_ha = (S::R + r * S::LDH + 4 * g) * 4; T.o_ha2 = T.o_ha + 64 * S::LDH * 4;
+    T.o_he = (S::R + 4 * g * S::LDH + 16 * w + c) * 4; T.o_he2 = T.o_he + 64 * S::LDH * 4;
+    asm volatile("" : "+v"(T.o_rs), "+v"(T.o_pg), "+v"(T.o_pp), "+v"(T.o_bias), "+v"(T.o_xa));
+    asm volatile("" : "+v"(T.o_xo), "+v"(T.o_ha), "+v"(T.o_ha2), "+v"(T.o_he), "+v"(T.o_he2));
+    T.o_l8 = (T.lane & 15) * 32; T.o_l1 = (T.lane & 15) * 4;
+    asm volatile("" : "+v"(T.o_l8), "+v"(T.o_l1));
+  }
+  for (int i = threadIdx.x; i < S::TOTAL; i += NW * 64)
+    if (i < S::BIAS || i >= S::BIAS + S::BTOT) lds[i] = 0.f;                   // halo pads, row state, scratch
   for (int i = threadIdx.x; i < S::BTOT; i += NW * 64) lds[S::BIAS + i] = n.bias[i];
 #pragma unroll
   for (int i = 0; i < 4; ++i) T.tz1[i] = 0.f;
@@ -601,7 +644,7 @@ __device__ __forceinline__ void fill_probe(FTile<D>& T, const float* z, int b0) 
   for (int q = 0; q < FTile<D>::TPW; ++q) {
     const int col = 16 * (T.wave + NW * q) + T.c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) T.lds[S::ZB + (4 * T.g + i) * S::LDX + 4 + col] = z[(size_t)(b0 + 4 * T.g + i) * D + col];
+    for (int i = 0; i < 4; ++i) *T.at(T.o_xo, S::ZB + i * S::LDX + 128 * q) = z[(size_t)(b0 + 4 * T.g + i) * D + col];
   }
 }
 
@@ -679,9 +722,9 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
       }
       if (f.mode == MFM_FLOW_IMH) {     // ref.logprob(u0) - ref.logprob(up) = -(|u0|^2 - |up|^2) / 2   (:254-255)
         __syncthreads();
-        T.part_put(lds + S::RED + 0 * 128, r0); T.part_put(lds + S::RED + 1 * 128, r1);
+        T.part_put(S::RED + 0 * 128, r0); T.part_put(S::RED + 1 * 128, r1);
         __syncthreads();
-        T.part_get(lds + S::RED + 0 * 128, r0); T.part_get(lds + S::RED + 1 * 128, r1);
+        T.part_get(S::RED + 0 * 128, r0); T.part_get(S::RED + 1 * 128, r1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) lq_ref[i] = -0.5f * (r0[i] - r1[i]);
       }
@@ -698,13 +741,10 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
   }
   // ---- target at the proposal (:270 / :252), tempered: beta * loglik (logprior = 0) ----
   __syncthreads();
-  float* xw = lds + S::XB0;
 #pragma unroll
-  for (int q = 0; q < TPW; ++q) {
-    const int col = 16 * (wave + NW * q) + c;
+  for (int q = 0; q < TPW; ++q)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xw[(4 * g + i) * LDX + 4 + col] = y[q][i];
-  }
+    for (int i = 0; i < 4; ++i) *T.at(T.o_xo, S::XB0 + i * LDX + 128 * q) = y[q][i];
   __syncthreads();
   double lpn[4];
   float gnew[TPW][4];
@@ -715,7 +755,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
       const int col = 16 * (wave + NW * q) + c;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float* xr = xw + (4 * g + i) * LDX + 4;
+        const float* xr = T.at(T.o_xo, S::XB0 + i * LDX + 128 * q) - col;      // row base: xr[col] is this lane's element
         part[i] += phi4_term(a.net.T, xr, col);
         gnew[q][i] = (float)f.beta * phi4_grad(a.net.T, xr, col);
       }
@@ -775,7 +815,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
   if (g_flow_dbg && threadIdx.x == 0) {
     unsigned long long* o = g_flow_dbg + blockIdx.x * 8;
     o[0] = __builtin_amdgcn_s_memtime() - fc0_; o[1] = __builtin_amdgcn_s_memrealtime() - fr0_;
-    o[2] = 0; o[3] = 0;
+    o[2] = T.n_eval; o[3] = T.cyc_eval; o[5] = T.n_tb; o[6] = T.cyc_tb;
   }
 #endif
 }

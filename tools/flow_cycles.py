@@ -40,6 +40,9 @@ for count in range(1, 304):
         print(f"flow step @ {count}: {ms:.1f} ms | natt mean {n.mean():.1f} p50 {np.median(n):.0f} p99 {np.percentile(n,99):.0f} max {n.max():.0f} | tile-max mean {t.max(1).mean():.1f} max {t.max(1).max():.0f}")
         print(f"   per WG: evals mean {nev.mean():.0f} max {nev.max():.0f} | cycles mean {cyc.mean()/1e6:.1f}M max {cyc.max()/1e6:.1f}M | clock {np.median(cyc/rt)*0.1:.3f} GHz "
               f"| cycles/eval in eval {np.median(cev/nev):.0f}, total/eval {np.median(cyc/nev):.0f} -> outside-eval share {1-np.median(cev/cyc):.3f}")
+        if d[:, 5].max() > 0:
+            ntb, ctb = d[:, 5], d[:, 6]
+            print(f"   time batches per WG mean {ntb.mean():.0f}; cycles/batch {np.median(ctb/ntb):.0f}; share of WG cycles: eval {np.median(cev/cyc):.3f} batch {np.median(ctb/cyc):.3f} other {1-np.median((cev+ctb)/cyc):.3f}")
         print(f"   WG time: mean/max {cyc.mean()/cyc.max():.3f}; alg evals (4+6 natt) mean {4+6*n.mean():.0f}; executed/alg {nev.mean()/(4+6*n.mean()):.3f}; max-WG/alg {nev.max()/(4+6*n.mean()):.3f}")
     else:
         ctx.mala_step(kg, 1.0, args.step_size, pos, logp, grad, acc)
