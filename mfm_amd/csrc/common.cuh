@@ -29,5 +29,16 @@ __device__ __forceinline__ float group16_sum(float v) {
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// the same sum by four DPP adds inside the 16-lane row (quad butterflies, then half-row mirror and row mirror once the
+// quads / halves are uniform), ~40 cycles: __shfl_xor lowers to ds_bpermute_b32, i.e. four dependent LDS round trips
+// (~500 cycles, measured in the solver's out-layer epilogue).  The association order of the adds differs from
+// group16_sum, so the two are not bit-identical; used by the shape-specialised solver (ode_fast.hip).
+__device__ __forceinline__ float group16_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
 
 __host__ __device__ __forceinline__ int ceil16(int x) { return (x + 15) & ~15; }

@@ -30,7 +30,9 @@ constexpr int SCR_F4_PER_WG = ODE_FAST_SCR_F4;      // float4 per workgroup: [sl
 template <int D>
 struct FS {                                         // float offsets (LDS, packed weights, biases)
   static constexpr int TPW = D / 128;
-  static constexpr int LDX = D + 8, LDH = H + 4;
+  // leading dimensions = 8 mod 64 dwords: the 16-lane groups of a ds_read_b128 A-fragment read (row = lane & 15, k offset
+  // 4 (lane >> 4)) then touch 64 distinct banks; K + 4 (= 4 mod 64) put two lanes of every group on the same four banks
+  static constexpr int LDX = D + 8, LDH = H + 8;
   // Small, often-addressed structures first: every LDS access below is (one of a handful of per-lane base registers) +
   // a constant that fits the 16-bit DS offset field.  (Constants beyond 64 KB each cost a register, and the compiler
   // hoists all of them out of the solver loop: with the row state at 135 KB that alone spilled ~250 registers.)
@@ -71,27 +73,53 @@ __device__ __forceinline__ void load_group(f32x4 (&bf)[4], __amdgpu_buffer_rsrc_
     bf[j] = NTL == 1 ? bload(r, lane * 16 + j * 1024, soff) : bload(r, lane * 16 + (j >> 1) * 1024, soff + (j & 1) * T1OFF);
 }
 
+#ifndef FAST_DBUF_MAX_MT
+#define FAST_DBUF_MAX_MT 2
+#endif
 template <int MT, int NTL, int LDA>
 __device__ __forceinline__ void exec_group(const float* arow, const f32x4 (&bf)[4], f32x4 (&acc)[NTL][MT]) {
   constexpr int KPG = 4 / NTL;
-  // ONE set of A fragments, refreshed in place: a[m] is reloaded for k-block u + 1 right after its last use in block u
-  // (k-step 3), i.e. MT - 1 MFMAs (>= 128 cycles with the SIMD partner) before block u + 1 needs it.  The scheduling
-  // barriers pin that order: left alone, the scheduler hoists a whole group's reads (MT = 5: 80 registers).
-  f32x4 a[MT];
+  if constexpr (MT <= FAST_DBUF_MAX_MT) {
+    // A fragments one k-block ahead (two register sets, statically renamed by the unroll): the LDS latency of block
+    // u + 1 hides behind the MFMAs of block u
+    f32x4 a[2][MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * LDA);
+    for (int m = 0; m < MT; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * LDA);
 #pragma unroll
-  for (int u = 0; u < KPG; ++u) {
+    for (int u = 0; u < KPG; ++u) {
+      if (u + 1 < KPG) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+        for (int m = 0; m < MT; ++m) a[(u + 1) & 1][m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * LDA + (u + 1) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) acc[t][m] = mfma4(a[m][s], bf[u * NTL + t][s], acc[t][m]);
-        if (s == 3 && u + 1 < KPG) {
-          __builtin_amdgcn_sched_barrier(0);
-          a[m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * LDA + (u + 1) * 16);
-          __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NTL; ++t) acc[t][m] = mfma4(a[u & 1][m][s], bf[u * NTL + t][s], acc[t][m]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // ONE set of A fragments, refreshed in place: a[m] is reloaded for k-block u + 1 right after its last use in block u
+    // (k-step 3), i.e. MT - 1 MFMAs before block u + 1 needs it.  The scheduling barriers pin that order: left alone,
+    // the scheduler hoists a whole group's reads (MT = 5: 80 registers).
+    f32x4 a[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * LDA);
+#pragma unroll
+    for (int u = 0; u < KPG; ++u) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+          for (int t = 0; t < NTL; ++t) acc[t][m] = mfma4(a[m][s], bf[u * NTL + t][s], acc[t][m]);
+          if (s == 3 && u + 1 < KPG) {
+            __builtin_amdgcn_sched_barrier(0);
+            a[m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * LDA + (u + 1) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }
@@ -148,7 +176,10 @@ struct FTile {
   int o_rs, o_pg, o_pp, o_bias, o_xa, o_xo, o_ha, o_ha2, o_he, o_he2, o_l8, o_l1;    // o_l8 / o_l1: row leaders (row = lane)
   __device__ __forceinline__ float* at(int off_bytes, int cfloats) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + off_bytes) + cfloats; }
 #ifdef MFM_STAMPS
-  unsigned long long n_eval = 0, cyc_eval = 0, n_tb = 0, cyc_tb = 0;
+  unsigned long long n_eval = 0, cyc_eval = 0, n_tb = 0, cyc_tb = 0, cyc_sec[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sec_t0 = 0;
+#define FSEC(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cyc_sec[i] += t_ - sec_t0; sec_t0 = t_; } while (0)
+#else
+#define FSEC(i) do {} while (0)
 #endif
 
   __device__ __forceinline__ int W(int off_floats, int nt, int KB, int kb = 0) const { return off_floats * 4 + (nt * KB + kb) * 1024; }   // byte offset of a fragment
@@ -160,7 +191,7 @@ struct FTile {
   // partial sums of this lane's 4 rows over its 16 columns -> LDS [slot][row][wave]; totals after a barrier
   __device__ __forceinline__ void part_put(int base, float (&p)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = group16_sum(p[i]);
+    for (int i = 0; i < 4; ++i) p[i] = group16_sum_dpp(p[i]);
     if (c == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) *at(o_pp, base + i * 8) = p[i];
@@ -192,6 +223,9 @@ struct FTile {
   // barrier has passed since every LDS access of this routine (region R is free for the x branch; a stage input written
   // by the caller BEFORE this call is visible).
   __device__ __forceinline__ void tbatch(int phase, f32x4 (&P)[4], f32x4 (&Q)[4]) {
+#ifdef MFM_STAMPS
+    sec_t0 = __builtin_amdgcn_s_memtime();
+#endif
     {
       float sv[5][4];
       const f32x4 t4 = rs_get(RS_T), h4 = rs_get(phase == 1 ? RS_H0 : RS_DT);
@@ -213,12 +247,15 @@ struct FTile {
         bstore(sr, lane * 16, ((s * NW + wave) * 3 + 0) * 1024, f32x4{sv[s][0], sv[s][1], sv[s][2], sv[s][3]});
       }
     }
+    FSEC(0);
     __syncthreads();
+    FSEC(1);
     f32x4 acc[1][5];
 #pragma unroll
     for (int m = 0; m < 5; ++m) acc[0][m] = f32x4{0, 0, 0, 0};
     const float* afh = at(o_ha, 0);
     run_job<5, 1, 8, LDH, 0, 1, 0>(afh, wr, W(S::W0, wave, 16, 0), W(S::W0, wave, 16, 8), lane, P, Q, acc);      // cos half
+    FSEC(2);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
@@ -227,6 +264,7 @@ struct FTile {
       for (int i = 0; i < 4; ++i) *at(o_he, (s * 16 + i) * LDH) = sn[i];
     }
     __syncthreads();
+    FSEC(3);
     run_job<5, 1, 8, LDH, 0, 1, 0>(afh, wr, W(S::W0, wave, 16, 8), W(S::W1, wave, 8), lane, P, Q, acc);           // sin half
     {
       const float b = bias(S::B0);
@@ -236,6 +274,7 @@ struct FTile {
         for (int i = 0; i < 4; ++i) *at(o_he2, (16 + m * 16 + i) * LDH) = fmaxf(acc[0][m][i] + b, 0.f);
     }
     __syncthreads();
+    FSEC(4);
 #pragma unroll
     for (int m = 0; m < 5; ++m) acc[0][m] = f32x4{0, 0, 0, 0};
     run_job<5, 1, 8, LDH, 0, 1, 0>(at(o_ha2, 16 * LDH), wr, W(S::W1, wave, 8), W(S::W4, wave, 8), lane, P, Q, acc);
@@ -247,6 +286,7 @@ struct FTile {
         for (int i = 0; i < 4; ++i) *at(o_he, (m * 16 + i) * LDH) = fmaxf(acc[0][m][i] + b, 0.f);   // st
     }
     __syncthreads();
+    FSEC(5);
     const float* ast = afh;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {        // gate tiles wave, wave + 8 (D = 256; D = 128: one tile), then the st half of j1
@@ -265,7 +305,9 @@ struct FTile {
 #pragma unroll
       for (int m = 0; m < 5; ++m) bstore(sr, lane * 16, ((m * NW + wave) * 3 + q) * 1024, f32x4{acc[0][m][0] + b, acc[0][m][1] + b, acc[0][m][2] + b, acc[0][m][3] + b});
     }
+    FSEC(6);
     __syncthreads();
+    FSEC(7);
   }
 
   // ---- one field evaluation (x branch) at the stage input in X buffer `cur`, time slot `slot` ----------------------
@@ -273,15 +315,43 @@ struct FTile {
   // elements (row 4g+i, col 16 (wave + 8 q) + c); this wave's divergence partials in DLP[dst]; P = first group of
   // `wnext` (W2: another evaluation follows, W0: a time batch follows).
   __device__ __forceinline__ void eval(int slot, int cur, int dst, bool next_is_tbatch, f32x4 (&P)[4], f32x4 (&Q)[4], float (&kv)[TPW][4]) {
+#ifdef MFM_STAMPS
+    sec_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int xsel = cur ? S::XB1 * 4 : S::XB0 * 4;
     // stage-time inputs of this lane, written by itself in tbatch
     f32x4 gt[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) gt[q] = bload(sr, lane * 16, ((slot * NW + wave) * 3 + q) * 1024);
     const f32x4 j1t = bload(sr, lane * 16, ((slot * NW + wave) * 3 + 2) * 1024);
+    // grad log pi(x) (clipped), the masked Hessian-vector product and z for this lane's out-layer elements.  Pure VALU
+    // + LDS work on inputs known when the evaluation starts: waves 0-3 do it before their x1 job, waves 4-7 after theirs,
+    // so on every SIMD one wave's VALU phase runs beside its partner's MFMAs instead of both stalling the matrix pipe
+    // at the head of the out job.
+    float gc[TPW][4], hz[TPW][4], zz[TPW][4];
+    auto target_terms = [&]() {
+      const float icoef = 1.f / coef;
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float* xr = at(o_xo + xsel, i * LDX + 128 * q);
+          const float* zr = at(o_xo, S::ZB + i * LDX + 128 * q);
+          const float x = xr[0], z = zr[0];
+          const float graw = -tbeta * (coef * (2.f * x - xr[-1] - xr[1]) - x * (1.f - x * x) * icoef);
+          const float hv = -tbeta * (coef * (2.f * z - zr[-1] - zr[1]) - (1.f - 3.f * x * x) * z * icoef);
+          gc[q][i] = clip > 0.f ? fminf(fmaxf(graw, -clip), clip) : graw;
+          hz[q][i] = (!(clip > 0.f) || fabsf(graw) <= clip) ? hv : 0.f;
+          zz[q][i] = z;
+        }
+      }
+    };
+    if (wave < NW / 2) target_terms();
     {   // x1: value rows; tangent rows = relu' * (z W_x1)
       f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
       run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(at(o_xa + xsel, 0), wr, W(S::W2, wave, D / 16), W(S::W3, wave, 8), lane, P, Q, acc);
+      FSEC(8);
+      if (wave >= NW / 2) target_terms();
       const float b = bias(S::B2);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -290,10 +360,13 @@ struct FTile {
         *at(o_he, (16 + i) * LDH) = pre > 0.f ? tz1[i] : 0.f;
       }
     }
+    FSEC(13);
     __syncthreads();
+    FSEC(18);
     {   // x2
       f32x4 acc[1][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}};
       run_job<2, 1, 8, LDH, 0, 1, 0>(at(o_ha, 0), wr, W(S::W3, wave, 8), W(S::W5, wave, 16, 0), lane, P, Q, acc);
+      FSEC(9);
       const float b = bias(S::B3);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -302,10 +375,13 @@ struct FTile {
         *at(o_he, (48 + i) * LDH) = pre > 0.f ? acc[0][1][i] : 0.f;
       }
     }
+    FSEC(14);
     __syncthreads();
+    FSEC(18);
     {   // j1: sx half of the concatenated input (:83); the st half + bias arrive as the initial accumulator
       f32x4 acc[1][2] = {{j1t, {0, 0, 0, 0}}};
       run_job<2, 1, 8, LDH, 0, 1, 0>(at(o_ha, 32 * LDH), wr, W(S::W5, wave, 16, 0), W(S::W6, wave, 8), lane, P, Q, acc);
+      FSEC(10);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float pre = acc[0][0][i];
@@ -313,10 +389,13 @@ struct FTile {
         *at(o_he2, (16 + i) * LDH) = pre > 0.f ? acc[0][1][i] : 0.f;
       }
     }
+    FSEC(15);
     __syncthreads();
+    FSEC(18);
     {   // j2
       f32x4 acc[1][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}};
       run_job<2, 1, 8, LDH, 0, TPW, OUT_T1OFF>(at(o_ha2, 0), wr, W(S::W6, wave, 8), W(S::W7, wave, 8), lane, P, Q, acc);
+      FSEC(11);
       const float b = bias(S::B6);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -325,42 +404,33 @@ struct FTile {
         *at(o_he2, (48 + i) * LDH) = pre > 0.f ? acc[0][1][i] : 0.f;
       }
     }
+    FSEC(16);
     __syncthreads();
+    FSEC(18);
     {   // out: v = nn_xt + nn_t * clip(grad log pi(x)) (:88-90);  J z = d nn_xt . z + nn_t * 1[|g| <= clip] * (H z)
-      float gc[TPW][4], hz[TPW][4];
-#pragma unroll
-      for (int q = 0; q < TPW; ++q) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float* xr = at(o_xo + xsel, i * LDX + 128 * q);
-          const float* zr = at(o_xo, S::ZB + i * LDX + 128 * q);
-          const float x = xr[0], z = zr[0];
-          const float graw = -tbeta * (coef * (2.f * x - xr[-1] - xr[1]) - x * (1.f - x * x) / coef);
-          const float hv = -tbeta * (coef * (2.f * z - zr[-1] - zr[1]) - (1.f - 3.f * x * x) * z / coef);
-          gc[q][i] = clip > 0.f ? fminf(fmaxf(graw, -clip), clip) : graw;
-          hz[q][i] = (!(clip > 0.f) || fabsf(graw) <= clip) ? hv : 0.f;
-        }
-      }
+      float bo[TPW];
       f32x4 acc[TPW][2];
 #pragma unroll
-      for (int q = 0; q < TPW; ++q) { acc[q][0] = f32x4{0, 0, 0, 0}; acc[q][1] = f32x4{0, 0, 0, 0}; }
+      for (int q = 0; q < TPW; ++q) { acc[q][0] = f32x4{0, 0, 0, 0}; acc[q][1] = f32x4{0, 0, 0, 0}; bo[q] = bias(S::B7 + 128 * q); }
       const int wnext = next_is_tbatch ? W(S::W0, wave, 16) : W(S::W2, wave, D / 16);
       run_job<2, TPW, 8, LDH, OUT_T1OFF, 1, 0>(at(o_ha2, 32 * LDH), wr, W(S::W7, wave, 8), wnext, lane, P, Q, acc);
+      FSEC(12);
       float dp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
-        const float b = bias(S::B7 + 128 * q);
+        const float b = bo[q];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float v = acc[q][0][i] + b + gt[q][i] * gc[q][i];
           const float jz = acc[q][1][i] + gt[q][i] * hz[q][i];
-          dp[i] += *at(o_xo, S::ZB + i * LDX + 128 * q) * jz;
+          dp[i] += zz[q][i] * jz;
           kv[q][i] = sign > 0 ? v : -v;
         }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) dp[i] = sign > 0 ? -dp[i] : dp[i];          // :218 / :239
       part_put(S::DLP + dst * 128, dp);
+      FSEC(17);
     }
   }
 };
@@ -812,10 +882,11 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
     }
   }
 #ifdef MFM_STAMPS
-  if (g_flow_dbg && threadIdx.x == 0) {
-    unsigned long long* o = g_flow_dbg + blockIdx.x * 8;
+  if (g_flow_dbg && (threadIdx.x == 0 || threadIdx.x == 256)) {
+    unsigned long long* o = g_flow_dbg + (blockIdx.x + (threadIdx.x ? gridDim.x : 0)) * 32;
     o[0] = __builtin_amdgcn_s_memtime() - fc0_; o[1] = __builtin_amdgcn_s_memrealtime() - fr0_;
     o[2] = T.n_eval; o[3] = T.cyc_eval; o[5] = T.n_tb; o[6] = T.cyc_tb;
+    for (int i = 0; i < 20; ++i) o[8 + i] = T.cyc_sec[i];
   }
 #endif
 }

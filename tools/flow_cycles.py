@@ -20,7 +20,7 @@ eng = Engine(dist, args, fourier)
 model = E.VectorFieldNet(fourier, dist.grad_logprob, args.hidden_x, args.hidden_t, args.hidden_xt).attach(eng)
 eng.ctx.set_params(E.flatten_params(model.init(k[2])))
 ctx = eng.ctx
-dbg = torch.zeros(B // 16 * 8, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(2 * B // 16 * 32, dtype=torch.int64, device="cuda")
 fn = ctx.lib.mfm_debug_flow_buffer; fn.restype = C.c_int; fn.argtypes = [C.c_void_p]
 assert fn(dbg.data_ptr()) == 0
 pos = eng.local(dist.init_params); logp = torch.empty(B, device="cuda", dtype=torch.float64); grad = torch.empty_like(pos)
@@ -34,7 +34,8 @@ for count in range(1, 304):
         e0.record(); ctx.flow_step(FLOW_RWMH, kg, 1.0, pos, logp, grad, acc, None, None, nst); e1.record()
         torch.cuda.synchronize()
         n = nst.cpu().numpy().astype(float); t = n.reshape(-1, 16)
-        d = dbg.cpu().numpy().reshape(-1, 8).astype(float)
+        dall = dbg.cpu().numpy().reshape(2, -1, 32).astype(float)
+        d = dall[0]
         cyc, rt, nev, cev = d[:, 0], d[:, 1], d[:, 2], d[:, 3]
         ms = e0.elapsed_time(e1)
         print(f"flow step @ {count}: {ms:.1f} ms | natt mean {n.mean():.1f} p50 {np.median(n):.0f} p99 {np.percentile(n,99):.0f} max {n.max():.0f} | tile-max mean {t.max(1).mean():.1f} max {t.max(1).max():.0f}")
@@ -43,6 +44,16 @@ for count in range(1, 304):
         if d[:, 5].max() > 0:
             ntb, ctb = d[:, 5], d[:, 6]
             print(f"   time batches per WG mean {ntb.mean():.0f}; cycles/batch {np.median(ctb/ntb):.0f}; share of WG cycles: eval {np.median(cev/cyc):.3f} batch {np.median(ctb/cyc):.3f} other {1-np.median((cev+ctb)/cyc):.3f}")
+        if d[:, 16:28].max() > 0:
+            print("   eval sections, cycles per eval: jobs x1,x2,j1,j2,out:", (np.median(d[:, 16:21] / d[:, 2:3], axis=0)).astype(int), " epilogue before barrier 1..4:", (np.median(d[:, 21:25] / d[:, 2:3], axis=0)).astype(int), " out epilogue:", int(np.median(d[:, 25] / d[:, 2])), " 4 barriers:", int(np.median(d[:, 26] / d[:, 2])))
+        if d[:, 8:16].max() > 0:
+            print("   time-batch sections, cycles per batch (sincos, bar, cos job, bar+sin write+bar, sin job+epi, bar+t2+epi, bar+gate/j1t, bar):", (np.median(d[:, 8:16] / d[:, 5:6], axis=0)).astype(int))
+        if d[:, 16:28].max() > 0:
+            print("   eval sections, cycles per eval: jobs x1,x2,j1,j2,out:", (np.median(d[:, 16:21] / d[:, 2:3], axis=0)).astype(int), " epilogue before barrier 1..4:", (np.median(d[:, 21:25] / d[:, 2:3], axis=0)).astype(int), " out epilogue:", int(np.median(d[:, 25] / d[:, 2])), " 4 barriers:", int(np.median(d[:, 26] / d[:, 2])))
+        d4 = dall[1]
+        if d4[:, 16:28].max() > 0:
+            print("   WAVE 4 eval sections: jobs x1,x2,j1,j2,out:", (np.median(d4[:, 16:21] / d4[:, 2:3], axis=0)).astype(int), " epilogue before barrier 1..4:", (np.median(d4[:, 21:25] / d4[:, 2:3], axis=0)).astype(int), " out epilogue:", int(np.median(d4[:, 25] / d4[:, 2])), " 4 barriers:", int(np.median(d4[:, 26] / d4[:, 2])), "eval total", int(np.median(d4[:, 3] / d4[:, 2])))
+            print("   WAVE 4 time-batch sections:", (np.median(d4[:, 8:16] / d4[:, 5:6], axis=0)).astype(int))
         print(f"   WG time: mean/max {cyc.mean()/cyc.max():.3f}; alg evals (4+6 natt) mean {4+6*n.mean():.0f}; executed/alg {nev.mean()/(4+6*n.mean()):.3f}; max-WG/alg {nev.max()/(4+6*n.mean()):.3f}")
     else:
         ctx.mala_step(kg, 1.0, args.step_size, pos, logp, grad, acc)

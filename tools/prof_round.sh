@@ -1,0 +1,33 @@
+#!/bin/bash
+# rocprofv3 evidence for profiles/: kernel trace + stats of the bench command, then PMC passes (separate runs, no trace
+# domains besides --kernel-trace).  usage (on the GPU box): tools/prof_round.sh TAG
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+TAG=${1:-r01}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 202 --warmup 101 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+echo "trace done"; head -5 $OUT/kernel_stats.csv | cut -c1-150
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE FETCH_SIZE" \
+           "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 101 --warmup 0 --no-cpu-baseline > $OUT/p$i.json 2> $OUT/p$i.err
+  echo "pmc pass $i done"
+done
+python3 - $OUT <<'PY'
+import csv, sys, glob, json, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(out + "/p*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:60]
+        if k.startswith("void at::") or k.startswith("__amd"): continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
+res = {k: {c: {"mean_per_launch": v / n[k][c], "launches": n[k][c]} for c, v in cs.items()} for k, cs in acc.items()}
+json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1)
+for k, cs in res.items():
+    if "flow_step" in k or "fm_fwd" in k: print(k, {c: "%.4g" % v["mean_per_launch"] for c, v in cs.items()})
+PY
