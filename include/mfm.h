@@ -126,6 +126,12 @@ int mfm_beta_update(mfm_ctx* ctx, double prev_beta, const double* d_logliks, int
 
 /* ---- measurement (bench.py): HIP-event timing of the kernels, recorded on the context's stream ------------------- */
 /* class ids: 0 mala_step, 1 fm_fwd_bwd, 2 wgrad, 3 adamw (4 small kernels), 4 flow_step, 5 fm eval, 6 reductions */
+/* ---- sample-quality metrics: mcmc_utils.py:28-85 (stein_disc) and :88-111 (max_mean_disc), called at
+ *      exe_flow_matching.py:469-487.  d_grad = grad log p of the UNTEMPERED target at d_x (mfm_mala_init at beta = 1
+ *      returns it).  beta is the reference's argument (default -1/2).  Synchronise; results on the host. ---- */
+int mfm_stein_disc(mfm_ctx* ctx, const float* d_x, const float* d_grad, int n, double beta, double h_u_v[2]);
+int mfm_max_mean_disc(mfm_ctx* ctx, const float* d_x, const float* d_y, int m, double* h_out);
+
 int mfm_profile(mfm_ctx* ctx, int enable);                      /* enable resets the record */
 int mfm_profile_read(mfm_ctx* ctx, double ms_total[8], int64_t launches[8]);   /* synchronises */
 

@@ -58,6 +58,8 @@ _SIGS = {
     "mfm_ode_transform": (C.c_int, [_P, C.c_int, C.c_int, _P, _U32, _U32, _P, C.c_int, _P, _P, _P]),
     "mfm_flow_step": (C.c_int, [_P, C.c_int, _U32, _U32, C.c_double, _P, _P, _P, _P, _P, _P, _P]),
     "mfm_beta_update": (C.c_int, [_P, C.c_double, _P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    "mfm_stein_disc": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    "mfm_max_mean_disc": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_double)]),
     "mfm_profile": (C.c_int, [_P, C.c_int]),
     "mfm_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mfm_pack_index": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -221,6 +223,20 @@ class Context:
         ms, cnt = (C.c_double * 8)(), (C.c_int64 * 8)()
         _chk(self.lib.mfm_profile_read(self.h, ms, cnt))
         return {n: dict(ms=ms[i], launches=cnt[i]) for i, n in enumerate(self.PROF_CLASSES) if cnt[i]}
+
+    def stein_disc(self, x, grad, beta=-0.5):
+        """(U, V) statistics of ``mcmc_utils.py:28-85`` for CUDA samples x [n, d] and grad log p at x."""
+        out = (C.c_double * 2)()
+        _chk(self.lib.mfm_stein_disc(self.h, _ptr(x, F32), _ptr(grad, F32), x.shape[0], float(beta), out))
+        return out[0], out[1]
+
+    def max_mean_disc(self, x, y):
+        """``mcmc_utils.py:88-111`` for CUDA sample sets x, y [m, d]."""
+        if x.shape != y.shape:
+            raise ValueError("max_mean_disc: both sample sets must have the same shape (the reference uses m = X.shape[0] for both)")
+        out = C.c_double()
+        _chk(self.lib.mfm_max_mean_disc(self.h, _ptr(x, F32), _ptr(y, F32), x.shape[0], C.byref(out)))
+        return out.value
 
     def beta_update(self, prev_beta, logliks, alpha):
         out = C.c_double()

@@ -14,6 +14,7 @@
 #include "optim.hip"
 #include "ode.hip"
 #include "anneal.hip"
+#include "metrics.hip"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -487,6 +488,43 @@ extern "C" int mfm_beta_update(mfm_ctx* x, double prev_beta, const double* d_ll,
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(h_out, x->beta_out, sizeof(double), hipMemcpyDeviceToHost, x->stream));
   HIPCHK(hipStreamSynchronize(x->stream));
+  return MFM_OK;
+}
+
+// ---- sample-quality metrics (mcmc_utils.py:28-111) ----------------------------------------------------------------
+static int pair_call(mfm_ctx* x, int mode, const float* A, const float* GA, const float* B, const float* GB, int na, int nb, float beta, double h[2]) {
+  double* ws = nullptr;
+  const size_t parts = pair_sum_parts(na, nb);
+  HIPCHK(hipMalloc((void**)&ws, (2 * parts + 2) * sizeof(double)));
+  launch_pair_sum(mode, A, GA, B, GB, na, nb, x->cfg.dim, beta, ws + 2, ws, x->stream);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(h, ws, 2 * sizeof(double), hipMemcpyDeviceToHost, x->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+  (void)hipFree(ws);
+  if (e != hipSuccess) return fail(MFM_EHIP, "pair-sum kernel: %s", hipGetErrorString(e));
+  return MFM_OK;
+}
+
+extern "C" int mfm_stein_disc(mfm_ctx* x, const float* d_x, const float* d_grad, int n, double beta, double h_out[2]) {
+  if (!x || !d_x || !d_grad || !h_out) return fail(MFM_EINVAL, "null argument");
+  if (n < 2) return fail(MFM_EINVAL, "stein_disc needs at least 2 samples");
+  double h[2];
+  int rc = pair_call(x, 0, d_x, d_grad, d_x, d_grad, n, n, (float)(-beta), h);      /* mcmc_utils.py:54: beta = -beta */
+  if (rc) return rc;
+  h_out[0] = (h[0] - h[1]) / ((double)n * (double)(n - 1));                         /* :85 U-statistic */
+  h_out[1] = h[0] / ((double)n * (double)n);                                        /*     V-statistic */
+  return MFM_OK;
+}
+
+extern "C" int mfm_max_mean_disc(mfm_ctx* x, const float* d_x, const float* d_y, int m, double* h_out) {
+  if (!x || !d_x || !d_y || !h_out) return fail(MFM_EINVAL, "null argument");
+  if (m < 2) return fail(MFM_EINVAL, "max_mean_disc needs at least 2 samples");
+  double xx[2], yy[2], xy[2];
+  int rc = pair_call(x, 1, d_x, nullptr, d_x, nullptr, m, m, 0.f, xx); if (rc) return rc;
+  rc = pair_call(x, 1, d_y, nullptr, d_y, nullptr, m, m, 0.f, yy); if (rc) return rc;
+  rc = pair_call(x, 1, d_x, nullptr, d_y, nullptr, m, m, 0.f, xy); if (rc) return rc;
+  const double m2 = (double)m * (double)m;
+  *h_out = (xx[0] - m) / (m2 - m) - 2.0 * xy[0] / m2 + (yy[0] - m) / (m2 - m);      /* mcmc_utils.py:106-110 */
   return MFM_OK;
 }
 

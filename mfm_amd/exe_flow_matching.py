@@ -285,12 +285,22 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     idx = torch.searchsorted(p_cuml, r).clamp_max(flow_samples.shape[0] - 1)
     exact_samples = flow_samples[idx]                                                       # :459
     logpdf = samples_logdensity.mean().item()                                               # :469
-    logpdf_ = _logprob_any(eng, exact_samples).mean().item()                                # :473
     logger.info(f"Logpdf of flow samples= {logpdf}")
+    stein = stein_disc(eng, flow_samples)                                                   # :471 (mcmc_utils.py:28-85)
+    logger.info(f"Stein U, V disc of flow samples= {stein[0]}, {stein[1]}")
+    logpdf_ = _logprob_any(eng, exact_samples).mean().item()                                # :473
     logger.info(f"Logpdf of exact samples= {logpdf_}")
-    nan = float("nan")      # KSD / MMD (mcmc_utils.py:28-111): SURVEY.md section 8f row N2, not built yet
-    res = np.array([logpdf, nan, nan, nan if target_gn is not None else 0.0, train_time])
-    res_ = np.array([logpdf_, nan, nan, nan if target_gn is not None else 0.0, train_time])
+    stein_ = stein_disc(eng, exact_samples)                                                 # :475
+    logger.info(f"Stein U, V disc of exact samples= {stein_[0]}, {stein_[1]}")
+    if target_gn is not None and eng.world == 1:                                            # :480-487 (mcmc_utils.py:88-111)
+        mmd = eng.ctx.max_mean_disc(real_samples, flow_samples)
+        logger.info(f"Max mean disc of flow samples= {mmd}")
+        mmd_ = eng.ctx.max_mean_disc(real_samples, exact_samples)
+        logger.info(f"Max mean disc of exact samples= {mmd_}")
+    else:
+        mmd = mmd_ = 0.0                                                                    # :490
+    res = np.array([logpdf, stein[0], stein[1], mmd, train_time])                           # :561
+    res_ = np.array([logpdf_, stein_[0], stein_[1], mmd_, train_time])
     wandb.finish()
     if return_extras:
         return res, res_, dict(metrics=metrics.cpu().numpy(), betas=np.array(betas), lrs=np.array(lrs), states=train_states,
@@ -299,11 +309,23 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     return res, res_
 
 
-def _logprob_any(eng, x):
+def stein_disc(eng, x, beta=-0.5):
+    """``mcmc_utils.stein_disc(X, dist.logprob)`` (mcmc_utils.py:28-85) for CUDA samples [n, d] -> (U, V)."""
+    _, grad = _logprob_any(eng, x, want_grad=True)
+    return eng.ctx.stein_disc(x.contiguous(), grad, beta)
+
+
+def max_mean_disc(eng, x, y):
+    """``mcmc_utils.max_mean_disc`` (mcmc_utils.py:88-111) for CUDA sample sets of equal size."""
+    return eng.ctx.max_mean_disc(x.contiguous(), y.contiguous())
+
+
+def _logprob_any(eng, x, want_grad=False):
     """vmap(dist.logprob) for any sample count: the MALA init kernel at beta = 1 returns loglik + logprior for every
     built target; samples are processed in chunks of the engine's chain count (zero padded)."""
     t = eng.torch
     out = t.empty(x.shape[0], device=eng.dev, dtype=t.float64)
+    gout = t.empty(x.shape[0], x.shape[1], device=eng.dev, dtype=t.float32) if want_grad else None
     n = eng.n_local
     lp = t.empty(n, device=eng.dev, dtype=t.float64)
     gr = t.empty(n, x.shape[1], device=eng.dev, dtype=t.float32)
@@ -315,4 +337,6 @@ def _logprob_any(eng, x):
             chunk = pad
         eng.ctx.mala_init(chunk.contiguous(), 1.0, lp, gr)
         out[s:s + m] = lp[:m]
-    return out
+        if want_grad:
+            gout[s:s + m] = gr[:m]
+    return (out, gout) if want_grad else out
