@@ -126,6 +126,20 @@ int mfm_beta_update(mfm_ctx* ctx, double prev_beta, const double* d_logliks, int
 
 /* ---- measurement (bench.py): HIP-event timing of the kernels, recorded on the context's stream ------------------- */
 /* class ids: 0 mala_step, 1 fm_fwd_bwd, 2 wgrad, 3 adamw (4 small kernels), 4 flow_step, 5 fm eval, 6 reductions */
+/* ---- rows of the flow's reference distribution: out[i] = normal(keys[i], (dim,))  (distributions.py:93-97 vmapped at
+ *      exe_flow_matching.py:285, :389, :453).  d_keys: uint32 [n][2]. ---- */
+int mfm_normal_rows(mfm_ctx* ctx, const uint32_t* d_keys, int n, float* d_out);
+
+/* ---- selection step of conditional importance sampling (exe_flow_matching.py:280-296, chosen when
+ *      num_importance_samples > 0): given, per chain b, the pull-back of the current position (u0, vol0 from
+ *      mfm_ode_transform direction -1 with key split(keys[b],4)[1]) and n_is flow samples (refs = normal rows of
+ *      split(split(keys[b],4)[0], n_is), xs / vols = mfm_ode_transform of them with keys split(split(keys[b],4)[2], n_is),
+ *      lps = tempered target log-density of xs; sample (b, j) at row b * n_is + j), draw the categorical choice with
+ *      split(keys[b],4)[3] and update position / logdensity in place (the gradient is left as is, :295). ---- */
+int mfm_cis_select(mfm_ctx* ctx, uint32_t key0, uint32_t key1, int n_is, const float* d_u0, const float* d_vol0,
+                   const float* d_refs, const float* d_xs, const float* d_vols, const double* d_lps, float* d_pos,
+                   double* d_logp, float* d_acc_prob, uint8_t* d_is_accepted, float* d_proposed, float* d_weight);
+
 /* ---- sample-quality metrics: mcmc_utils.py:28-85 (stein_disc) and :88-111 (max_mean_disc), called at
  *      exe_flow_matching.py:469-487.  d_grad = grad log p of the UNTEMPERED target at d_x (mfm_mala_init at beta = 1
  *      returns it).  beta is the reference's argument (default -1/2).  Synchronise; results on the host. ---- */

@@ -58,6 +58,8 @@ _SIGS = {
     "mfm_ode_transform": (C.c_int, [_P, C.c_int, C.c_int, _P, _U32, _U32, _P, C.c_int, _P, _P, _P]),
     "mfm_flow_step": (C.c_int, [_P, C.c_int, _U32, _U32, C.c_double, _P, _P, _P, _P, _P, _P, _P]),
     "mfm_beta_update": (C.c_int, [_P, C.c_double, _P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    "mfm_normal_rows": (C.c_int, [_P, _P, C.c_int, _P]),
+    "mfm_cis_select": (C.c_int, [_P, _U32, _U32, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfm_stein_disc": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     "mfm_max_mean_disc": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_double)]),
     "mfm_profile": (C.c_int, [_P, C.c_int]),
@@ -223,6 +225,15 @@ class Context:
         ms, cnt = (C.c_double * 8)(), (C.c_int64 * 8)()
         _chk(self.lib.mfm_profile_read(self.h, ms, cnt))
         return {n: dict(ms=ms[i], launches=cnt[i]) for i, n in enumerate(self.PROF_CLASSES) if cnt[i]}
+
+    def normal_rows(self, keys, out):
+        """out[i] = normal(keys[i], (dim,)); keys: int32 CUDA tensor [n, 2] holding uint32 bit patterns."""
+        _chk(self.lib.mfm_normal_rows(self.h, _ptr(keys, I32), out.shape[0], _ptr(out, F32)))
+
+    def cis_select(self, key, n_is, u0, vol0, refs, xs, vols, lps, pos, logp, acc=None, is_acc=None, proposed=None, weight=None):
+        _chk(self.lib.mfm_cis_select(self.h, int(key[0]), int(key[1]), int(n_is), _ptr(u0, F32), _ptr(vol0, F32), _ptr(refs, F32),
+                                     _ptr(xs, F32), _ptr(vols, F32), _ptr(lps, F64), _ptr(pos, F32), _ptr(logp, F64), _ptr(acc, F32),
+                                     _ptr(is_acc, U8), _ptr(proposed, F32), _ptr(weight, F32)))
 
     def stein_disc(self, x, grad, beta=-0.5):
         """(U, V) statistics of ``mcmc_utils.py:28-85`` for CUDA samples x [n, d] and grad log p at x."""

@@ -15,6 +15,7 @@
 #include "ode.hip"
 #include "anneal.hip"
 #include "metrics.hip"
+#include "cis.hip"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -488,6 +489,31 @@ extern "C" int mfm_beta_update(mfm_ctx* x, double prev_beta, const double* d_ll,
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(h_out, x->beta_out, sizeof(double), hipMemcpyDeviceToHost, x->stream));
   HIPCHK(hipStreamSynchronize(x->stream));
+  return MFM_OK;
+}
+
+// ---- reference-distribution rows and the CIS selection step ---------------------------------------------------------
+extern "C" int mfm_normal_rows(mfm_ctx* x, const uint32_t* d_keys, int n, float* d_out) {
+  if (!x || !d_keys || !d_out) return fail(MFM_EINVAL, "null argument");
+  if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
+  launch_probe(0, d_keys, Key2{0, 0}, 0, 0, 0, n, x->cfg.dim, d_out, x->stream);
+  LAUNCHCHK();
+  return MFM_OK;
+}
+
+extern "C" int mfm_cis_select(mfm_ctx* x, uint32_t k0, uint32_t k1, int n_is, const float* d_u0, const float* d_vol0, const float* d_refs,
+                              const float* d_xs, const float* d_vols, const double* d_lps, float* d_pos, double* d_logp, float* d_acc,
+                              uint8_t* d_isacc, float* d_prop, float* d_weight) {
+  if (!x || !d_u0 || !d_vol0 || !d_refs || !d_xs || !d_vols || !d_lps || !d_pos || !d_logp) return fail(MFM_EINVAL, "null argument");
+  if (n_is <= 0) return fail(MFM_EINVAL, "num_importance_samples must be positive");
+  CisArgs a; memset(&a, 0, sizeof a);
+  a.key = Key2{k0, k1}; a.n_total = x->cfg.n_chain_total; a.chain_offset = x->cfg.chain_offset;
+  a.B = x->cfg.n_chain_local; a.d = x->cfg.dim; a.n_is = n_is;
+  a.u0 = d_u0; a.vol0 = d_vol0; a.refs = d_refs; a.xs = d_xs; a.vols = d_vols; a.lps = d_lps;
+  a.pos = d_pos; a.logp = d_logp; a.acc_prob = d_acc; a.accepted = d_isacc; a.proposed = d_prop; a.weight = d_weight;
+  ProfScope ps_(x, PROF_FLOW);
+  launch_cis_select(a, x->stream);
+  LAUNCHCHK();
   return MFM_OK;
 }
 

@@ -161,9 +161,8 @@ def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
     model = vector_field_apply.__self__
     eng = model.engine
     t = eng.torch
-    if args.num_importance_samples > 0:
-        raise NotImplementedError("conditional importance sampling (:280-296): SURVEY.md section 8f row N3")
-    mode = FLOW_IMH if args.num_importance_samples < 0 else FLOW_RWMH                      # :298
+    n_is = int(args.num_importance_samples)
+    mode = FLOW_IMH if n_is < 0 else FLOW_RWMH                                             # :298
     n, d = eng.n_local, eng.dim
     info = dict(acc=t.empty(n, device=eng.dev, dtype=t.float32), isacc=t.empty(n, device=eng.dev, dtype=t.uint8),
                 prop=t.empty(n, d, device=eng.dev, dtype=t.float32), w=t.zeros(n, device=eng.dev, dtype=t.float32),
@@ -177,6 +176,25 @@ def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
         eng.ctx.ode_transform(1, ref_sample, out, ldj, key=key)
         return out, ldj
 
+    def _keys_dev(k):
+        return t.as_tensor(np.ascontiguousarray(k, dtype=np.uint32).view(np.int32), device=eng.dev)
+
+    def conditional_importance_sampling(rng_key, beta, pos, logp):
+        """:280-296.  The solves and target evaluations are the kernels the other flow steps use; the per-chain
+        weights, the categorical draw and the state update run in ``mfm_cis_select``."""
+        keys = jr.split(rng_key, eng.n_total)[eng.offset:eng.offset + n]                   # :303
+        kk = jr.split_rows(keys, 4)                                                        # :281
+        u0 = t.empty_like(pos); vol0 = t.empty(n, device=eng.dev, dtype=t.float32)
+        eng.ctx.ode_transform(-1, pos, u0, vol0, keys=_keys_dev(kk[:, 1]))                  # :282
+        ks = jr.split_rows(kk[:, 0], n_is).reshape(n * n_is, 2)                            # :284
+        kh = jr.split_rows(kk[:, 2], n_is).reshape(n * n_is, 2)                            # :286
+        refs = t.empty(n * n_is, d, device=eng.dev, dtype=t.float32)
+        eng.ctx.normal_rows(_keys_dev(ks), refs)                                           # :285
+        xs = t.empty_like(refs); vols = t.empty(n * n_is, device=eng.dev, dtype=t.float32)
+        eng.ctx.ode_transform(1, refs, xs, vols, keys=_keys_dev(kh))                        # :287
+        lps = _logprob_any(eng, xs, beta=beta)                                             # :288
+        eng.ctx.cis_select(rng_key, n_is, u0, vol0, refs, xs, vols, lps, pos, logp, info["acc"], info["isacc"], info["prop"], info["w"])
+
     def train_data_generator(rng_key, states, count, vector_field_param=None, beta=1.0):
         """:300-314.  States are updated IN PLACE (and returned); infos are views of reused device buffers."""
         _maybe_upload(eng, vector_field_param)
@@ -186,7 +204,9 @@ def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
         else:
             do_flow = count % (int(K) + 1) == 0                                            # :311
         pos, logp, grad = states
-        if do_flow:
+        if do_flow and n_is > 0:
+            conditional_importance_sampling(rng_key, beta, pos, logp)
+        elif do_flow:
             eng.ctx.flow_step(mode, rng_key, beta, pos, logp, grad, info["acc"], info["isacc"], info["prop"], info["nsteps"])
         else:
             eng.ctx.mala_step(rng_key, beta, args.step_size, pos, logp, grad, info["acc"], info["isacc"], info["prop"], info["w"])
@@ -210,8 +230,8 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     import torch
     logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", datefmt="%m/%d/%Y %H:%M:%S", level=logging.INFO)
     use_real_samples = args.mcmc_per_flow_steps < 0                                        # :328
-    if use_real_samples:
-        raise NotImplementedError("training on exact samples (mcmc_per_flow_steps < 0): SURVEY.md section 8f row N3")
+    if use_real_samples and target_gn is None:
+        raise ValueError("mcmc_per_flow_steps < 0 trains on exact samples and needs a target with sample_model (:382-386)")
     learning_iter = args.learning_iter
     iter_per_temp = args.anneal_iter // args.num_anneal_temp                                # :330
     n_iter, n_chain = args.eval_iter, args.num_chain
@@ -221,7 +241,7 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     model = VectorFieldNet(fourier_random, dist.grad_logprob, args.hidden_x, args.hidden_t, args.hidden_xt,
                            non_lins[args.non_linearity], args.gradient_clip if args.dim > 128 else None)     # :351
     n_eval = n_iter * n_chain if target_gn is not None else 0
-    eng = Engine(dist, args, fourier_random, max_eval_samples=max(n_eval, n_iter * n_chain))
+    eng = Engine(dist, args, fourier_random, max_eval_samples=max(n_eval, n_iter * n_chain, n_chain * max(int(args.num_importance_samples), 0)))
     model.attach(eng)
     vector_field_param = model.init(key_init, dist.init_params[0], 0.0)                     # :353
     learning_rate_fn = create_learning_rate_fn(learning_iter, args.warmup_steps, args.learning_rate)          # :355-359
@@ -241,8 +261,18 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     train_start = time.time()                                                               # :421
 
     pos0 = eng.local(dist.init_params)
-    beta = eng.ctx.beta_update(0.0, eng.all_logliks(pos0), args.alpha)                      # :426
-    logger.info(f"Initial beta= {beta}")
+    if use_real_samples:                                                                    # :382-386, :429-430
+        def train_data_generator(key, states, count, *_):
+            """positions = vmap(target_gn)(split(key, n_chain)); no MCMC state, acceptance is NaN."""
+            rows = dist.sample_rows(jr.split(key, n_chain))[eng.offset:eng.offset + eng.n_local]
+            states.position.copy_(torch.as_tensor(np.ascontiguousarray(rows, dtype=np.float32), device=eng.dev))
+            return states, MALAInfo(nan_acc, None, None, None)
+        nan_acc = torch.full((eng.n_local,), float("nan"), device=eng.dev, dtype=torch.float32)
+        init_fn = lambda positions, *_: MALAState(positions, None, None)
+        beta = 1.0
+    else:
+        beta = eng.ctx.beta_update(0.0, eng.all_logliks(pos0), args.alpha)                  # :426
+        logger.info(f"Initial beta= {beta}")
     train_states = init_fn(pos0, beta)                                                      # :431
     metrics = torch.zeros(learning_iter, 4, device=eng.dev, dtype=torch.float64)            # loss, acc mean, acc std, target loss
     betas, lrs = [], []
@@ -251,7 +281,7 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
         train_states, infos = train_data_generator(key_train_gn, train_states, count, state.params, beta)    # :438
         loss = eng.train_step(key_train_step, train_states.position)                        # :439 (:362-368)
         lrs.append(learning_rate_fn(count - 1))                                             # :367 (pre-increment step)
-        if count % iter_per_temp == 0 and beta < 1.0:                                       # :440-441, :417
+        if not use_real_samples and count % iter_per_temp == 0 and beta < 1.0:              # :440-441, :417
             beta = eng.ctx.beta_update(beta, eng.all_logliks(train_states.position), args.alpha)              # :413
             train_states = init_fn(train_states.position, beta)                             # :415
         m, s = eng.mean_std(infos.acceptance_rate)                                          # :442-443
@@ -320,7 +350,7 @@ def max_mean_disc(eng, x, y):
     return eng.ctx.max_mean_disc(x.contiguous(), y.contiguous())
 
 
-def _logprob_any(eng, x, want_grad=False):
+def _logprob_any(eng, x, want_grad=False, beta=1.0):
     """vmap(dist.logprob) for any sample count: the MALA init kernel at beta = 1 returns loglik + logprior for every
     built target; samples are processed in chunks of the engine's chain count (zero padded)."""
     t = eng.torch
@@ -335,7 +365,7 @@ def _logprob_any(eng, x, want_grad=False):
         if m < n:
             pad = t.zeros(n, x.shape[1], device=eng.dev, dtype=x.dtype); pad[:m] = chunk
             chunk = pad
-        eng.ctx.mala_init(chunk.contiguous(), 1.0, lp, gr)
+        eng.ctx.mala_init(chunk.contiguous(), float(beta), lp, gr)
         out[s:s + m] = lp[:m]
         if want_grad:
             gout[s:s + m] = gr[:m]

@@ -42,6 +42,15 @@ def split(key, num=2):
     return np.concatenate([y0, y1]).reshape(num, 2)
 
 
+def split_rows(keys, num):
+    """vmap(lambda k: split(k, num))(keys): keys [n, 2] -> [n, num, 2]."""
+    keys = np.atleast_2d(np.asarray(keys, U32))
+    cnt = np.arange(2 * num, dtype=U32)[None, :]
+    y0, y1 = _threefry(keys[:, 0:1], keys[:, 1:2], np.broadcast_to(cnt[:, :num], (keys.shape[0], num)),
+                       np.broadcast_to(cnt[:, num:], (keys.shape[0], num)))
+    return np.concatenate([y0, y1], axis=1).reshape(keys.shape[0], num, 2)
+
+
 def _bits64(keys, size):
     """keys [n, 2] -> [n, size] uint64 (one independent draw of `size` samples per key)."""
     keys = np.atleast_2d(np.asarray(keys, U32))

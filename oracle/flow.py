@@ -62,6 +62,39 @@ def imh_step(keys, prev, value_and_grad, model, params, args, stats=None):
     return _accept(kk[:, 1], a, prev, (xp, lpn, gn))
 
 
+def cis_step(keys, prev, value_and_grad, model, params, args, stats=None):
+    """``exe_flow_matching.py:280-296``: conditional importance sampling with ``args.num_importance_samples`` fresh
+    flow samples per chain.  Quirk kept: an accepted state carries the STALE ``prev_state.logdensity_grad`` (``:295``)."""
+    B, d = prev.position.shape
+    n_is = int(args.num_importance_samples)
+    ref = IndepGaussian(d)
+    kk = prng.split_rows(keys, 4)                      # :281 key_sample, key_hutch_prev, key_hutch, key_choice
+    o = dict(hutch=args.hutchs, rtol=args.rtol, atol=args.atol, mxstep=args.mxstep, n_ts=args.n_ts)
+    u0, vol0 = ode.inverse_and_logdet(model, params, kk[:, 1], prev.position, **o)                 # :282
+    with np.errstate(over="ignore", invalid="ignore"):
+        w_prev = np.exp(prev.logdensity - ref.logprob(u0) - vol0)                                  # :283
+    ks = np.stack([prng.split(kk[b, 0], n_is) for b in range(B)]).reshape(B * n_is, 2)           # :284
+    kh = np.stack([prng.split(kk[b, 2], n_is) for b in range(B)]).reshape(B * n_is, 2)           # :286
+    refs = ref.sample_model_rows(ks)                                                               # :285
+    xs, vols = ode.transform_and_logdet(model, params, kh, refs, **o)                              # :287
+    lps, _ = value_and_grad(xs)                                                                    # :288
+    with np.errstate(over="ignore", invalid="ignore"):
+        w = np.exp(lps - ref.logprob(refs) - vols).reshape(B, n_is)                                # :289
+    allw = np.concatenate([w_prev[:, None], w], axis=1)
+    norm = allw / allw.sum(1, keepdims=True)                                                       # :290-291
+    choice = np.array([prng.choice_p(kk[b, 3], norm[b]) for b in range(B)])                        # :292
+    choice = np.minimum(choice, n_is)
+    acc = choice != 0
+    pick = np.maximum(choice - 1, 0) + np.arange(B) * n_is
+    m = acc[:, None]
+    wsel = norm[np.arange(B), choice]
+    state = MALAState(np.where(m, xs[pick], prev.position), np.where(acc, lps[pick], prev.logdensity), prev.logdensity_grad)   # :293-295
+    info = MALAInfo(wsel, acc, np.where(m, xs[pick], prev.position), wsel)
+    if stats is not None:
+        stats.update(u0=u0, vol0=vol0, refs=refs, xs=xs, vols=vols, lps=lps, norm=norm, choice=choice)
+    return state, info
+
+
 def train_data_generator(key, states, count, model, params, dist, args, beta=1.0, n_total=None,
                          start=0, stats=None):
     """``exe_flow_matching.py:300-314``; chain b uses ``split(key, B_total)[b]`` (``:303``)."""
@@ -75,9 +108,7 @@ def train_data_generator(key, states, count, model, params, dist, args, beta=1.0
     else:
         do_flow = count % (int(K) + 1) == 0                                                        # :311
     if do_flow:
-        step = imh_step if args.num_importance_samples < 0 else rwmh_step                          # :298
-        if args.num_importance_samples > 0:
-            raise NotImplementedError("conditional importance sampling: SURVEY.md section 8f row N3")
+        step = cis_step if args.num_importance_samples > 0 else imh_step if args.num_importance_samples < 0 else rwmh_step   # :298
         return step(keys, states, vg, model, params, args, stats)
     st, info, _ = mala.kernel(keys, states, vg, args.step_size)                                    # :313
     return st, info

@@ -56,24 +56,34 @@ def run(dist, args, target_gn=None, params_override=None, beta_override=None, ti
         state.params = [{kk: v.astype(np.float32).copy() for kk, v in p.items()} for p in params_override]
     n_chain = args.num_chain
     iter_per_temp = args.anneal_iter // args.num_anneal_temp                             # :330
-    if beta_override is not None:
+    use_real_samples = args.mcmc_per_flow_steps < 0                                       # :328
+    if use_real_samples:
+        beta = 1.0                                                                       # :429-430
+    elif beta_override is not None:
         beta = beta_override
     else:
         beta = flow.beta_fn(0.0, dist.loglik(dist.init_params), args.alpha, n_chain)     # :426
-    states = flow.init_fn(dist.init_params, dist, beta)                                  # :431
+    if use_real_samples:
+        states = flow.MALAState(dist.init_params, None, None)                            # :386
+    else:
+        states = flow.init_fn(dist.init_params, dist, beta)                              # :431
     key_sample = k["sample"]
     trace = dict(loss=[], learning_rate=[], acc_mean=[], acc_std=[], target_loss=[], beta=[], n_att=[])
     t0 = time.perf_counter()
     for count in range(1, args.learning_iter + 1):                                       # :432
         key_sample, key_gn, key_step = prng.split(key_sample, 3)                         # :433
         stats = {}
-        states, infos = flow.train_data_generator(key_gn, states, count, model, state.params, dist,
-                                                  args, beta, stats=stats)               # :438
+        if use_real_samples:                                                             # :382-385
+            states = flow.MALAState(target_gn(prng.split(key_gn, n_chain)), None, None)
+            infos = flow.MALAInfo(np.full(n_chain, np.nan), None, None, None)
+        else:
+            states, infos = flow.train_data_generator(key_gn, states, count, model, state.params, dist,
+                                                      args, beta, stats=stats)           # :438
         loss, grads = fm.loss_and_grad(model, state.params, key_step, states.position, args.sigma,
                                        args.cond_flow)                                   # :364-365
         lr = lr_fn(state.step)                                                           # :367
         state.apply_gradients(grads)                                                     # :366
-        if count % iter_per_temp == 0:                                                   # :440-441
+        if not use_real_samples and count % iter_per_temp == 0:                          # :440-441
             beta, states = flow.beta_gen(beta, states, dist, args.alpha, n_chain)
         trace["loss"].append(loss); trace["learning_rate"].append(lr)
         trace["acc_mean"].append(infos.acceptance_rate.mean())                           # :442

@@ -84,3 +84,25 @@ def test_pines_loop_matches_oracle():
     np.testing.assert_allclose(ex["states"].logdensity.cpu().numpy().mean(), out["states"].logdensity.mean(), rtol=2e-3)
     assert np.isfinite(res[0])
     ex["engine"].close()
+
+
+def test_exact_sample_training_matches_oracle():
+    """mcmc_per_flow_steps < 0 (exe_flow_matching.py:328,382-386): every iteration trains on fresh exact samples of the
+    target; no MCMC, beta = 1, acceptance is NaN."""
+    out, res, ex = _run_both("4-mode", 2, 64, 8, -1, hutch=False, step_size=0.2)
+    tr, m = out["trace"], ex["metrics"]
+    np.testing.assert_allclose(m[:, 0], tr["loss"], rtol=2e-5)
+    np.testing.assert_allclose(m[:, 3], tr["target_loss"], rtol=2e-4)
+    assert np.isnan(m[:, 1]).all() and np.isnan(np.array(tr["acc_mean"])).all()
+    assert ex["betas"][0] == 1.0
+    ex["engine"].close()
+
+
+def test_cis_loop_runs_and_matches_oracle_before_first_flow_step():
+    """num_importance_samples > 0 selects conditional importance sampling as the flow step (:298)."""
+    out, res, ex = _run_both("4-mode", 2, 64, 6, 2, hutch=False, step_size=0.2, num_importance_samples=3)
+    tr, m = out["trace"], ex["metrics"]
+    np.testing.assert_allclose(m[:2, 0], tr["loss"][:2], rtol=1e-5)          # MALA iterations before the first CIS step
+    assert np.isfinite(m[:, 0]).all() and np.isfinite(tr["loss"]).all()
+    np.testing.assert_allclose(m[:, 0], tr["loss"], rtol=0.05)               # afterwards: near-tie categorical draws may differ
+    ex["engine"].close()

@@ -198,3 +198,58 @@ def test_lgcp_transform_and_flow_step_match_oracle():
     np.testing.assert_allclose(logp.cpu().numpy()[same], new.logdensity[same], rtol=1e-4, atol=5e-2)
     np.testing.assert_allclose(grad.cpu().numpy()[same], new.logdensity_grad[same], rtol=1e-3, atol=5e-2)
     ctx.close()
+
+
+def test_flow_cis_step_matches_oracle():
+    """Conditional importance sampling (num_importance_samples > 0, exe_flow_matching.py:280-296): host composition of the
+    ODE / target kernels + mfm_normal_rows + mfm_cis_select vs the oracle step on the same keys (4-mode mixture: its
+    log-densities are O(10), so the un-stabilised weights of the reference neither overflow nor vanish)."""
+    import torch
+    from mfm_amd import random as jr
+    from tests import gpu_util as gu
+    d, B, n_is = 2, 32, 5
+    args, dist, k, model, state = gu.gmm4_setup(B=B, hutchs=False, num_importance_samples=n_is)
+    params = gu.rand_params(model, seed=9, out_scale=0.3)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, max_eval=B * n_is)
+    beta = 0.9
+    vg = targets.Tempered(dist, beta).value_and_grad
+    x32 = dist.init_params.astype(np.float32)
+    pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+    ctx.mala_init(pos, beta, logp, grad)
+    g_before = grad.cpu().numpy().copy()
+    st = mala.MALAState(x32.astype(np.float64), logp.cpu().numpy(), g_before.astype(np.float64))
+    key = prng.PRNGKey(55)
+    stats = {}
+    new, info = flow.cis_step(prng.split(key, B), st, vg, model, params, args, stats)
+    # device composition (what exe_flow_matching.create_train_data_gn does)
+    kk = jr.split_rows(jr.split(key, B), 4)
+    kd = lambda a: _dev(np.ascontiguousarray(a, dtype=np.uint32).view(np.int32))
+    u0 = torch.empty(B, d, device="cuda"); vol0 = torch.empty(B, device="cuda")
+    ctx.ode_transform(-1, pos, u0, vol0, keys=kd(kk[:, 1]))
+    ks = jr.split_rows(kk[:, 0], n_is).reshape(B * n_is, 2); kh = jr.split_rows(kk[:, 2], n_is).reshape(B * n_is, 2)
+    refs = torch.empty(B * n_is, d, device="cuda"); ctx.normal_rows(kd(ks), refs)
+    np.testing.assert_allclose(refs.cpu().numpy(), stats["refs"], atol=1e-6)
+    xs = torch.empty_like(refs); vols = torch.empty(B * n_is, device="cuda")
+    ctx.ode_transform(1, refs, xs, vols, keys=kd(kh))
+    assert np.abs(xs.cpu().numpy() - stats["xs"]).max() < 5e-3 * max(1.0, np.abs(stats["xs"]).max())
+    lps = torch.empty(B * n_is, dtype=torch.float64, device="cuda"); gtmp = torch.empty(B, d, device="cuda"); ltmp = torch.empty(B, dtype=torch.float64, device="cuda")
+    for j in range(n_is):
+        ctx.mala_init(xs[j * B:(j + 1) * B].contiguous(), beta, ltmp, gtmp); lps[j * B:(j + 1) * B] = ltmp
+    np.testing.assert_allclose(lps.cpu().numpy(), stats["lps"], rtol=1e-3, atol=2e-2)
+    acc = torch.empty(B, device="cuda"); isacc = torch.empty(B, dtype=torch.uint8, device="cuda"); prop = torch.empty(B, d, device="cuda"); w = torch.empty(B, device="cuda")
+    ctx.cis_select(key, n_is, u0, vol0, refs, xs, vols, lps, pos, logp, acc, isacc, prop, w)
+    # the categorical draw is an inverse-CDF search: compare the decisions whose uniform is not within 1e-2 of a boundary
+    norm, ch = stats["norm"], stats["choice"]
+    assert np.isfinite(norm).all()
+    cum = np.cumsum(norm, axis=1)
+    r = np.array([cum[b, -1] * (1.0 - prng.uniform(prng.split(prng.split(key, B)[b], 4)[3])) for b in range(B)])
+    clear = np.abs(cum - r[:, None]).min(1) > 1e-2
+    assert clear.mean() > 0.7
+    np.testing.assert_array_equal(isacc.cpu().numpy().astype(bool)[clear], info.is_accepted[clear])
+    assert 0.1 < info.is_accepted.mean() < 1.0                       # both branches are exercised
+    np.testing.assert_allclose(acc.cpu().numpy()[clear], info.acceptance_rate[clear], atol=2e-2)
+    np.testing.assert_allclose(w.cpu().numpy()[clear], info.proposed_weight[clear], atol=2e-2)
+    np.testing.assert_allclose(pos.cpu().numpy()[clear], new.position[clear], atol=5e-3 * max(1.0, np.abs(new.position).max()))
+    np.testing.assert_allclose(logp.cpu().numpy()[clear], new.logdensity[clear], rtol=1e-3, atol=2e-2)
+    np.testing.assert_array_equal(grad.cpu().numpy(), g_before)          # :295 the gradient is NOT refreshed
+    ctx.close()
