@@ -87,6 +87,21 @@ def cpu_baseline(params_flat, fourier, steps_mala, chains, seed=1):
                 n_att=float(stats["n_att_inv"].mean() + stats["n_att_fwd"].mean()))
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc passes of this
+    same command, tools/prof_round.sh): 2 * FETCH_SIZE + WRITE_SIZE, both reported in KB; the factor 2 is the gfx950
+    correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section).  None when no summary is present."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None, None
+    for name, c in d.items():
+        if kernel_class in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return int((2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024), "profiles/r01_pmc_summary.json"
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,9 +204,10 @@ def main():
         if dom is not None and prof[dom]["launches"]:
             avg_ms = prof[dom]["ms"] / prof[dom]["launches"]
             ach = alg[dom] / (avg_ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(dom)
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
-                    "algorithmic_flop_per_launch": alg[dom]}
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "avg_launch_ms": round(avg_ms, 5), "algorithmic_flop_per_launch": alg[dom]}
         out = {
             "metric": "MFM train-steps/s x chains (phi-four d=256, 4096 chains per GPU)", "value": round(value, 1),
             "unit": "chain-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
