@@ -181,12 +181,12 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
   ALLOC(x->acts, (size_t)x->ws.a_tiles * nbb * 256); ALLOC(x->dzs, (size_t)x->ws.z_tiles * nbb * 256);
   ALLOC(x->slabs, (size_t)x->split * n.n_params);
   ALLOC(x->loss_part, x->loss_cap);
-  ALLOC(x->jobs, x->n_jobs); ALLOC(x->opt, 1); ALLOC(x->flag, 1); ALLOC(x->beta_out, 4);
+  ALLOC(x->jobs, x->n_jobs); ALLOC(x->opt, 1); ALLOC(x->flag, 4); ALLOC(x->beta_out, 4);
   HIPCHK(hipMemcpy(x->jobs, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(x->master, 0, n.n_params * 4)); HIPCHK(hipMemset(x->mu, 0, n.n_params * 4));
   HIPCHK(hipMemset(x->nu, 0, n.n_params * 4)); HIPCHK(hipMemset(x->Wp, 0, n.n_packed * 4));
   HIPCHK(hipMemset(x->WpT, 0, n.n_packed * 4)); HIPCHK(hipMemset(x->bias, 0, n.n_bias * 4));
-  HIPCHK(hipMemset(x->opt, 0, sizeof(OptState))); HIPCHK(hipMemset(x->flag, 0, 4));
+  HIPCHK(hipMemset(x->opt, 0, sizeof(OptState))); HIPCHK(hipMemset(x->flag, 0, 16));
   n.Wp = x->Wp; n.WpT = x->WpT; n.bias = x->bias; n.fourier = x->fourier;
   int rc = ode_ws_alloc(n, c, x->ode);
   if (rc) return fail(rc, "ODE workspace allocation failed");
@@ -381,6 +381,7 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
   { ProfScope ps_(x, train ? PROF_FM : PROF_EVAL); rc = launch_fm(a, train, x->stream); }
   if (rc) return fail(rc, "fm kernel cannot be launched for this configuration");
   LAUNCHCHK();
+  if (train) return MFM_OK;            // the training path totals the loss partials in its slab-reduction kernel
   ProfScope ps2_(x, PROF_REDUCE);
   launch_reduce_loss(x->loss_part, n / 16, d_loss, 0, x->stream);
   LAUNCHCHK();
@@ -398,7 +399,7 @@ extern "C" int mfm_fm_loss_grad(mfm_ctx* x, uint32_t k0, uint32_t k1, const floa
   { ProfScope ps_(x, PROF_WGRAD); launch_wgrad(w, x->stream); }
   LAUNCHCHK();
   ProfScope ps2_(x, PROF_REDUCE);
-  launch_reduce_slabs(x->slabs, x->split, x->net.n_params, d_grads, x->stream);
+  launch_reduce_slabs(x->slabs, x->split, x->net.n_params, d_grads, x->loss_part, x->cfg.n_chain_local / 16, d_loss, x->stream);
   LAUNCHCHK();
   return MFM_OK;
 }

@@ -434,13 +434,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   }
 }
 
-// grads[p] = sum_s slabs[s][p]
-__global__ void reduce_slabs_kernel(const float* slabs, int split, int n, float* out) {
+// grads[p] = sum_s slabs[s][p]; the last workgroup of the grid also totals the per-tile loss partials of the forward
+// kernel (same fixed order as reduce_loss_kernel), which saves a launch per training step.
+__global__ void reduce_slabs_kernel(const float* slabs, int split, int n, float* out, const double* loss_part, int n_part, double* loss_out) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < split; ++k) s += slabs[(size_t)k * n + p];
-  out[p] = s;
+  if (p < n) {
+    float s = 0.f;
+    for (int k = 0; k < split; ++k) s += slabs[(size_t)k * n + p];
+    out[p] = s;
+  }
+  if (loss_part && blockIdx.x == gridDim.x - 1) {
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += 256) s += loss_part[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_out = sm[0];
+  }
 }
 
 __global__ void reduce_loss_kernel(const double* part, int n, double* out, int accumulate) {
@@ -483,8 +497,8 @@ int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
   return 0;
 }
 
-void launch_reduce_slabs(const float* slabs, int split, int n, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, slabs, split, n, out);
+void launch_reduce_slabs(const float* slabs, int split, int n, float* out, const double* loss_part, int n_part, double* loss_out, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, slabs, split, n, out, loss_part, n_part, loss_out);
 }
 void launch_reduce_loss(const double* part, int n, double* out, int accumulate, hipStream_t stream) {
   hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, stream, part, n, out, accumulate);

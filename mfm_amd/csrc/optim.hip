@@ -1,4 +1,4 @@
-// K7: apply_if_finite(chain(adamw(mask = not-bias), clip(+-c)), 10) as ONE elementwise kernel that also re-emits the
+// K7: apply_if_finite(chain(adamw(mask = not-bias), clip(+-c)), 10) as a check/decide kernel + ONE elementwise kernel that also re-emits the
 // MFMA-operand-ready packed weights (forward and transposed) the MLP kernels stream.
 //
 // Replaces state.apply_gradients at exe_flow_matching.py:366 with the optimizer of :129-137,184 (optax 0.1.9 rules:
@@ -23,22 +23,11 @@ struct AdamArgs {
   float* master; float* mu; float* nu; // canonical flat layout
   float* Wp; float* WpT; float* bias;  // packed outputs
   OptState* st;
-  int* flag;                           // scratch: non-finite flag (zeroed by the check kernel's predecessor)
+  int* flag;                           // scratch: [0] non-finite flag, [1] / [2] arrival tickets of the two kernels (self-resetting)
   double lr0; int learning_iter, warmup;
   double b1, b2; float eps, wd, clip;
   int max_err;
 };
-
-__global__ void finite_check_kernel(const float* grads, int n_slabs, int n, int* flag) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  bool bad = false;
-  if (p < n) {
-    float s = 0.f;
-    for (int k = 0; k < n_slabs; ++k) s += grads[(size_t)k * n + p];
-    bad = !isfinite(s);
-  }
-  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-}
 
 __device__ __forceinline__ float lr_schedule(double lr0, int learning_iter, int warmup, int count) {
   // join_schedules([linear(0 -> lr, warmup), linear(lr -> 0, learning_iter - warmup)], [warmup]) (:189-198)
@@ -49,21 +38,53 @@ __device__ __forceinline__ float lr_schedule(double lr0, int learning_iter, int 
   return (float)(lr0 * (1.0 - (double)cc / (double)ts));
 }
 
-// One thread decides; every thread of the grid must see the same decision -> the decision kernel runs alone first.
-__global__ void opt_decide_kernel(OptState* st, int* flag, double lr0, int learning_iter, int warmup, int max_err) {
-  const bool finite = (*flag == 0);
-  st->notfinite_count = finite ? 0 : st->notfinite_count + 1;
-  st->last_lr = lr_schedule(lr0, learning_iter, warmup, st->step);
-  st->step += 1;
-  st->last_applied = (finite || st->notfinite_count > max_err) ? 1 : 0;
-  *flag = 0;
+// Finite check over the (summed) gradient + the apply_if_finite decision.  Every thread of the update kernel must see the
+// same decision, so the decision is taken by the LAST workgroup of this kernel to arrive (self-resetting ticket): one
+// launch instead of a check kernel and a single-thread decision kernel.
+__global__ void finite_decide_kernel(const float* grads, int n_slabs, int n, OptState* st, int* flag, double lr0, int learning_iter,
+                                     int warmup, int max_err) {
+  bool bad = false;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {     // few workgroups: one ticket each
+    float s = 0.f;
+    for (int k = 0; k < n_slabs; ++k) s += grads[(size_t)k * n + p];
+    bad |= !isfinite(s);
+  }
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (threadIdx.x == 0) {
+    // device-scope atomics are performed at the memory side; the ticket is issued only after the flag update has RETURNED
+    // (data dependence), so the last arrival sees every flag update without an L2 write-back fence (3.5 us each)
+    unsigned int dep = any_bad ? (unsigned int)atomicOr(flag, 1) : 0u;
+    if (atomicInc(reinterpret_cast<unsigned int*>(flag + 1) + (dep & 0x40000000u), gridDim.x - 1) == gridDim.x - 1) {      // last arrival
+      const bool finite = atomicOr(flag, 0) == 0;
+      st->notfinite_count = finite ? 0 : st->notfinite_count + 1;
+      st->last_lr = lr_schedule(lr0, learning_iter, warmup, st->step);
+      st->step += 1;
+      st->last_applied = (finite || st->notfinite_count > max_err) ? 1 : 0;
+      atomicExch(flag, 0);
+    }
+  }
 }
 
+__device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool apply, float bc1, float bc2, float lr);
+
+// The update + repack; the LAST workgroup to finish advances the inner optimizer count (every workgroup has read it by
+// then), which used to be a kernel of its own.
 __global__ void adamw_kernel(AdamArgs a) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const NetDev& n = a.net;
-  if (p >= n.n_params) return;
   const bool apply = a.st->last_applied != 0;
+  const int count = a.st->count;
+  // per-step scalars once per thread (two float64 pow calls used to be evaluated per parameter)
+  const int c1 = count + 1;
+  const float bc1 = (float)(1.0 - pow(a.b1, (double)c1)), bc2 = (float)(1.0 - pow(a.b2, (double)c1));
+  const float lr = lr_schedule(a.lr0, a.learning_iter, a.warmup, count);
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < a.net.n_params; p += gridDim.x * blockDim.x) adamw_element(a, p, apply, bc1, bc2, lr);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (atomicInc(reinterpret_cast<unsigned int*>(a.flag + 2), gridDim.x - 1) == gridDim.x - 1 && apply) a.st->count = count + 1;
+  }
+}
+
+__device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool apply, float bc1, float bc2, float lr) {
+  const NetDev& n = a.net;
   float w = a.master[p];
   // locate (layer, kernel/bias, k, nn)
   int layer = 0;
@@ -74,16 +95,13 @@ __global__ void adamw_kernel(AdamArgs a) {
   if (apply) {
     float gsum = 0.f;
     for (int k = 0; k < a.n_slabs; ++k) gsum += a.grads[(size_t)k * n.n_params + p];
-    const int c1 = a.st->count + 1;
-    const float bc1 = (float)(1.0 - pow(a.b1, (double)c1));
-    const float bc2 = (float)(1.0 - pow(a.b2, (double)c1));
     const float b1 = (float)a.b1, b2 = (float)a.b2;
     const float m = b1 * a.mu[p] + (1.f - b1) * gsum;
     const float v = b2 * a.nu[p] + (1.f - b2) * gsum * gsum;
     a.mu[p] = m; a.nu[p] = v;
     float u = (m / bc1) / (sqrtf(v / bc2) + a.eps);
     if (!is_bias) u += a.wd * w;
-    u = -lr_schedule(a.lr0, a.learning_iter, a.warmup, a.st->count) * u;
+    u = -lr * u;
     u = fminf(fmaxf(u, -a.clip), a.clip);
     w += u;
     a.master[p] = w;
@@ -99,17 +117,12 @@ __global__ void adamw_kernel(AdamArgs a) {
   }
 }
 
-__global__ void opt_commit_kernel(OptState* st) {
-  if (st->last_applied) st->count += 1;
-}
-
 void launch_adamw(const AdamArgs& a, hipStream_t stream) {
   const int n = a.net.n_params;
-  dim3 grid((n + 255) / 256), block(256);
-  hipLaunchKernelGGL(finite_check_kernel, grid, block, 0, stream, a.grads, a.n_slabs, n, a.flag);
-  hipLaunchKernelGGL(opt_decide_kernel, dim3(1), dim3(1), 0, stream, a.st, a.flag, a.lr0, a.learning_iter, a.warmup, a.max_err);
+  const int nb = (n + 255) / 256;
+  dim3 grid(nb < 256 ? nb : 256), block(256);      // a ticket atomic per workgroup: ~11 ns each on one word, keep them few
+  hipLaunchKernelGGL(finite_decide_kernel, grid, block, 0, stream, a.grads, a.n_slabs, n, a.st, a.flag, a.lr0, a.learning_iter, a.warmup, a.max_err);
   hipLaunchKernelGGL(adamw_kernel, grid, block, 0, stream, a);
-  hipLaunchKernelGGL(opt_commit_kernel, dim3(1), dim3(1), 0, stream, a.st);
 }
 
 // pack only (after mfm_set_params)
