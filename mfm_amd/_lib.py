@@ -138,6 +138,13 @@ class Context:
         self.n_params = self.lib.mfm_num_params(h)
         self.use_current_stream()
 
+    before_params = None      # set by the engine: called before any call that reads or writes the network parameters
+    # (a deferred optimizer step whose gradient all-reduce is still in flight is applied there)
+
+    def _p(self):
+        if self.before_params is not None:
+            self.before_params()
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.mfm_destroy(self.h)
@@ -163,16 +170,19 @@ class Context:
         _chk(self.lib.mfm_set_fourier(self.h, f.ctypes.data_as(C.POINTER(C.c_float))))
 
     def set_params(self, flat):
+        self._p()
         flat = _f32(flat)
         assert flat.size == self.n_params, (flat.size, self.n_params)
         _chk(self.lib.mfm_set_params(self.h, flat.ctypes.data_as(C.POINTER(C.c_float))))
 
     def get_params(self):
+        self._p()
         out = np.empty(self.n_params, dtype=np.float32)
         _chk(self.lib.mfm_get_params(self.h, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
     def reset_optimizer(self):
+        self._p()
         _chk(self.lib.mfm_reset_optimizer(self.h))
 
     # ---- kernels ----------------------------------------------------------------------------------------------
@@ -189,30 +199,37 @@ class Context:
         _chk(self.lib.mfm_loglik(self.h, _ptr(pos, F32), _ptr(out, F64)))
 
     def fm_loss_grad(self, key, pos, loss, grads):
+        self._p()
         _chk(self.lib.mfm_fm_loss_grad(self.h, int(key[0]), int(key[1]), _ptr(pos, F32), _ptr(loss, F64), _ptr(grads, F32)))
 
     def fm_loss(self, key, samples, loss, n_total=None, offset=0):
+        self._p()
         n = samples.shape[0]
         _chk(self.lib.mfm_fm_loss(self.h, int(key[0]), int(key[1]), _ptr(samples, F32), n, n if n_total is None else n_total,
                                   offset, _ptr(loss, F64)))
 
     def adamw_step(self, grads):
+        self._p()
         _chk(self.lib.mfm_adamw_step(self.h, _ptr(grads, F32)))
 
     def opt_state(self):
+        self._p()
         out = (C.c_int32 * 4)()
         lr = C.c_float()
         _chk(self.lib.mfm_opt_state(self.h, out, C.byref(lr)))
         return dict(step=out[0], count=out[1], notfinite_count=out[2], last_applied=out[3], last_lr=lr.value)
 
     def vf_apply(self, x, t, v, tangent=None, jvp=None):
+        self._p()
         _chk(self.lib.mfm_vf_apply(self.h, _ptr(x, F32), _ptr(t, F32), _ptr(tangent, F32), x.shape[0], _ptr(v, F32), _ptr(jvp, F32)))
 
     def ode_transform(self, direction, x, out, ldj, keys=None, key=(0, 0), nsteps=None):
+        self._p()
         _chk(self.lib.mfm_ode_transform(self.h, direction, 0 if keys is None else 1, _ptr(keys, I32), int(key[0]), int(key[1]),
                                         _ptr(x, F32), x.shape[0], _ptr(out, F32), _ptr(ldj, F32), _ptr(nsteps, I32)))
 
     def flow_step(self, mode, key, beta, pos, logp, grad, acc=None, is_acc=None, proposed=None, nsteps=None):
+        self._p()
         _chk(self.lib.mfm_flow_step(self.h, mode, int(key[0]), int(key[1]), float(beta), _ptr(pos, F32), _ptr(logp, F64), _ptr(grad, F32),
                                     _ptr(acc, F32), _ptr(is_acc, U8), _ptr(proposed, F32), _ptr(nsteps, I32)))
 

@@ -60,6 +60,39 @@ def global_mean_std(x, n_total):
     return mean, (s[1] / n_total - mean * mean).clamp_min(0).sqrt()
 
 
+class DeferredAllReduce:
+    """The gradient all-reduce of iteration i kept in flight while iteration i+1 starts.
+
+    ``submit(t)`` issues ``all_reduce(t, SUM, async_op=True)``: RCCL runs it on its own stream, ordered after the work
+    already queued on the caller's stream.  ``flush()`` makes the caller's stream wait for it and then runs ``apply``
+    (the optimizer step).  The engine flushes before every call that reads or writes the network parameters, so a MALA
+    step (which needs neither the parameters nor the gradient buffer) overlaps the collective; a flow step or the next
+    loss/gradient evaluation waits for it.  Without a process group ``submit`` applies immediately."""
+
+    def __init__(self, apply):
+        self.apply = apply
+        self.work = None
+        self.armed = False
+
+    def submit(self, *tensors):
+        td = _dist()
+        if td is None or td.get_world_size() == 1:
+            self.apply()
+            return
+        self.flush()
+        self.work = [td.all_reduce(t, op=td.ReduceOp.SUM, async_op=True) for t in tensors]
+        self.armed = True
+
+    def flush(self):
+        if not self.armed:
+            return
+        self.armed = False                   # first: apply() may re-enter through the parameter hook
+        for w in self.work:
+            w.wait()
+        self.work = None
+        self.apply()
+
+
 class Engine:
     def __init__(self, dist, args, fourier_random=None, max_eval_samples=0):
         import torch
@@ -101,6 +134,8 @@ class Engine:
         self.dev = dev
         self.grads = torch.zeros(self.n_params, device=dev, dtype=torch.float32)
         self.loss = torch.zeros(1, device=dev, dtype=torch.float64)
+        self._deferred = DeferredAllReduce(lambda: self.ctx.adamw_step(self.grads))
+        self.ctx.before_params = self._deferred.flush
 
     # ---- helpers --------------------------------------------------------------------------------------------
     def local(self, full):
@@ -123,11 +158,20 @@ class Engine:
         return allgather_cat(self.loglik(pos))
 
     # ---- one training step on the local chains (exe_flow_matching.py:362-368) -----------------------------------
-    def train_step(self, key, positions):
-        self.ctx.fm_loss_grad(key, positions, self.loss, self.grads)
-        allreduce_sum_(self.grads, self.loss)                    # the loss is a SUM over chains (:178)
-        self.ctx.adamw_step(self.grads)
-        return self.loss
+    def train_step(self, key, positions, loss_out=None):
+        """Loss + gradient on the local chains, ONE all-reduce(SUM) of the gradient, AdamW.  Returns the LOCAL loss (a
+        sum over this rank's chains, :178) in ``loss_out`` (default ``self.loss``); callers that log it sum it over
+        ranks off the critical path (``allreduce_sum_`` on a batch of iterations, see ``run()``).  With more than one
+        rank the optimizer step is deferred until the parameters are next needed, so the collective overlaps the
+        following MALA step (``DeferredAllReduce``)."""
+        loss = self.loss if loss_out is None else loss_out
+        self.ctx.fm_loss_grad(key, positions, loss, self.grads)  # flushes the previous iteration's deferred step first
+        self._deferred.submit(self.grads)
+        return loss
+
+    def flush(self):
+        """Apply a deferred optimizer step now (before reading parameters / optimizer state from outside the ctx)."""
+        self._deferred.flush()
 
     def eval_loss(self, key, samples, out=None, n_total=None, offset=0):
         out = self.torch.zeros(1, device=self.dev, dtype=self.torch.float64) if out is None else out
@@ -139,4 +183,6 @@ class Engine:
         return global_mean_std(x, self.n_total)
 
     def close(self):
+        self._deferred.flush()
+        self.ctx.before_params = None
         self.ctx.close()

@@ -19,7 +19,7 @@ from . import wandb_shim as wandb
 from ._lib import FLOW_IMH, FLOW_RWMH
 from .bblackjax.mcmc.mala import MALAInfo, MALAState, build_kernel, init  # noqa: F401  (same import as :28)
 from .distributions import IndepGaussian
-from .engine import Engine
+from .engine import Engine, allreduce_sum_
 
 logger = logging.getLogger(__name__)
 
@@ -224,6 +224,19 @@ def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
     return train_data_generator, init_fn, transform_and_logdet
 
 
+def _finish_metric_rows(eng, metrics, lo, hi):
+    """Rows [lo, hi) of the per-iteration metrics hold per-rank partial sums (loss, sum acc, sum acc^2, target loss):
+    sum them over ranks in one collective (off the per-iteration critical path) and turn the acceptance sums into the
+    mean / population std logged at exe_flow_matching.py:442-443."""
+    if hi <= lo:
+        return
+    rows = metrics[lo:hi]
+    allreduce_sum_(rows)
+    mean = rows[:, 1] / eng.n_total
+    rows[:, 2] = (rows[:, 2] / eng.n_total - mean * mean).clamp_min(0).sqrt()
+    rows[:, 1] = mean
+
+
 def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     """``exe_flow_matching.py:321-561``: the hot loop runs entirely on the device; metrics are fetched every
     ``log_every`` iterations (the reference syncs to the host every iteration for wandb, :442-449)."""
@@ -276,6 +289,7 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     train_states = init_fn(pos0, beta)                                                      # :431
     metrics = torch.zeros(learning_iter, 4, device=eng.dev, dtype=torch.float64)            # loss, acc mean, acc std, target loss
     betas, lrs = [], []
+    n_reduced = 0
     for count in range(1, learning_iter + 1):                                               # :432
         key_sample, key_train_gn, key_train_step = jr.split(key_sample, 3)                  # :433
         train_states, infos = train_data_generator(key_train_gn, train_states, count, state.params, beta)    # :438
@@ -284,13 +298,14 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
         if not use_real_samples and count % iter_per_temp == 0 and beta < 1.0:              # :440-441, :417
             beta = eng.ctx.beta_update(beta, eng.all_logliks(train_states.position), args.alpha)              # :413
             train_states = init_fn(train_states.position, beta)                             # :415
-        m, s = eng.mean_std(infos.acceptance_rate)                                          # :442-443
-        metrics[count - 1, 0] = loss[0]; metrics[count - 1, 1] = m; metrics[count - 1, 2] = s
+        acc = infos.acceptance_rate.double()
+        metrics[count - 1, 0] = loss[0]; metrics[count - 1, 1] = acc.sum(); metrics[count - 1, 2] = (acc * acc).sum()
         if real_samples is not None:                                                        # :444-446
             eng.eval_loss(key_loss, real_samples, eval_loss, n_total=n_eval, offset=eng.rank * (n_eval // eng.world))
             metrics[count - 1, 3] = eval_loss[0]
         betas.append(beta)
         if count % log_every == 0 or count == learning_iter:
+            _finish_metric_rows(eng, metrics, n_reduced, count); n_reduced = count          # ONE collective per log interval
             row = metrics[count - 1].tolist()                                               # host sync
             wandb.log({"loss": row[0], "learning_rate": lrs[-1], "acceptance avg.": row[1], "acceptance std.": row[2],
                        "target_loss": row[3], "train_time": time.time() - train_start})     # :447-449

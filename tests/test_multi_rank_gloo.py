@@ -37,6 +37,18 @@ def _worker(rank, world, port, out):
     ll = engine.allgather_cat(torch.from_numpy(dist.loglik(st.position)))
     beta = flow.beta_fn(0.0, ll.numpy(), 0.95, n_total)
     m, s = engine.global_mean_std(torch.from_numpy(info.acceptance_rate), n_total)
+    # deferred optimizer step: the all-reduce is in flight until the parameters are next needed
+    applied = []
+    buf = torch.full((5,), float(rank + 1), dtype=torch.float64)
+    d = engine.DeferredAllReduce(lambda: applied.append(buf.clone()))
+    d.submit(buf)
+    assert applied == [] and d.armed
+    d.flush(); d.flush()
+    assert len(applied) == 1 and torch.equal(applied[0], torch.full((5,), 3.0, dtype=torch.float64))
+    buf.fill_(float(rank)); d.submit(buf); buf2 = buf          # a second submit flushes nothing (already flushed)
+    d.submit(buf2)                                              # ... but a submit while armed flushes the first one
+    d.flush()
+    assert len(applied) == 3
     if rank == 0:
         np.savez(out, g=g.numpy(), l=l.numpy(), pos=st.position, beta=beta, m=m.item(), s=s.item(), ll=ll.numpy())
     td.destroy_process_group()
