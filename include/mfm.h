@@ -35,6 +35,7 @@ enum { MFM_OK = 0, MFM_EINVAL = -1, MFM_EUNSUPPORTED = -2, MFM_ETOOLARGE = -3, M
 
 enum { MFM_PHI4 = 0, MFM_GMM = 1, MFM_LGCP = 2 };                 /* distributions.py:114,42,231 */
 enum { MFM_FLOW_RWMH = 0, MFM_FLOW_IMH = 1 };                      /* exe_flow_matching.py:264-278 / :246-260 */
+enum { MFM_FAMILY_AUTO = 0, MFM_FAMILY_TILE = 1, MFM_FAMILY_WIDE = 2 };
 
 typedef struct mfm_config {
   int32_t dim;                 /* args.dim */
@@ -56,6 +57,9 @@ typedef struct mfm_config {
   double learning_rate, adam_b1, adam_b2, adam_eps, weight_decay, update_clip;
   int32_t learning_iter, warmup_steps;
   int32_t max_eval_samples;    /* largest n passed to mfm_fm_loss / mfm_vf_apply (0: n_chain_local) */
+  int32_t kernel_family;       /* MFM_FAMILY_AUTO: fused 16-chain LDS tile kernels when the network fits them, else the wide
+                                  family (per-layer MFMA GEMMs on HBM-resident activations: the "pines" widths of
+                                  multi_modal.py:89-96); _TILE / _WIDE force one (ETOOLARGE if _TILE does not fit) */
 } mfm_config;
 
 const char* mfm_last_error(void);

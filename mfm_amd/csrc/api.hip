@@ -16,6 +16,7 @@
 #include "anneal.hip"
 #include "metrics.hip"
 #include "cis.hip"
+#include "wide.hip"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -51,6 +52,7 @@ struct mfm_ctx {
   float *gmm_mode, *gmm_std, *gmm_logw, *counts, *Kinv, *kbias;
   OdeWs ode;
   double* beta_out;
+  wide::Ctx* wide;             // non-null: the wide kernel family serves the network kernels (wide.hip)
 };
 
 struct ProfScope {
@@ -159,12 +161,22 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
   build_net(c, x->net);
   build_ws(x->net, x->ws);
   NetDev& n = x->net;
+  bool use_wide = c.kernel_family == MFM_FAMILY_WIDE;
   {
     const FmLds L = fm_lds_layout(n, true);
-    if ((size_t)L.total * 4 > 160 * 1024 || (n.dp / 16 + MLP_WAVES_FM - 1) / MLP_WAVES_FM > 2) {
+    size_t sm_ode; int tpw_ode;
+    const bool fits = (size_t)L.total * 4 <= 160 * 1024 && (n.dp / 16 + MLP_WAVES_FM - 1) / MLP_WAVES_FM <= 2 && ode_check(n, sm_ode, tpw_ode) == 0;
+    if (!fits && c.kernel_family == MFM_FAMILY_TILE) {
       delete x;
       return fail(MFM_ETOOLARGE, "network does not fit the fused 16-chain tile kernel (LDS %zu B, dim %d)", (size_t)L.total * 4, c.dim);
     }
+    if (!fits) use_wide = true;
+  }
+  if (c.kernel_family < 0 || c.kernel_family > MFM_FAMILY_WIDE) { delete x; return fail(MFM_EINVAL, "unknown kernel_family %d", c.kernel_family); }
+  if (use_wide && !c.hutch) {
+    delete x;
+    return fail(MFM_EUNSUPPORTED, "the wide kernel family integrates the log-det with the Hutchinson estimator only (--hutch); "
+                                  "the exact trace needs dim tangent passes per evaluation");
   }
   const int nbb = c.n_chain_local / 16;
   x->split = nbb < 16 ? nbb : 16;
@@ -178,8 +190,10 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
 #define ALLOC(p, cnt) HIPCHK(hipMalloc((void**)&(p), (size_t)(cnt) * sizeof(*(p))))
   ALLOC(x->master, n.n_params); ALLOC(x->mu, n.n_params); ALLOC(x->nu, n.n_params);
   ALLOC(x->Wp, n.n_packed); ALLOC(x->WpT, n.n_packed); ALLOC(x->bias, n.n_bias); ALLOC(x->fourier, n.F);
-  ALLOC(x->acts, (size_t)x->ws.a_tiles * nbb * 256); ALLOC(x->dzs, (size_t)x->ws.z_tiles * nbb * 256);
-  ALLOC(x->slabs, (size_t)x->split * n.n_params);
+  if (!use_wide) {       // packed activation / gradient workspaces of the fused family
+    ALLOC(x->acts, (size_t)x->ws.a_tiles * nbb * 256); ALLOC(x->dzs, (size_t)x->ws.z_tiles * nbb * 256);
+    ALLOC(x->slabs, (size_t)x->split * n.n_params);
+  }
   ALLOC(x->loss_part, x->loss_cap);
   ALLOC(x->jobs, x->n_jobs); ALLOC(x->opt, 1); ALLOC(x->flag, 4); ALLOC(x->beta_out, 4);
   HIPCHK(hipMemcpy(x->jobs, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice));
@@ -190,6 +204,10 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
   n.Wp = x->Wp; n.WpT = x->WpT; n.bias = x->bias; n.fourier = x->fourier;
   int rc = ode_ws_alloc(n, c, x->ode);
   if (rc) return fail(rc, "ODE workspace allocation failed");
+  if (use_wide) {
+    rc = wide::create(n, c.n_chain_local, &x->wide);
+    if (rc) return fail(rc, "workspace allocation of the wide kernel family failed");
+  }
   *out = x;
   return MFM_OK;
 }
@@ -201,6 +219,7 @@ extern "C" int mfm_destroy(mfm_ctx* x) {
                 x->jobs, x->opt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->beta_out};
   for (void* p : ps) if (p) hipFree(p);
   ode_ws_free(x->ode);
+  wide::destroy(x->wide);
   if (x->prof) { for (auto& e : x->prof->ev) (void)hipEventDestroy(e); delete x->prof; }
   delete x;
   return MFM_OK;
@@ -223,6 +242,7 @@ extern "C" int mfm_set_target(mfm_ctx* x, int kind, const double* p, size_t np) 
     const int K = (int)p[0];
     if (K <= 0 || K > MFM_GMM_MAX_MODES || np != (size_t)(1 + 2 * K * d + K)) return fail(MFM_EINVAL, "bad GMM parameter block");
     if (d > 8) return fail(MFM_EUNSUPPORTED, "GMM targets support dim <= 8 (the reference forces dim = 2)");
+    if (x->wide) return fail(MFM_EUNSUPPORTED, "the wide kernel family serves the PhiFour and LGCP targets");
     std::vector<float> mode(K * d), sd(K * d), lw(K);
     for (int i = 0; i < K * d; ++i) { mode[i] = (float)p[1 + i]; sd[i] = (float)p[1 + K * d + i]; }
     for (int k = 0; k < K; ++k) {
@@ -261,7 +281,7 @@ extern "C" int mfm_set_target(mfm_ctx* x, int kind, const double* p, size_t np) 
     // the K^-1 tile buffers must fit next to the MLP tiles
     const FmLds Lf = fm_lds_layout(x->net, true);
     const OdeLds Lo = ode_lds_layout(x->net, ODE_NW);
-    if ((size_t)Lf.total * 4 > 160 * 1024 || (size_t)Lo.total * 4 > 160 * 1024) {
+    if (!x->wide && ((size_t)Lf.total * 4 > 160 * 1024 || (size_t)Lo.total * 4 > 160 * 1024)) {
       memset(&T, 0, sizeof T);
       return fail(MFM_ETOOLARGE, "LGCP target with dim %d does not fit the 16-chain LDS tile next to this network", d);
     }
@@ -363,10 +383,10 @@ extern "C" int mfm_loglik(mfm_ctx* x, const float* d_pos, double* d_out) {
 }
 
 static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_samples, int n, int n_total, int offset, bool train,
-                     double* d_loss) {
+                     double* d_loss, float* d_grads = nullptr) {
   if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
   if (n <= 0 || n % 16) return fail(MFM_EUNSUPPORTED, "sample count must be a positive multiple of 16 (got %d)", n);
-  if (n / 16 > x->loss_cap) return fail(MFM_ETOOLARGE, "n=%d exceeds max_eval_samples given at mfm_create", n);
+  if (!x->wide && n / 16 > x->loss_cap) return fail(MFM_ETOOLARGE, "n=%d exceeds max_eval_samples given at mfm_create", n);
   FmArgs a; memset(&a, 0, sizeof a);
   a.net = x->net; a.ws = x->ws;
   const Key2 key{k0, k1};
@@ -377,6 +397,22 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
   }
   a.n_total = n_total; a.chain_offset = offset; a.B = n; a.sigma = x->cfg.sigma; a.cond_flow = x->cfg.cond_flow;
   a.pos = d_samples; a.acts = x->acts; a.dzs = x->dzs; a.loss_part = x->loss_part;
+  if (x->wide) {      // R rows per pass; the loss is accumulated over the passes
+    wide::Ctx* w = x->wide;
+    for (int r0 = 0; r0 < n; r0 += w->R) {
+      wide::FmCall c;
+      c.key_time = a.key_time; c.key_ref = a.key_ref; c.key_gauss = a.key_gauss; c.n_total = (uint32_t)n_total; c.chain_offset = (uint32_t)(offset + r0);
+      c.sigma = a.sigma; c.cond_flow = a.cond_flow; c.pos = d_samples + (size_t)r0 * x->cfg.dim; c.rows = n - r0 < w->R ? n - r0 : w->R;
+      int rcw;
+      { ProfScope ps_(x, train ? PROF_FM : PROF_EVAL); rcw = wide::fm(w, x->net, c, train, train ? d_grads : nullptr, x->stream); }
+      if (rcw) return fail(rcw, "wide fm kernels cannot be launched for this configuration");
+      LAUNCHCHK();
+      ProfScope ps2_(x, PROF_REDUCE);
+      launch_reduce_loss(w->loss_part, (c.rows + 3) / 4, d_loss, r0 > 0, x->stream);
+      LAUNCHCHK();
+    }
+    return MFM_OK;
+  }
   int rc;
   { ProfScope ps_(x, train ? PROF_FM : PROF_EVAL); rc = launch_fm(a, train, x->stream); }
   if (rc) return fail(rc, "fm kernel cannot be launched for this configuration");
@@ -391,8 +427,8 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
 extern "C" int mfm_fm_loss_grad(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_pos, double* d_loss, float* d_grads) {
   NEED_TARGET();
   if (!d_pos || !d_loss || !d_grads) return fail(MFM_EINVAL, "null device pointer");
-  int rc = fm_common(x, k0, k1, d_pos, x->cfg.n_chain_local, x->cfg.n_chain_total, x->cfg.chain_offset, true, d_loss);
-  if (rc) return rc;
+  int rc = fm_common(x, k0, k1, d_pos, x->cfg.n_chain_local, x->cfg.n_chain_total, x->cfg.chain_offset, true, d_loss, d_grads);
+  if (rc || x->wide) return rc;
   WgradArgs w; memset(&w, 0, sizeof w);
   w.net = x->net; w.ws = x->ws; w.acts = x->acts; w.dzs = x->dzs; w.jobs = x->jobs; w.n_jobs = x->n_jobs;
   w.nbb = x->cfg.n_chain_local / 16; w.split = x->split; w.slabs = x->slabs;
@@ -441,6 +477,11 @@ extern "C" int mfm_vf_apply(mfm_ctx* x, const float* d_x, const float* d_t, cons
   if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
   if (!d_x || !d_t || !d_v || ((d_tan == nullptr) != (d_jvp == nullptr))) return fail(MFM_EINVAL, "bad pointer arguments");
   if (n <= 0 || n % 16) return fail(MFM_EUNSUPPORTED, "n must be a positive multiple of 16");
+  if (x->wide) {
+    if (wide::vf_apply(x->wide, x->net, d_x, d_t, d_tan, n, d_v, d_jvp, x->stream)) return fail(MFM_EHIP, "wide vf_apply failed");
+    LAUNCHCHK();
+    return MFM_OK;
+  }
   int rc = launch_vf_apply(x->net, d_x, d_t, d_tan, n, d_v, d_jvp, x->stream);
   if (rc) return fail(rc, "vf_apply cannot be launched for this configuration");
   LAUNCHCHK();
@@ -458,6 +499,13 @@ extern "C" int mfm_ode_transform(mfm_ctx* x, int direction, int per_chain, const
   OdeArgs a = ode_args(x->net, x->cfg, x->ode);
   a.direction = direction; a.per_chain_keys = per_chain; a.keys = d_keys; a.key = Key2{k0, k1};
   a.in = d_in; a.out = d_out; a.ldj = d_ldj; a.nsteps = d_nsteps; a.n = n;
+  if (x->wide) {
+    launch_probe(per_chain ? 0 : 1, d_keys, a.key, 0, 0, 0, n, x->net.d, const_cast<float*>(a.z1), x->stream);
+    const int rcw = wide::transform(x->wide, x->net, direction, a.rtol, a.atol, a.max_attempts, a.z1, d_in, n, d_out, d_ldj, d_nsteps, x->stream);
+    if (rcw) return fail(rcw, "wide ODE transform failed: %s", hipGetErrorString(hipGetLastError()));
+    LAUNCHCHK();
+    return MFM_OK;
+  }
   int rc = launch_ode_transform(a, x->stream);
   if (rc) return fail(rc, "ODE kernel cannot be launched for this configuration");
   LAUNCHCHK();
@@ -477,6 +525,19 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
   f.beta = beta; f.pos = d_pos; f.logp = d_logp; f.grad = d_grad; f.acc_prob = d_acc; f.accepted = d_isacc;
   f.proposed = d_prop; f.nsteps = d_nsteps;
   ProfScope ps_(x, PROF_FLOW);
+  if (x->wide) {
+    launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 0, a.n, x->net.d, const_cast<float*>(a.zgen), x->stream);     // key_gen
+    launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 3, a.n, x->net.d, const_cast<float*>(a.z1), x->stream);       // key_hutch2
+    launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 2, a.n, x->net.d, const_cast<float*>(a.z2), x->stream);       // key_hutch1
+    wide::FlowCall c; memset(&c, 0, sizeof c);
+    c.mode = mode; c.key = f.key; c.n_total = f.n_total; c.chain_offset = f.chain_offset; c.beta = beta; c.rows = a.n;
+    c.rtol = a.rtol; c.atol = a.atol; c.max_attempts = a.max_attempts; c.z_inv = a.z1; c.z_fwd = a.z2; c.zgen = a.zgen;
+    c.pos = d_pos; c.logp = d_logp; c.grad = d_grad; c.acc_prob = d_acc; c.accepted = d_isacc; c.proposed = d_prop; c.nsteps = d_nsteps;
+    const int rcw = wide::flow_step(x->wide, x->net, c, x->stream);
+    if (rcw) return fail(rcw, "wide flow step failed: %s", hipGetErrorString(hipGetLastError()));
+    LAUNCHCHK();
+    return MFM_OK;
+  }
   int rc = launch_flow_step(a, f, x->stream);
   if (rc) return fail(rc, "flow step cannot be launched for this configuration");
   LAUNCHCHK();

@@ -1,0 +1,968 @@
+// The WIDE kernel family: networks / dimensions that do not fit the fused 16-chain LDS tile (mlp.cuh) -- the
+// "pines" configuration of the reference (multi_modal.py:89-96: hidden widths 1024, d = 1024 / 1600; SURVEY.md
+// section 8d config C4).  Same arithmetic and the same C ABI as the fused family; what changes is the data movement:
+//
+//   * activations live in HBM / MALL as plain row-major [rows][features] float32 (a 1024-wide layer of 1024 chains is
+//     4 MB: L2-resident between the producing and the consuming kernel), one GEMM kernel launch per layer;
+//   * the GEMM is computed TRANSPOSED on the matrix cores: D = W^T-tile (A operand, the packed weights exactly as the
+//     fused family streams them) x activation-tile^T (B operand: one float4 per lane from a row-major activation row).
+//     The f32 accumulator of v_mfma_f32_16x16x4_f32 then holds 4 consecutive FEATURES of one chain per lane, so
+//     bias / ReLU / masks / residual adds and the store are float4 wide and row-major again: no LDS staging, no
+//     transposes, no packed activation copies;
+//   * forward-mode (value + tangent) evaluation shares every weight fragment between the value rows and the tangent
+//     rows of the same chains (two accumulator sets), with the ReLU mask applied to the tangent in the epilogue;
+//   * the weight-gradient GEMM (reduction over chains) loads BOTH operands as row-major float4 and issues the 4 x 4
+//     outer product of their elements as 16 MFMAs (a 64 x 64 block of dW per wave, k-depth 4 chains per MFMA); the
+//     accumulators come out as float4 runs of the canonical [in][out] gradient layout;
+//   * the adaptive Dopri5 state machine (oracle/ode.py) is the same per-chain masked lock-step
+//     as ode.hip, but driven from the host: one attempt = 6 field evaluations of ~10 launches each on the context's
+//     stream, then a 4-byte read-back of the number of chains still integrating.
+//
+// Replaces the same reference code as fm.hip / ode.hip: exe_flow_matching.py:56-90 (VectorFieldNet), :151-178 (loss),
+// :206-242 (CNF transforms), :246-278 (flow-MH steps), jax.value_and_grad at :364-365.
+#include "mlp.cuh"
+#include "prng.cuh"
+
+namespace wide {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GEMM:  Y[r][n] = epi( sum_k X[r][k] W[k][n] ),  optionally also the tangent rows YT = epi'( XT W ).
+// ---------------------------------------------------------------------------------------------------------------------
+struct Gemm {
+  const float* W; int KB, NT;            // packed weights [NT][KB][64 lanes] float4 (mlp.cuh "Wp" layout), K blocks, N tiles
+  const float* bias;                     // [16 NT] or null
+  const float* X; int ldx;               // value rows (row-major, ld multiple of 4)
+  const float* XT; int KBT;              // tangent rows (same ld) and the K blocks they span (<= KB); null: no tangent GEMM
+  const float* TS; int ldts;             // tangent taken from a precomputed buffer instead of a GEMM (x1 layer: z W_x1)
+  float* Y; int ldy; int ycol;           // value output (+ column offset, e.g. the st half of [sx | st])
+  float* YT;                             // tangent output (same ld / offset) or null
+  int rows;                              // multiple of 16
+  int relu;                              // y = max(pre, 0); tangent masked by pre > 0
+  const float* mask; int ldm, mcol;      // backward: y = (mask > 0) ? pre : 0
+  const float* add; int lda, acol;       // backward: pre += add (second contribution to the same activation)
+};
+
+template <int MTW, int NTW, bool DUAL>
+__global__ __launch_bounds__(256) void gemm_kernel(Gemm a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int mt0 = (blockIdx.y * 2 + (wave >> 1)) * MTW, nt0 = (blockIdx.x * 2 + (wave & 1)) * NTW;
+  const int MT = a.rows >> 4;
+  if (mt0 >= MT || nt0 >= a.NT) return;                       // no barriers in this kernel
+  const f32x4* wp[NTW];
+  const float* xp[MTW];
+  const float* xtp[MTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) wp[j] = reinterpret_cast<const f32x4*>(a.W) + (size_t)(nt0 + j < a.NT ? nt0 + j : nt0) * a.KB * 64 + lane;
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const size_t row = (size_t)(mt0 + m < MT ? mt0 + m : mt0) * 16 + c;
+    xp[m] = a.X + row * a.ldx + 4 * g;
+    xtp[m] = DUAL ? a.XT + row * a.ldx + 4 * g : nullptr;
+  }
+  f32x4 acc[NTW][MTW], acT[NTW][MTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) { acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f}; acT[j][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  struct Frag { f32x4 w[NTW], x[MTW], t[MTW]; };
+  auto load = [&](Frag& f, int kb) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) f.w[j] = wp[j][(size_t)kb * 64];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) f.x[m] = *reinterpret_cast<const f32x4*>(xp[m] + kb * 16);
+    if (DUAL) {
+      if (kb < a.KBT) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) f.t[m] = *reinterpret_cast<const f32x4*>(xtp[m] + kb * 16);
+      }
+    }
+  };
+  auto mac = [&](const Frag& f, int kb) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[j][s], f.x[m][s], acc[j][m], 0, 0, 0);
+    if (DUAL) {
+      if (kb < a.KBT) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) acT[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[j][s], f.t[m][s], acT[j][m], 0, 0, 0);
+      }
+    }
+  };
+  // two ping-pong fragment sets: the loads of block kb + 1 are in flight while block kb is multiplied
+  Frag fa, fb;
+  load(fa, 0);
+  for (int kb = 0; kb < a.KB; kb += 2) {
+    if (kb + 1 < a.KB) load(fb, kb + 1);
+    mac(fa, kb);
+    if (kb + 2 < a.KB) load(fa, kb + 2);
+    if (kb + 1 < a.KB) mac(fb, kb + 1);
+  }
+  // epilogue: lane (g, c) holds features 16 nt + 4 g .. + 3 of row 16 mt + c
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int nt = nt0 + j;
+    if (nt >= a.NT) continue;
+    const int f0 = nt * 16 + 4 * g;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + f0);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      if (mt0 + m >= MT) continue;
+      const size_t row = (size_t)(mt0 + m) * 16 + c;
+      f32x4 pre = acc[j][m] + bv;
+      if (a.add) pre += *reinterpret_cast<const f32x4*>(a.add + row * a.lda + a.acol + f0);
+      if (a.mask) {
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + row * a.ldm + a.mcol + f0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[i] = mk[i] > 0.f ? pre[i] : 0.f;
+      }
+      f32x4 y = pre;
+      if (a.relu) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = fmaxf(pre[i], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(a.Y + row * a.ldy + a.ycol + f0) = y;
+      if (a.YT) {
+        f32x4 t = acT[j][m];
+        if (a.TS) t = *reinterpret_cast<const f32x4*>(a.TS + row * a.ldts + f0);
+        if (a.relu) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t[i] = pre[i] > 0.f ? t[i] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(a.YT + row * a.ldy + a.ycol + f0) = t;
+      }
+    }
+  }
+}
+
+static void launch_gemm(const Gemm& a, hipStream_t s) {
+  const bool dual = a.XT != nullptr;
+  const int MT = a.rows / 16;
+  // 2 x 2 waves per workgroup; wave tile (16 MTW) rows x (16 NTW) features.  Small problems (this path runs ~1024 rows)
+  // take the 32 x 32 wave tile so that the launch still covers the 1024 SIMDs.
+  const bool big = (long long)MT * a.NT >= 4 * 4096 && !dual;
+  if (big) {
+    dim3 grid((a.NT + 3) / 4, (MT + 7) / 8);
+    hipLaunchKernelGGL((gemm_kernel<4, 2, false>), grid, dim3(256), 0, s, a);
+  } else {
+    dim3 grid((a.NT + 3) / 4, (MT + 3) / 4);
+    if (dual) hipLaunchKernelGGL((gemm_kernel<2, 2, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<2, 2, false>), grid, dim3(256), 0, s, a);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradients: dW[k][n] = sum_r A[r][k] dZ[r][n], db[n] = sum_r dZ[r][n]; one wave per 64 x 64 block of dW.
+// ---------------------------------------------------------------------------------------------------------------------
+struct WgLayer { const float* A; int lda; const float* Z; int ldz; int K, N, Kp, Np, m_w, m_b; };
+struct WgJob { int layer, kt, nt; };
+struct WgArgs { WgLayer L[MLP_NLAYER]; const WgJob* jobs; int n_jobs; int rows; float* grads; };
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int job = blockIdx.x * 4 + wave;
+  if (job >= a.n_jobs) return;
+  const WgJob J = a.jobs[job];
+  const WgLayer& L = a.L[J.layer];
+  const int ac = 64 * J.kt + 4 * c, zc = 64 * J.nt + 4 * c;
+  const bool av = ac < L.Kp, zv = zc < L.Np;
+  const float* ap = L.A + (size_t)g * L.lda + (av ? ac : 0);
+  const float* zp = L.Z + (size_t)g * L.ldz + (zv ? zc : 0);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[4][4], bs = zero;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[s][u] = zero;
+  auto lda_ = [&](int r) { return av ? *reinterpret_cast<const f32x4*>(ap + (size_t)r * L.lda) : zero; };
+  auto ldz_ = [&](int r) { return zv ? *reinterpret_cast<const f32x4*>(zp + (size_t)r * L.ldz) : zero; };
+  auto mac = [&](const f32x4& af, const f32x4& zf) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[s][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], zf[u], acc[s][u], 0, 0, 0);
+    bs += zf;
+  };
+  // rows is a multiple of 16: four steps of 4 chains per iteration, loads of the next iteration issued first
+  f32x4 a0 = lda_(0), a1 = lda_(4), a2 = lda_(8), a3 = lda_(12), z0 = ldz_(0), z1 = ldz_(4), z2 = ldz_(8), z3 = ldz_(12);
+  for (int r = 0; r < a.rows; r += 16) {
+    f32x4 na0 = zero, na1 = zero, na2 = zero, na3 = zero, nz0 = zero, nz1 = zero, nz2 = zero, nz3 = zero;
+    if (r + 16 < a.rows) {
+      na0 = lda_(r + 16); na1 = lda_(r + 20); na2 = lda_(r + 24); na3 = lda_(r + 28);
+      nz0 = ldz_(r + 16); nz1 = ldz_(r + 20); nz2 = ldz_(r + 24); nz3 = ldz_(r + 28);
+    }
+    mac(a0, z0); mac(a1, z1); mac(a2, z2); mac(a3, z3);
+    a0 = na0; a1 = na1; a2 = na2; a3 = na3; z0 = nz0; z1 = nz1; z2 = nz2; z3 = nz3;
+  }
+  // acc[s][u][i] = dW[64 kt + 4 (4 g + i) + s][64 nt + 4 c + u]
+  float* gw = a.grads + L.m_w;
+  const bool vec = (L.N & 3) == 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 64 * J.kt + 4 * (4 * g + i) + s;
+      if (k >= L.K) continue;
+      if (vec) {
+        if (zc < L.N) *reinterpret_cast<f32x4*>(gw + (size_t)k * L.N + zc) = f32x4{acc[s][0][i], acc[s][1][i], acc[s][2][i], acc[s][3][i]};
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (zc + u < L.N) gw[(size_t)k * L.N + zc + u] = acc[s][u][i];
+      }
+    }
+  if (J.kt == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { bs[u] += __shfl_xor(bs[u], 16, 64); bs[u] += __shfl_xor(bs[u], 32, 64); }
+    if (g == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (zc + u < L.N) a.grads[L.m_b + zc + u] = bs[u];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row kernels (one wavefront per chain row, 4 rows per workgroup)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fourier_row(const float* __restrict__ fr, int F, int F2p, double te, float* out, int lane) {
+  for (int col = lane; col < F; col += 64) {                 // :70-71: cos block then sin block
+    double ft = (double)fr[col] * te;
+    ft -= rint(ft);
+    float sv, cv;
+    sincospif(2.f * (float)ft, &sv, &cv);
+    out[col] = cv; out[F + col] = sv;
+  }
+  for (int col = 2 * F + lane; col < F2p; col += 64) out[col] = 0.f;
+}
+
+struct FmPro {
+  Key2 key_time, key_ref, key_gauss; uint32_t n_total, chain_offset;
+  int rows, d, dp, F, F2p; float sigma; int cond_flow;
+  const float* pos; const float* fourier;
+  float* cond; float* tgt; float* ffat;
+};
+// K3 batch construction (exe_flow_matching.py:151-169 / :139-147), same draws as fm.hip's prologue
+__global__ __launch_bounds__(256) void fm_prologue_kernel(FmPro a) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.rows) return;
+  const uint32_t bg = a.chain_offset + (uint32_t)b, d = (uint32_t)a.d;
+  const float tf = (float)uniform01(a.key_time, bg, a.n_total);                 // :154 / :142
+  const double t = tf;
+  const Key2 kref = split_at(a.key_ref, a.n_total, bg);                         // :155
+  for (int col = lane; col < a.dp; col += 64) {
+    float cv = 0.f, tv = 0.f;
+    if (col < a.d) {
+      const double x1v = a.pos[(size_t)b * a.d + col];
+      double cnd, tg;
+      if (a.cond_flow) {
+        const double x0 = normal64(kref, (uint32_t)col, d);
+        const double ne = normal64(a.key_gauss, bg * d + (uint32_t)col, a.n_total * d);       // :166
+        cnd = (double)a.sigma * ne + t * x1v + (1.0 - t) * x0;                                // :167
+        tg = x1v - x0;                                                                        // :168
+      } else {
+        const double x0 = normal64(a.key_ref, bg * d + (uint32_t)col, a.n_total * d);         // :143
+        const double sds = 1.0 - (1.0 - (double)a.sigma) * t;                                 // :144
+        cnd = t * x1v + sds * x0;                                                             // :145
+        tg = x1v - (1.0 - (double)a.sigma) * x0;                                              // :146
+      }
+      cv = (float)cnd; tv = (float)tg;
+    }
+    a.cond[(size_t)b * a.dp + col] = cv;
+    a.tgt[(size_t)b * a.dp + col] = tv;
+  }
+  fourier_row(a.fourier, a.F, a.F2p, t, a.ffat + (size_t)b * a.F2p, lane);
+}
+
+// clip(grad log pi(x)) of the UNTEMPERED target (:351) and, with a tangent, the masked Hessian-vector product.
+// LGCP: KV = K^-1 (x - mu) and KZ = K^-1 z come from GEMMs with the packed K^-1.
+struct TgtArgs {
+  TargetDev T; float clip; int rows, d, dp;
+  const float* X; const float* Z; const float* KV; const float* KZ;
+  float* GC; float* HZ;
+};
+__global__ __launch_bounds__(256) void target_kernel(TgtArgs a) {
+  const size_t n = (size_t)a.rows * a.dp;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+    const int col = (int)(idx % a.dp);
+    const size_t r0 = idx - col;
+    float gc = 0.f, hz = 0.f;
+    if (col < a.d) {
+      const float x = a.X[idx];
+      float graw, hraw = 0.f;
+      if (a.T.kind == MFM_TARGET_PHI4) {
+        const float xl = col > 0 ? a.X[idx - 1] : 0.f, xr = col + 1 < a.d ? a.X[idx + 1] : 0.f;
+        graw = -a.T.tbeta * (a.T.coef * (2.f * x - xl - xr) - x * (1.f - x * x) / a.T.coef);
+        if (a.Z) {
+          const float v = a.Z[idx], vl = col > 0 ? a.Z[idx - 1] : 0.f, vr = col + 1 < a.d ? a.Z[idx + 1] : 0.f;
+          hraw = -a.T.tbeta * (a.T.coef * (2.f * v - vl - vr) - (1.f - 3.f * x * x) * v / a.T.coef);
+        }
+      } else {
+        const float ex = a.T.poisson_a * expf(x);
+        graw = a.T.counts[col] - ex - a.KV[idx];
+        if (a.Z) hraw = -ex * a.Z[idx] - a.KZ[idx];
+      }
+      gc = clipf(graw, a.clip);
+      const bool inside = !(a.clip > 0.f) || fabsf(graw) <= a.clip;
+      hz = inside ? hraw : 0.f;
+    }
+    (void)r0;
+    a.GC[idx] = gc;
+    if (a.HZ) a.HZ[idx] = hz;
+  }
+}
+
+// loss (:177-178) and the two output-side gradients: dv = 2 (v - target), dgate = dv * clip(grad log pi)
+struct LossArgs { int rows, d, dp; const float* out; const float* gate; const float* gc; const float* tgt; float* dv; float* dg; double* part; };
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
+  __shared__ double sm[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.x * 4 + w;
+  float loc = 0.f;
+  if (b < a.rows) {
+    for (int col = lane; col < a.dp; col += 64) {
+      const size_t o = (size_t)b * a.dp + col;
+      float dv = 0.f, dg = 0.f;
+      if (col < a.d) {
+        const float gc = a.gc[o];
+        const float r = a.out[o] + a.gate[o] * gc - a.tgt[o];
+        loc += r * r;
+        dv = 2.f * r; dg = dv * gc;
+      }
+      if (a.dv) { a.dv[o] = dv; a.dg[o] = dg; }
+    }
+  }
+  const double s = wave_sum((double)loc);
+  if (lane == 0) sm[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) a.part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Adaptive Dopri5, per-row state in global memory
+// ---------------------------------------------------------------------------------------------------------------------
+struct RowState { float *t, *dt, *h0, *d1, *ell, *kl /* [7][rows] */; int *natt, *done; };
+
+__device__ static const float W_TAB[8][7] = {   // [phase][j]: input = y + h sum_j TAB[phase][j] k_j ; last column: time fraction
+    {0, 0, 0, 0, 0, 0, 0.f},
+    {1, 0, 0, 0, 0, 0, 1.f},
+    {1.f / 5, 0, 0, 0, 0, 0, 1.f / 5},
+    {3.f / 40, 9.f / 40, 0, 0, 0, 0, 3.f / 10},
+    {44.f / 45, -56.f / 15, 32.f / 9, 0, 0, 0, 4.f / 5},
+    {19372.f / 6561, -25360.f / 2187, 64448.f / 6561, -212.f / 729, 0, 0, 8.f / 9},
+    {9017.f / 3168, -355.f / 33, 46732.f / 5247, 49.f / 176, -5103.f / 18656, 0, 1.f},
+    {35.f / 384, 0, 500.f / 1113, 125.f / 192, -2187.f / 6784, 11.f / 84, 1.f}};
+__device__ static const float W_E[7] = {(float)(35.0 / 384 - 1951.0 / 21600), 0.f, (float)(500.0 / 1113 - 22642.0 / 50085),
+                                        (float)(125.0 / 192 - 451.0 / 720), (float)(-2187.0 / 6784 + 12231.0 / 42400),
+                                        (float)(11.0 / 84 - 649.0 / 6300), (float)(-1.0 / 60)};
+__device__ static const float W_M[7] = {(float)(6025192743.0 / 30085553152.0 / 2), 0.f, (float)(51252292925.0 / 65400821598.0 / 2),
+                                        (float)(-2691868925.0 / 45128329728.0 / 2), (float)(187940372067.0 / 1594534317056.0 / 2),
+                                        (float)(-1776094331.0 / 19743644256.0 / 2), (float)(11237099.0 / 235043384.0 / 2)};
+
+struct OdeBuf {
+  int rows, d, dp, F, F2p, sign;
+  float rtol, atol; int max_attempts;
+  RowState rs;
+  float* Y;            // [rows][dp] state x
+  float* K;            // [7][rows][dp] stage derivatives of x
+  float* X;            // [rows][dp] stage input (value rows of the field evaluation)
+  const float* Z;      // [rows][dp] probe (zero padded)
+  float* ffat;         // [rows][F2p]
+  const float* fourier;
+  const float* out; const float* outT; const float* gate; const float* gc; const float* hz;   // results of the evaluation
+  int* n_active;
+};
+
+// stage input of phase p: X = y + h sum_j TAB[p][j] k_j, Fourier features of the stage time (:70-71, :229)
+__global__ __launch_bounds__(256) void stage_prep_kernel(OdeBuf a, int phase) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.rows) return;
+  float cf[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) cf[j] = W_TAB[phase][j];
+  const float h = phase == 1 ? a.rs.h0[b] : a.rs.dt[b];
+  const float ts = a.rs.t[b] + h * cf[6];
+  const size_t o0 = (size_t)b * a.dp, ks = (size_t)a.rows * a.dp;
+  for (int col = lane; col < a.dp; col += 64) {
+    float v = 0.f;
+    if (col < a.d) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (cf[j] != 0.f) acc += cf[j] * a.K[j * ks + o0 + col];
+      v = a.Y[o0 + col] + h * acc;
+    }
+    a.X[o0 + col] = v;
+  }
+  if (phase != 7) {        // stages 6 and 7 share t + dt: the time branch of stage 6 is still valid
+    const double te = a.sign > 0 ? (double)ts : 1.0 - (double)ts;
+    fourier_row(a.fourier, a.F, a.F2p, te, a.ffat + (size_t)b * a.F2p, lane);
+  }
+}
+
+// end of a field evaluation: k_dst = +-v, kl_dst = -+ z . J z, then the phase-specific part of the state machine
+// (phase 0 / 1: initial step size, Hairer II.4 order 4; phase 7: error norm, accept / reject, step-size controller,
+// 4th-order interpolation at t = 1, FSAL) -- the same float32 arithmetic as ode_solve() in ode.hip.
+__global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.rows) return;
+  const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
+  const size_t o0 = (size_t)b * a.dp, ks = (size_t)a.rows * a.dp;
+  const int R = a.rows;
+  float dpart = 0.f;
+  for (int col = lane; col < a.d; col += 64) {
+    const size_t o = o0 + col;
+    const float gt = a.gate[o];
+    const float v = a.out[o] + gt * a.gc[o];
+    a.K[dst * ks + o] = a.sign > 0 ? v : -v;
+    if (a.Z) dpart += a.Z[o] * (a.outT[o] + gt * a.hz[o]);
+  }
+  dpart = wave_sum(dpart);
+  const float dl = a.sign > 0 ? -dpart : dpart;                 // :218 / :239
+  if (lane == 0) a.rs.kl[dst * R + b] = dl;
+  const float atol = a.atol, rtol = a.rtol;
+  if (phase == 0) {
+    float p0 = 0.f, p1 = 0.f;
+    for (int col = lane; col < a.d; col += 64) {
+      const float y = a.Y[o0 + col], k0 = a.K[o0 + col];      // same lane wrote K[0] above
+      const float sc = atol + fabsf(y) * rtol;
+      const float a0 = y / sc, a1 = k0 / sc;
+      p0 += a0 * a0; p1 += a1 * a1;
+    }
+    p0 = wave_sum(p0); p1 = wave_sum(p1);
+    if (lane == 0) {
+      const float a1 = dl / atol;
+      const float d0 = sqrtf(p0), d1 = sqrtf(p1 + a1 * a1);
+      a.rs.h0[b] = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+      a.rs.d1[b] = d1;
+    }
+  } else if (phase == 1) {
+    float p2 = 0.f;
+    for (int col = lane; col < a.d; col += 64) {
+      const float y = a.Y[o0 + col];
+      const float sc = atol + fabsf(y) * rtol;
+      const float a2 = (a.K[ks + o0 + col] - a.K[o0 + col]) / sc;
+      p2 += a2 * a2;
+    }
+    p2 = wave_sum(p2);
+    if (lane == 0) {
+      const float h0 = a.rs.h0[b], d1 = a.rs.d1[b];
+      const float a2 = (dl - a.rs.kl[b]) / atol;
+      const float d2 = sqrtf(p2 + a2 * a2) / h0;
+      const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
+      const float dt = fminf(100.f * h0, h1);
+      a.rs.dt[b] = dt;
+      if (dt > 0.f) atomicAdd(a.n_active, 1);
+    }
+  } else if (phase == 7) {
+    const float dti = a.rs.dt[b], t0 = a.rs.t[b], ell0 = a.rs.ell[b];
+    const int na = a.rs.natt[b], dn = a.rs.done[b];
+    float kl[7];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) kl[j] = a.rs.kl[j * R + b];
+    kl[6] = dl;
+    float e2 = 0.f;
+    for (int col = lane; col < a.d; col += 64) {
+      const size_t o = o0 + col;
+      float er = 0.f;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) er += W_E[j] * a.K[j * ks + o];
+      er *= dti;
+      const float tol = atol + rtol * fmaxf(fabsf(a.Y[o]), fabsf(a.X[o]));
+      const float rr = er / tol;
+      e2 += rr * rr;
+    }
+    e2 = wave_sum(e2);
+    const bool active = !dn && na < a.max_attempts && dti > 0.f;
+    float sl = 0.f, el = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) sl += W_TAB[7][j] * kl[j];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) el += W_E[j] * kl[j];
+    const float l1 = ell0 + dti * sl;
+    el *= dti;
+    const float tol = atol + rtol * fmaxf(fabsf(ell0), fabsf(l1));
+    const float rr = el / tol;
+    const float ratio = sqrtf((e2 + rr * rr) / (float)(a.d + 1));
+    const bool acc = active && ratio <= 1.f;
+    const float dfac = ratio < 1.f ? 1.f : 0.2f;
+    const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
+    const float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+    float t_n = t0, ell_n = ell0, kl0_n = kl[0];
+    int dn_n = dn;
+    if (acc) {
+      const float tn = t0 + dti;
+      if (tn >= 1.f) {
+        const float sfrac = (1.f - t0) / (tn - t0);
+        float lm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) lm += W_M[j] * kl[j];
+        {
+          const float y0 = ell0, y1 = l1, ym = y0 + dti * lm, f0 = dti * kl[0], f1 = dti * kl[6];
+          const float pa = -2.f * f0 + 2.f * f1 - 8.f * y0 - 8.f * y1 + 16.f * ym;
+          const float pb = 5.f * f0 - 3.f * f1 + 18.f * y0 + 14.f * y1 - 32.f * ym;
+          const float pc = -4.f * f0 + f1 - 11.f * y0 - 5.f * y1 + 16.f * ym;
+          ell_n = (((pa * sfrac + pb) * sfrac + pc) * sfrac + f0) * sfrac + y0;
+        }
+        for (int col = lane; col < a.d; col += 64) {
+          const size_t o = o0 + col;
+          float km = 0.f;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) km += W_M[j] * a.K[j * ks + o];
+          const float x0 = a.Y[o], x1 = a.X[o], xm = x0 + dti * km, g0 = dti * a.K[o], g1 = dti * a.K[6 * ks + o];
+          const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
+          const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
+          const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
+          a.Y[o] = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
+        }
+        dn_n = 1;
+      } else {
+        ell_n = l1;
+        for (int col = lane; col < a.d; col += 64) {
+          const size_t o = o0 + col;
+          a.Y[o] = a.X[o];
+          a.K[o] = a.K[6 * ks + o];               // FSAL
+        }
+        kl0_n = kl[6];
+      }
+      t_n = tn;
+    }
+    if (lane == 0) {
+      const float dt_n = active ? ndt : dti;
+      const int na_n = active ? na + 1 : na;
+      a.rs.t[b] = t_n; a.rs.dt[b] = dt_n; a.rs.ell[b] = ell_n; a.rs.kl[b] = kl0_n; a.rs.natt[b] = na_n; a.rs.done[b] = dn_n;
+      if (!dn_n && na_n < a.max_attempts && dt_n > 0.f) atomicAdd(a.n_active, 1);
+    }
+  }
+}
+
+__global__ void ode_init_kernel(RowState rs, int rows) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= rows) return;
+  rs.t[b] = 0.f; rs.dt[b] = 0.f; rs.h0[b] = 0.f; rs.d1[b] = 0.f; rs.ell[b] = 0.f; rs.natt[b] = 0; rs.done[b] = 0;
+  for (int j = 0; j < 7; ++j) rs.kl[j * rows + b] = 0.f;
+}
+
+// rows [n][d] (caller layout) <-> [n][dp] zero-padded work layout
+__global__ void pad_rows_kernel(const float* src, int n, int d, int dp, float* dst) {
+  const size_t tot = (size_t)n * dp;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+    const int col = (int)(i % dp);
+    dst[i] = col < d ? src[(i / dp) * d + col] : 0.f;
+  }
+}
+__global__ void unpad_rows_kernel(const float* src, int n, int d, int dp, float* dst) {
+  const size_t tot = (size_t)n * d;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+    const int col = (int)(i % d);
+    dst[i] = src[(i / d) * dp + col];
+  }
+}
+// v = out + gate * gc ; J z = outT + gate * hz  (mfm_vf_apply)
+__global__ void vf_out_kernel(int n, int d, int dp, const float* out, const float* outT, const float* gate, const float* gc, const float* hz,
+                              float* v, float* jvp) {
+  const size_t tot = (size_t)n * d;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+    const size_t o = (i / d) * dp + (i % d);
+    v[i] = out[o] + gate[o] * gc[o];
+    if (jvp) jvp[i] = outT[o] + gate[o] * hz[o];
+  }
+}
+
+// ---- flow-MH step glue (exe_flow_matching.py:246-278) ----------------------------------------------------------------
+struct FlowGlue {
+  int mode; Key2 key; uint32_t n_total, chain_offset; double beta;
+  int rows, d, dp;
+  TargetDev T;
+  float* Y;                  // [rows][dp]: u0 after the inverse solve -> proposal -> x' after the forward solve
+  const float* zgen;         // [rows][d]
+  const float* ell;          // log-det of the solve that just finished
+  float* vol0; float* lqref; int* natt_tot; const int* natt;
+  const float* KV;           // LGCP: K^-1 (x' - mu)
+  float* pos; double* logp; float* grad; float* acc_prob; uint8_t* accepted; float* proposed; int* nsteps;
+};
+// after the inverse solve: keep vol0, build the latent proposal (:268 random walk / :249 independent)
+__global__ __launch_bounds__(256) void flow_propose_kernel(FlowGlue a) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.rows) return;
+  const float scale = 2.38f / sqrtf((float)a.d);                                                  // :262
+  float r0 = 0.f, r1 = 0.f;
+  for (int col = lane; col < a.d; col += 64) {
+    const size_t o = (size_t)b * a.dp + col;
+    const float nz = a.zgen[(size_t)b * a.d + col], u0 = a.Y[o];
+    if (a.mode == MFM_FLOW_RWMH) a.Y[o] = u0 + scale * nz;
+    else { r0 += u0 * u0; r1 += nz * nz; a.Y[o] = nz; }
+  }
+  r0 = wave_sum(r0); r1 = wave_sum(r1);
+  if (lane == 0) {
+    a.vol0[b] = a.ell[b];
+    a.lqref[b] = a.mode == MFM_FLOW_IMH ? -0.5f * (r0 - r1) : 0.f;                                // :254-255
+    a.natt_tot[b] = a.natt[b];
+  }
+}
+// after the forward solve: tempered target at the proposal (:270 / :252), unclipped acceptance ratio, accept / reject
+__global__ __launch_bounds__(256) void flow_accept_kernel(FlowGlue a) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.rows) return;
+  const float* y = a.Y + (size_t)b * a.dp;
+  double lpn;
+  if (a.T.kind == MFM_TARGET_PHI4) {
+    double part = 0.0;
+    for (int col = lane; col < a.d; col += 64) {
+      const double x = y[col];
+      const double xr = col + 1 < a.d ? (double)y[col + 1] : 0.0;
+      const double dr = xr - x;
+      double u = dr * dr;
+      if (col == 0) u += x * x;
+      const double q = 1.0 - x * x;
+      part += -(double)a.T.tbeta * (0.5 * (double)a.T.coef * u + q * q / (4.0 * (double)a.T.coef));
+    }
+    lpn = a.beta * wave_sum(part);
+  } else {
+    double lik = 0.0, quad = 0.0;
+    for (int col = lane; col < a.d; col += 64) {
+      const float xv = y[col], yv = a.KV[(size_t)b * a.dp + col], ex = expf(xv);
+      lik += (double)xv * (double)a.T.counts[col] - (double)a.T.poisson_a * (double)ex;
+      quad += (double)(xv - a.T.mu) * (double)yv;
+    }
+    lpn = a.beta * wave_sum(lik) - 0.5 * wave_sum(quad) + (double)a.T.log_norm;
+  }
+  const Key2 kb = split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);                      // :303
+  const double la = lpn - (double)a.ell[b] - a.logp[b] - (double)a.vol0[b] + (double)a.lqref[b];
+  const double ap = exp(la);
+  const double u = uniform01(split_at(kb, 4, 1), 0, 1);
+  const bool acc = u <= ap;                      // NaN compares false -> reject
+  for (int col = lane; col < a.d; col += 64) {
+    const size_t o = (size_t)b * a.d + col;
+    const float xv = y[col];
+    if (a.proposed) a.proposed[o] = xv;
+    if (acc) {
+      float gv;
+      if (a.T.kind == MFM_TARGET_PHI4) {
+        const float xl = col > 0 ? y[col - 1] : 0.f, xr = col + 1 < a.d ? y[col + 1] : 0.f;
+        gv = (float)a.beta * (-a.T.tbeta * (a.T.coef * (2.f * xv - xl - xr) - xv * (1.f - xv * xv) / a.T.coef));
+      } else {
+        gv = (float)a.beta * (a.T.counts[col] - a.T.poisson_a * expf(xv)) - a.KV[(size_t)b * a.dp + col];
+      }
+      a.pos[o] = xv; a.grad[o] = gv;
+    }
+  }
+  if (lane == 0) {
+    if (acc) a.logp[b] = lpn;
+    if (a.acc_prob) a.acc_prob[b] = (float)ap;
+    if (a.accepted) a.accepted[b] = acc ? 1 : 0;
+    if (a.nsteps) a.nsteps[b] = a.natt_tot[b] + a.natt[b];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------------------------------
+struct Ctx {
+  int R;                                   // row capacity of one pass (multiple of 16)
+  int d, dp, F2p, ht1, ht2, hx1, hx2, hj1, hj2, cat;
+  float* pool = nullptr; size_t pool_floats = 0;
+  // forward activations
+  float *ffat, *t1, *catv, *cond, *x1, *j1, *j2, *gate, *out, *tgt, *gc, *kv;
+  // tangent twins
+  float *zp, *tz1, *kz, *hz, *x1T, *catT, *j1T, *j2T, *outT;
+  // backward
+  float *dv, *dg, *dj2, *dj1, *dcat, *dx1, *dt1;
+  // ODE
+  float *Y, *K, *rsf; int* rsi; RowState rs;
+  float *vol0, *lqref; int* natt_tot;
+  double* loss_part; int n_loss_part;
+  WgJob* jobs = nullptr; int n_jobs = 0;
+  int* n_active = nullptr; int* h_active = nullptr;
+};
+
+static int create(const NetDev& n, int rows_cap, Ctx** out) {
+  Ctx* w = new Ctx();
+  w->R = (rows_cap + 15) & ~15;
+  w->d = n.d; w->dp = n.dp; w->F2p = n.F2p; w->ht1 = n.ht1; w->ht2 = n.ht2; w->hx1 = n.hx1; w->hx2 = n.hx2; w->hj1 = n.hj1; w->hj2 = n.hj2;
+  w->cat = n.hx2 + n.ht2;
+  const size_t R = w->R;
+  size_t o = 0;
+  auto take = [&](size_t cnt) { size_t r = o; o += (cnt + 63) & ~(size_t)63; return r; };
+  const size_t o_ffat = take(R * n.F2p), o_t1 = take(R * n.ht1), o_cat = take(R * w->cat), o_cond = take(R * n.dp), o_x1 = take(R * n.hx1),
+               o_j1 = take(R * n.hj1), o_j2 = take(R * n.hj2), o_gate = take(R * n.dp), o_out = take(R * n.dp), o_tgt = take(R * n.dp),
+               o_gc = take(R * n.dp), o_kv = take(R * n.dp), o_zp = take(R * n.dp), o_tz1 = take(R * n.hx1), o_kz = take(R * n.dp),
+               o_hz = take(R * n.dp), o_x1T = take(R * n.hx1), o_catT = take(R * w->cat), o_j1T = take(R * n.hj1), o_j2T = take(R * n.hj2),
+               o_outT = take(R * n.dp), o_dv = take(R * n.dp), o_dg = take(R * n.dp), o_dj2 = take(R * n.hj2), o_dj1 = take(R * n.hj1),
+               o_dcat = take(R * w->cat), o_dx1 = take(R * n.hx1), o_dt1 = take(R * n.ht1), o_Y = take(R * n.dp), o_K = take(7 * R * n.dp),
+               o_rsf = take(12 * R), o_vol0 = take(R), o_lq = take(R);
+  w->pool_floats = o;
+  if (hipMalloc((void**)&w->pool, o * sizeof(float)) != hipSuccess) { delete w; return -4; }
+  (void)hipMemset(w->pool, 0, o * sizeof(float));
+  float* p = w->pool;
+  w->ffat = p + o_ffat; w->t1 = p + o_t1; w->catv = p + o_cat; w->cond = p + o_cond; w->x1 = p + o_x1; w->j1 = p + o_j1; w->j2 = p + o_j2;
+  w->gate = p + o_gate; w->out = p + o_out; w->tgt = p + o_tgt; w->gc = p + o_gc; w->kv = p + o_kv; w->zp = p + o_zp; w->tz1 = p + o_tz1;
+  w->kz = p + o_kz; w->hz = p + o_hz; w->x1T = p + o_x1T; w->catT = p + o_catT; w->j1T = p + o_j1T; w->j2T = p + o_j2T; w->outT = p + o_outT;
+  w->dv = p + o_dv; w->dg = p + o_dg; w->dj2 = p + o_dj2; w->dj1 = p + o_dj1; w->dcat = p + o_dcat; w->dx1 = p + o_dx1; w->dt1 = p + o_dt1;
+  w->Y = p + o_Y; w->K = p + o_K; w->rsf = p + o_rsf; w->vol0 = p + o_vol0; w->lqref = p + o_lq;
+  w->rs.t = w->rsf; w->rs.dt = w->rsf + R; w->rs.h0 = w->rsf + 2 * R; w->rs.d1 = w->rsf + 3 * R; w->rs.ell = w->rsf + 4 * R; w->rs.kl = w->rsf + 5 * R;
+  if (hipMalloc((void**)&w->rsi, 3 * R * sizeof(int)) != hipSuccess) return -4;
+  w->rs.natt = w->rsi; w->rs.done = w->rsi + R; w->natt_tot = w->rsi + 2 * R;
+  w->n_loss_part = (int)(R / 4 + 1);
+  if (hipMalloc((void**)&w->loss_part, w->n_loss_part * sizeof(double)) != hipSuccess) return -4;
+  if (hipMalloc((void**)&w->n_active, 16) != hipSuccess) return -4;
+  if (hipHostMalloc((void**)&w->h_active, 16, hipHostMallocDefault) != hipSuccess) return -4;
+  std::vector<WgJob> jobs;
+  for (int l = 0; l < MLP_NLAYER; ++l)
+    for (int nt = 0; nt * 64 < n.L[l].Np; ++nt)
+      for (int kt = 0; kt * 64 < n.L[l].Kp; ++kt) jobs.push_back(WgJob{l, kt, nt});
+  w->n_jobs = (int)jobs.size();
+  if (hipMalloc((void**)&w->jobs, jobs.size() * sizeof(WgJob)) != hipSuccess) return -4;
+  (void)hipMemcpy(w->jobs, jobs.data(), jobs.size() * sizeof(WgJob), hipMemcpyHostToDevice);
+  *out = w;
+  return 0;
+}
+
+static void destroy(Ctx* w) {
+  if (!w) return;
+  if (w->pool) (void)hipFree(w->pool);
+  if (w->rsi) (void)hipFree(w->rsi);
+  if (w->loss_part) (void)hipFree(w->loss_part);
+  if (w->n_active) (void)hipFree(w->n_active);
+  if (w->h_active) (void)hipHostFree(w->h_active);
+  if (w->jobs) (void)hipFree(w->jobs);
+  delete w;
+}
+
+static Gemm fwd(const NetDev& n, int layer, const float* X, int ldx, float* Y, int ldy, int ycol, int rows, int relu) {
+  Gemm g; memset(&g, 0, sizeof g);
+  const LayerDesc& L = n.L[layer];
+  g.W = n.Wp + L.w_off; g.KB = L.Kp / 16; g.NT = L.Np / 16; g.bias = n.bias + L.b_off;
+  g.X = X; g.ldx = ldx; g.Y = Y; g.ldy = ldy; g.ycol = ycol; g.rows = rows; g.relu = relu;
+  return g;
+}
+static Gemm bwd(const NetDev& n, int layer, const float* dZ, int ldz, float* dA, int lda, int acol, int rows) {
+  Gemm g; memset(&g, 0, sizeof g);
+  const LayerDesc& L = n.L[layer];
+  g.W = n.WpT + L.w_off; g.KB = L.Np / 16; g.NT = L.Kp / 16;          // dA = dZ W^T: the transposed packing is the "weight" here
+  g.X = dZ; g.ldx = ldz; g.Y = dA; g.ldy = lda; g.ycol = acol; g.rows = rows;
+  return g;
+}
+static Gemm kinv(const NetDev& n, const float* X, float* Y, int rows, bool with_bias) {
+  Gemm g; memset(&g, 0, sizeof g);
+  g.W = n.T.KinvP; g.KB = n.dp / 16; g.NT = n.dp / 16; g.bias = with_bias ? n.T.kbias : nullptr;
+  g.X = X; g.ldx = n.dp; g.Y = Y; g.ldy = n.dp; g.rows = rows;
+  return g;
+}
+static int grid4(int rows) { return (rows + 3) / 4; }
+static int grid_el(size_t n) { size_t b = (n + 255) / 256; return (int)(b < 4096 ? b : 4096); }
+
+static void target_eval(Ctx* w, const NetDev& n, const float* X, const float* Z, int rows, hipStream_t s) {
+  if (n.T.kind == MFM_TARGET_LGCP) launch_gemm(kinv(n, X, w->kv, rows, true), s);
+  TgtArgs t; memset(&t, 0, sizeof t);
+  t.T = n.T; t.clip = n.grad_clip; t.rows = rows; t.d = n.d; t.dp = n.dp; t.X = X; t.Z = Z; t.KV = w->kv; t.KZ = w->kz; t.GC = w->gc; t.HZ = Z ? w->hz : nullptr;
+  hipLaunchKernelGGL(target_kernel, dim3(grid_el((size_t)rows * n.dp)), dim3(256), 0, s, t);
+}
+
+// time branch: ffat -> t1 -> st (into [sx | st]) -> gate
+static void time_branch(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
+  launch_gemm(fwd(n, 0, w->ffat, n.F2p, w->t1, n.ht1, 0, rows, 1), s);
+  launch_gemm(fwd(n, 1, w->t1, n.ht1, w->catv, w->cat, n.hx2, rows, 1), s);
+  launch_gemm(fwd(n, 4, w->catv + n.hx2, w->cat, w->gate, n.dp, 0, rows, 0), s);
+}
+// x branch + joint layers on value rows X (and tangent rows: z in w->zp, z W_x1 in w->tz1)
+static void x_branch(Ctx* w, const NetDev& n, const float* X, bool tangent, int rows, hipStream_t s) {
+  Gemm g = fwd(n, 2, X, n.dp, w->x1, n.hx1, 0, rows, 1);
+  if (tangent) { g.YT = w->x1T; g.TS = w->tz1; g.ldts = n.hx1; }
+  launch_gemm(g, s);
+  g = fwd(n, 3, w->x1, n.hx1, w->catv, w->cat, 0, rows, 1);
+  if (tangent) { g.XT = w->x1T; g.KBT = g.KB; g.YT = w->catT; }
+  launch_gemm(g, s);
+  g = fwd(n, 5, w->catv, w->cat, w->j1, n.hj1, 0, rows, 1);
+  if (tangent) { g.XT = w->catT; g.KBT = n.hx2 / 16; g.YT = w->j1T; }          // the st half of the tangent is zero
+  launch_gemm(g, s);
+  g = fwd(n, 6, w->j1, n.hj1, w->j2, n.hj2, 0, rows, 1);
+  if (tangent) { g.XT = w->j1T; g.KBT = g.KB; g.YT = w->j2T; }
+  launch_gemm(g, s);
+  g = fwd(n, 7, w->j2, n.hj2, w->out, n.dp, 0, rows, 0);
+  if (tangent) { g.XT = w->j2T; g.KBT = g.KB; g.YT = w->outT; }
+  launch_gemm(g, s);
+}
+// once per solve: z W_x1 (no bias) and, LGCP, K^-1 z
+static void probe_setup(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
+  Gemm g = fwd(n, 2, w->zp, n.dp, w->tz1, n.hx1, 0, rows, 0);
+  g.bias = nullptr;
+  launch_gemm(g, s);
+  if (n.T.kind == MFM_TARGET_LGCP) launch_gemm(kinv(n, w->zp, w->kz, rows, false), s);
+}
+
+struct FmCall {
+  Key2 key_time, key_ref, key_gauss; uint32_t n_total, chain_offset; float sigma; int cond_flow;
+  const float* pos; int rows;
+};
+// loss (+ gradient into d_grads, canonical layout) on `rows` samples; the per-workgroup loss partials land in w->loss_part
+static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_grads, hipStream_t s) {
+  const int rows = c.rows;
+  if (rows > w->R || rows % 16) return -3;
+  FmPro p; memset(&p, 0, sizeof p);
+  p.key_time = c.key_time; p.key_ref = c.key_ref; p.key_gauss = c.key_gauss; p.n_total = c.n_total; p.chain_offset = c.chain_offset;
+  p.rows = rows; p.d = n.d; p.dp = n.dp; p.F = n.F; p.F2p = n.F2p; p.sigma = c.sigma; p.cond_flow = c.cond_flow;
+  p.pos = c.pos; p.fourier = n.fourier; p.cond = w->cond; p.tgt = w->tgt; p.ffat = w->ffat;
+  hipLaunchKernelGGL(fm_prologue_kernel, dim3(grid4(rows)), dim3(256), 0, s, p);
+  time_branch(w, n, rows, s);
+  target_eval(w, n, w->cond, nullptr, rows, s);
+  x_branch(w, n, w->cond, false, rows, s);
+  LossArgs l; memset(&l, 0, sizeof l);
+  l.rows = rows; l.d = n.d; l.dp = n.dp; l.out = w->out; l.gate = w->gate; l.gc = w->gc; l.tgt = w->tgt; l.part = w->loss_part;
+  if (train) { l.dv = w->dv; l.dg = w->dg; }
+  hipLaunchKernelGGL(loss_kernel, dim3(grid4(rows)), dim3(256), 0, s, l);
+  if (!train) return 0;
+  // ---- backward: data gradients (the reverse sweep jax.value_and_grad performs at :364-365) ----
+  Gemm g = bwd(n, 7, w->dv, n.dp, w->dj2, n.hj2, 0, rows); g.mask = w->j2; g.ldm = n.hj2; launch_gemm(g, s);
+  g = bwd(n, 6, w->dj2, n.hj2, w->dj1, n.hj1, 0, rows); g.mask = w->j1; g.ldm = n.hj1; launch_gemm(g, s);
+  // d [sx | st] through j1, ReLU-masked on both halves; the st half then receives the gate path and is masked again
+  // ((m a + b) m = (a + b) m for a 0/1 mask m)
+  g = bwd(n, 5, w->dj1, n.hj1, w->dcat, w->cat, 0, rows); g.mask = w->catv; g.ldm = w->cat; launch_gemm(g, s);
+  g = bwd(n, 4, w->dg, n.dp, w->dcat, w->cat, n.hx2, rows);
+  g.add = w->dcat; g.lda = w->cat; g.acol = n.hx2; g.mask = w->catv; g.ldm = w->cat; g.mcol = n.hx2; launch_gemm(g, s);
+  g = bwd(n, 3, w->dcat, w->cat, w->dx1, n.hx1, 0, rows); g.mask = w->x1; g.ldm = n.hx1; launch_gemm(g, s);
+  g = bwd(n, 1, w->dcat + n.hx2, w->cat, w->dt1, n.ht1, 0, rows); g.mask = w->t1; g.ldm = n.ht1; launch_gemm(g, s);
+  // ---- weight gradients, straight into the canonical flat gradient vector ----
+  WgArgs a; memset(&a, 0, sizeof a);
+  const float* A[MLP_NLAYER] = {w->ffat, w->t1, w->cond, w->x1, w->catv + n.hx2, w->catv, w->j1, w->j2};
+  const int lda[MLP_NLAYER] = {n.F2p, n.ht1, n.dp, n.hx1, w->cat, w->cat, n.hj1, n.hj2};
+  const float* Z[MLP_NLAYER] = {w->dt1, w->dcat + n.hx2, w->dx1, w->dcat, w->dg, w->dj1, w->dj2, w->dv};
+  const int ldz[MLP_NLAYER] = {n.ht1, w->cat, n.hx1, w->cat, n.dp, n.hj1, n.hj2, n.dp};
+  for (int l = 0; l < MLP_NLAYER; ++l) {
+    const LayerDesc& L = n.L[l];
+    a.L[l] = WgLayer{A[l], lda[l], Z[l], ldz[l], L.K, L.N, L.Kp, L.Np, L.m_w, L.m_b};
+  }
+  a.jobs = w->jobs; a.n_jobs = w->n_jobs; a.rows = rows; a.grads = d_grads;
+  hipLaunchKernelGGL(wgrad_kernel, dim3((w->n_jobs + 3) / 4), dim3(256), 0, s, a);
+  return 0;
+}
+
+// ---- one evaluation of the augmented field on the rows in w->X-like buffer `X` (times already in w->ffat) ----
+static void field_eval(Ctx* w, const NetDev& n, const float* X, bool tangent, bool time_too, int rows, hipStream_t s) {
+  if (time_too) time_branch(w, n, rows, s);
+  target_eval(w, n, X, tangent ? w->zp : nullptr, rows, s);
+  x_branch(w, n, X, tangent, rows, s);
+}
+
+struct SolveArgs { int sign; float rtol, atol; int max_attempts; int rows; };
+
+// Integrate rows of w->Y (padded [rows][dp]) from t = 0 to 1 with the probe in w->zp; results: w->Y, w->rs.ell, w->rs.natt.
+// Synchronises the stream once per attempted step (4-byte read-back of the number of rows still integrating).
+static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hipStream_t s) {
+  const int rows = c.rows;
+  OdeBuf o; memset(&o, 0, sizeof o);
+  o.rows = rows; o.d = n.d; o.dp = n.dp; o.F = n.F; o.F2p = n.F2p; o.sign = c.sign; o.rtol = c.rtol; o.atol = c.atol; o.max_attempts = c.max_attempts;
+  o.rs = w->rs; o.Y = w->Y; o.K = w->K; o.X = xstage; o.Z = w->zp; o.ffat = w->ffat; o.fourier = n.fourier;
+  o.out = w->out; o.outT = w->outT; o.gate = w->gate; o.gc = w->gc; o.hz = w->hz; o.n_active = w->n_active;
+  hipLaunchKernelGGL(ode_init_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, w->rs, rows);
+  if (hipMemsetAsync(w->K, 0, (size_t)7 * rows * n.dp * sizeof(float), s) != hipSuccess) return -4;
+  probe_setup(w, n, rows, s);
+  auto read_active = [&](int& v) -> int {
+    if (hipMemcpyAsync(w->h_active, w->n_active, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return -4;
+    if (hipStreamSynchronize(s) != hipSuccess) return -4;
+    v = *w->h_active;
+    return 0;
+  };
+  for (int phase = 0; phase < 2; ++phase) {                   // f0 and the extra evaluation of the initial-step heuristic
+    if (phase == 1 && hipMemsetAsync(w->n_active, 0, sizeof(int), s) != hipSuccess) return -4;
+    hipLaunchKernelGGL(stage_prep_kernel, dim3(grid4(rows)), dim3(256), 0, s, o, phase);
+    field_eval(w, n, xstage, true, true, rows, s);
+    hipLaunchKernelGGL(stage_finish_kernel, dim3(grid4(rows)), dim3(256), 0, s, o, phase);
+  }
+  int active = 0;
+  if (read_active(active)) return -4;
+  // every row stops after max_attempts attempted steps, so the loop is bounded even if the read-back misbehaves
+  for (int it = 0; active > 0 && it < c.max_attempts; ++it) {
+    if (hipMemsetAsync(w->n_active, 0, sizeof(int), s) != hipSuccess) return -4;
+    for (int phase = 2; phase < 8; ++phase) {
+      hipLaunchKernelGGL(stage_prep_kernel, dim3(grid4(rows)), dim3(256), 0, s, o, phase);
+      field_eval(w, n, xstage, true, phase != 7, rows, s);
+      hipLaunchKernelGGL(stage_finish_kernel, dim3(grid4(rows)), dim3(256), 0, s, o, phase);
+    }
+    if (read_active(active)) return -4;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+
+static void pad_rows(const float* src, int n, int d, int dp, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_el((size_t)n * dp)), dim3(256), 0, s, src, n, d, dp, dst);
+}
+static void unpad_rows(const float* src, int n, int d, int dp, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(unpad_rows_kernel, dim3(grid_el((size_t)n * d)), dim3(256), 0, s, src, n, d, dp, dst);
+}
+
+// transform_and_logdet / inverse_and_logdet (:206-242) on n samples, R rows per pass.  z: Hutchinson probes [n][d].
+static int transform(Ctx* w, const NetDev& n, int direction, float rtol, float atol, int max_attempts, const float* z, const float* in,
+                     int cnt, float* out, float* ldj, int* nsteps, hipStream_t s) {
+  for (int r0 = 0; r0 < cnt; r0 += w->R) {
+    const int rows = cnt - r0 < w->R ? cnt - r0 : w->R;
+    pad_rows(in + (size_t)r0 * n.d, rows, n.d, n.dp, w->Y, s);
+    pad_rows(z + (size_t)r0 * n.d, rows, n.d, n.dp, w->zp, s);
+    SolveArgs c{direction, rtol, atol, max_attempts, rows};
+    const int rc = solve(w, n, c, w->cond, s);
+    if (rc) return rc;
+    unpad_rows(w->Y, rows, n.d, n.dp, out + (size_t)r0 * n.d, s);
+    if (hipMemcpyAsync(ldj + r0, w->rs.ell, rows * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -4;
+    if (nsteps && hipMemcpyAsync(nsteps + r0, w->rs.natt, rows * sizeof(int), hipMemcpyDeviceToDevice, s) != hipSuccess) return -4;
+  }
+  return 0;
+}
+
+struct FlowCall {
+  int mode; Key2 key; uint32_t n_total, chain_offset; double beta; int rows;
+  float rtol, atol; int max_attempts;
+  const float *z_inv, *z_fwd, *zgen;          // [rows][d]: key_hutch2, key_hutch1, key_gen draws (:265 / :247)
+  float* pos; double* logp; float* grad; float* acc_prob; uint8_t* accepted; float* proposed; int* nsteps;
+};
+static int flow_step(Ctx* w, const NetDev& n, const FlowCall& c, hipStream_t s) {
+  const int rows = c.rows;
+  if (rows > w->R || rows % 16) return -3;
+  FlowGlue f; memset(&f, 0, sizeof f);
+  f.mode = c.mode; f.key = c.key; f.n_total = c.n_total; f.chain_offset = c.chain_offset; f.beta = c.beta;
+  f.rows = rows; f.d = n.d; f.dp = n.dp; f.T = n.T; f.Y = w->Y; f.zgen = c.zgen; f.ell = w->rs.ell; f.vol0 = w->vol0; f.lqref = w->lqref;
+  f.natt_tot = w->natt_tot; f.natt = w->rs.natt; f.KV = w->kv;
+  f.pos = c.pos; f.logp = c.logp; f.grad = c.grad; f.acc_prob = c.acc_prob; f.accepted = c.accepted; f.proposed = c.proposed; f.nsteps = c.nsteps;
+  // inverse solve from the current position (:267 / :251)
+  pad_rows(c.pos, rows, n.d, n.dp, w->Y, s);
+  pad_rows(c.z_inv, rows, n.d, n.dp, w->zp, s);
+  SolveArgs sa{-1, c.rtol, c.atol, c.max_attempts, rows};
+  int rc = solve(w, n, sa, w->cond, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(flow_propose_kernel, dim3(grid4(rows)), dim3(256), 0, s, f);
+  // forward solve of the proposal (:269 / :250)
+  pad_rows(c.z_fwd, rows, n.d, n.dp, w->zp, s);
+  sa.sign = 1;
+  rc = solve(w, n, sa, w->cond, s);
+  if (rc) return rc;
+  if (n.T.kind == MFM_TARGET_LGCP) launch_gemm(kinv(n, w->Y, w->kv, rows, true), s);
+  hipLaunchKernelGGL(flow_accept_kernel, dim3(grid4(rows)), dim3(256), 0, s, f);
+  return 0;
+}
+
+// v(x, t) and J z for cnt samples (mfm_vf_apply)
+__global__ void fourier_rows_kernel(const float* fr, int F, int F2p, const float* t, int rows, float* ffat) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b < rows) fourier_row(fr, F, F2p, (double)t[b], ffat + (size_t)b * F2p, lane);
+}
+static int vf_apply(Ctx* w, const NetDev& n, const float* x, const float* t, const float* tan, int cnt, float* v, float* jvp, hipStream_t s) {
+  for (int r0 = 0; r0 < cnt; r0 += w->R) {
+    const int rows = cnt - r0 < w->R ? cnt - r0 : w->R;
+    pad_rows(x + (size_t)r0 * n.d, rows, n.d, n.dp, w->cond, s);
+    if (tan) { pad_rows(tan + (size_t)r0 * n.d, rows, n.d, n.dp, w->zp, s); probe_setup(w, n, rows, s); }
+    hipLaunchKernelGGL(fourier_rows_kernel, dim3(grid4(rows)), dim3(256), 0, s, n.fourier, n.F, n.F2p, t + r0, rows, w->ffat);
+    field_eval(w, n, w->cond, tan != nullptr, true, rows, s);
+    hipLaunchKernelGGL(vf_out_kernel, dim3(grid_el((size_t)rows * n.d)), dim3(256), 0, s, rows, n.d, n.dp, w->out, w->outT, w->gate, w->gc, w->hz,
+                       v + (size_t)r0 * n.d, jvp ? jvp + (size_t)r0 * n.d : nullptr);
+  }
+  return 0;
+}
+
+}  // namespace wide

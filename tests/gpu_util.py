@@ -42,7 +42,7 @@ def target_block(dist):
     raise NotImplementedError(dist.kind)
 
 
-def make_ctx(dist, args, n_local=None, n_total=None, offset=0, fourier=None, params=None, max_eval=0):
+def make_ctx(dist, args, n_local=None, n_total=None, offset=0, fourier=None, params=None, max_eval=0, family=None):
     from mfm_amd import _lib
     n_local = args.num_chain if n_local is None else n_local
     ctx = _lib.Context(
@@ -52,7 +52,7 @@ def make_ctx(dist, args, n_local=None, n_total=None, offset=0, fourier=None, par
         hutch=int(args.hutchs), rtol=args.rtol, atol=args.atol, mxstep=int(args.mxstep), n_ts=args.n_ts,
         learning_rate=args.learning_rate, adam_b1=args.adam_beta1, adam_b2=args.adam_beta2, adam_eps=args.adam_epsilon,
         weight_decay=args.weight_decay, update_clip=args.gradient_clip, learning_iter=args.learning_iter,
-        warmup_steps=args.warmup_steps, max_eval_samples=max_eval)
+        warmup_steps=args.warmup_steps, max_eval_samples=max_eval, **({} if family is None else {"kernel_family": family}))
     kind, blk = target_block(dist)
     ctx.set_target(kind, blk)
     if fourier is not None:

@@ -1,0 +1,206 @@
+"""GPU parity of the WIDE kernel family (mfm_amd/csrc/wide.hip: per-layer MFMA GEMMs on HBM-resident activations; what
+serves the "pines" widths of the reference, multi_modal.py:89-96) against the float64 oracle -- the same cases and
+tolerances as the fused 16-chain family (tests/test_gpu_fm.py, test_gpu_ode.py), forced onto small shapes with
+kernel_family = WIDE, plus the real pines shape (32 x 32 grid, hidden width 1024)."""
+import numpy as np
+import pytest
+
+from oracle import flow, fm, mala, ode, prng, targets
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x, dtype=None):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda()
+
+
+def _relerr(a, b):
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def _setup(kind, d, B, hidden, F, **kw):
+    from tests import gpu_util as gu
+    if kind == "phi4":
+        return gu.phi4_setup(d=d, B=B, hidden=hidden, F=F, **kw)
+    return gu.lgcp_setup(n=int(np.sqrt(d)), B=B, hidden=hidden, F=F, **kw)
+
+
+def _wide_ctx(dist, args, model, params, **kw):
+    from mfm_amd import _lib
+    from tests import gpu_util as gu
+    return gu.make_ctx(dist, args, fourier=model.f, params=params, family=_lib.FAMILY_WIDE, **kw)
+
+
+# d = 40 / hidden 48 / F = 10: nothing is a multiple of 64 (tile guards); 1024 / 1024 is BASELINE configs[4]'s network
+@pytest.mark.parametrize("kind,d,B,hidden,F", [("phi4", 256, 64, 128, 128), ("phi4", 40, 16, 48, 10), ("lgcp", 64, 32, 32, 16),
+                                              ("lgcp", 1024, 32, 1024, 128)])
+def test_wide_fm_loss_and_grad_match_oracle(kind, d, B, hidden, F):
+    import torch
+    from tests import gpu_util as gu
+    args, dist, k, model, state = _setup(kind, d, B, hidden, F)
+    params = gu.rand_params(model, seed=3)
+    ctx = _wide_ctx(dist, args, model, params)
+    x32 = dist.init_params.astype(np.float32)
+    key = prng.PRNGKey(11)
+    loss_o, grads_o = fm.loss_and_grad(model, params, key, x32.astype(np.float64), args.sigma)
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.full((ctx.n_params,), float("nan"), device="cuda")
+    ctx.fm_loss_grad(key, _dev(x32), loss, grads)
+    assert abs(loss.item() - loss_o) <= 2e-5 * abs(loss_o), (loss.item(), loss_o)
+    g = gu.unflat_params(model, grads.cpu().numpy())
+    for i, (gg, go) in enumerate(zip(g, grads_o)):
+        for kk in ("kernel", "bias"):
+            assert np.isfinite(gg[kk]).all()                      # every element of the gradient vector is written
+            assert _relerr(gg[kk], go[kk].astype(np.float64)) < 2e-4, (i, kk, _relerr(gg[kk], go[kk]))
+    l2 = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ctx.fm_loss(key, _dev(x32), l2)
+    assert abs(l2.item() - loss_o) <= 2e-5 * abs(loss_o)
+    # optimizer step on the wide family's gradient: same AdamW kernels, parameters stay finite and move
+    p0 = ctx.get_params(); ctx.adamw_step(grads); p1 = ctx.get_params()
+    assert np.isfinite(p1).all() and np.abs(p1 - p0).max() > 0
+    ctx.close()
+
+
+def test_wide_matches_tile_family():
+    """The two kernel families are two schedules of the same arithmetic: same loss / gradient / field to float32 rounding."""
+    import torch
+    from mfm_amd import _lib
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.phi4_setup(d=256, B=64)
+    params = gu.rand_params(model, seed=5)
+    x32 = dist.init_params.astype(np.float32)
+    res = []
+    for fam in (_lib.FAMILY_TILE, _lib.FAMILY_WIDE):
+        ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, family=fam)
+        loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctx.n_params, device="cuda")
+        ctx.fm_loss_grad(prng.PRNGKey(7), _dev(x32), loss, grads)
+        res.append((loss.item(), grads.cpu().numpy()))
+        ctx.close()
+    assert abs(res[0][0] - res[1][0]) < 1e-6 * abs(res[0][0])
+    assert np.abs(res[0][1] - res[1][1]).max() < 2e-5 * np.abs(res[0][1]).max()
+
+
+@pytest.mark.parametrize("kind,d,hidden,F", [("phi4", 256, 128, 128), ("phi4", 40, 32, 10), ("lgcp", 64, 32, 16), ("lgcp", 1024, 1024, 128)])
+def test_wide_vector_field_and_jvp_match_oracle(kind, d, hidden, F):
+    import torch
+    from tests import gpu_util as gu
+    B = 32
+    args, dist, k, model, state = _setup(kind, d, B, hidden, F)
+    params = gu.rand_params(model, seed=6)
+    ctx = _wide_ctx(dist, args, model, params)
+    rng = np.random.default_rng(1)
+    x = dist.init_params.astype(np.float32); t = rng.uniform(0, 1, B).astype(np.float32)
+    z = rng.standard_normal((B, d)).astype(np.float32)
+    v_o, jv_o = model.forward(params, x.astype(np.float64), t.astype(np.float64), tangent=z.astype(np.float64))
+    v = torch.empty(B, d, device="cuda"); jv = torch.empty(B, d, device="cuda")
+    ctx.vf_apply(_dev(x), _dev(t), v, _dev(z), jv)
+    assert _relerr(v.cpu().numpy(), v_o) < 2e-5
+    assert _relerr(jv.cpu().numpy(), jv_o) < 2e-5
+    v2 = torch.empty(B, d, device="cuda")
+    ctx.vf_apply(_dev(x), _dev(t), v2)
+    assert _relerr(v2.cpu().numpy(), v_o) < 2e-5
+    ctx.close()
+
+
+def _tamed(model, seed, out_scale, gate_scale):
+    from tests import gpu_util as gu
+    params = gu.rand_params(model, seed=seed, out_scale=out_scale)
+    params[4]["kernel"] *= gate_scale; params[4]["bias"] *= gate_scale
+    return params
+
+
+@pytest.mark.parametrize("kind,d,hidden,F,gs", [("phi4", 64, 32, 16, 1e-3), ("lgcp", 64, 32, 16, 0.05)])
+def test_wide_ode_transform_and_inverse_match_oracle(kind, d, hidden, F, gs):
+    import torch
+    B = 32
+    args, dist, k, model, state = _setup(kind, d, B, hidden, F)
+    params = _tamed(model, 9, 0.5 if kind == "phi4" else 0.3, gs)
+    ctx = _wide_ctx(dist, args, model, params)
+    x32 = dist.init_params.astype(np.float32)
+    keys = prng.split(prng.PRNGKey(21), B)
+    for direction, fn in ((1, ode.transform_and_logdet), (-1, ode.inverse_and_logdet)):
+        st = {}
+        y_o, l_o = fn(model, params, keys, x32.astype(np.float64), True, args.rtol, args.atol, args.mxstep, stats=st)
+        out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda")
+        ns = torch.empty(B, dtype=torch.int32, device="cuda")
+        ctx.ode_transform(direction, _dev(x32), out, ldj, keys=_dev(keys.astype(np.uint32).view(np.int32)), nsteps=ns)
+        y, l, n = out.cpu().numpy(), ldj.cpu().numpy(), ns.cpu().numpy()
+        assert np.abs(y - x32).max() > 1e-2
+        assert np.abs(y - y_o).max() < 2e-3 * max(1.0, np.abs(y_o).max()), np.abs(y - y_o).max()
+        assert np.abs(y - y_o).mean() < 1e-4 * max(1.0, np.abs(y_o).max())
+        assert np.abs(l - l_o).max() < 5e-2 * max(1.0, np.abs(l_o).max())
+        dn = np.abs(n - st["n_attempted"])
+        assert (dn == 0).mean() >= 0.5 and abs(n.mean() - st["n_attempted"].mean()) < 0.1 * st["n_attempted"].mean(), (n, st["n_attempted"])
+    out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda")
+    ctx.ode_transform(1, _dev(x32), out, ldj, key=prng.PRNGKey(4))
+    back = torch.empty(B, d, device="cuda"); l2 = torch.empty(B, device="cuda")
+    ctx.ode_transform(-1, out, back, l2, key=prng.PRNGKey(4))             # inverse(transform(x)) == x
+    assert np.abs(back.cpu().numpy() - x32).max() < 2e-3 * max(1.0, np.abs(x32).max())
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind,d,hidden,F,gs,mode", [("lgcp", 64, 32, 16, 0.05, "rwmh"), ("phi4", 64, 32, 16, 1e-3, "imh")])
+def test_wide_flow_step_matches_oracle(kind, d, hidden, F, gs, mode):
+    import torch
+    from mfm_amd import _lib
+    B = 32
+    args, dist, k, model, state = _setup(kind, d, B, hidden, F)
+    params = _tamed(model, 9, 0.3 if kind == "lgcp" else 0.05, gs)
+    ctx = _wide_ctx(dist, args, model, params)
+    x32 = dist.init_params.astype(np.float32)
+    beta = 0.7
+    vg = targets.Tempered(dist, beta).value_and_grad
+    pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+    ctx.mala_init(pos, beta, logp, grad)
+    st = mala.MALAState(x32.astype(np.float64), logp.cpu().numpy(), grad.cpu().numpy().astype(np.float64))
+    key = prng.PRNGKey(31)
+    stats = {}
+    step = flow.rwmh_step if mode == "rwmh" else flow.imh_step
+    new, info = step(prng.split(key, B), st, vg, model, params, args, stats)
+    acc = torch.empty(B, device="cuda"); isacc = torch.empty(B, dtype=torch.uint8, device="cuda")
+    prop = torch.empty(B, d, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
+    ctx.flow_step(_lib.FLOW_RWMH if mode == "rwmh" else _lib.FLOW_IMH, key, beta, pos, logp, grad, acc, isacc, prop, ns)
+    p = prop.cpu().numpy()
+    assert np.abs(p - info.proposed_position).max() < 5e-3 * max(1.0, np.abs(p).max())
+    with np.errstate(divide="ignore"):
+        la_g, la_o = np.log(acc.cpu().numpy().astype(np.float64)), np.log(info.acceptance_rate)
+    fin = np.isfinite(la_g) & np.isfinite(la_o)
+    if fin.any():
+        assert np.abs(la_g[fin] - la_o[fin]).max() < 0.5
+    sure = ~fin | (np.abs(la_o) > 1)
+    np.testing.assert_array_equal(isacc.cpu().numpy().astype(bool)[sure], info.is_accepted[sure])
+    same = isacc.cpu().numpy().astype(bool) == info.is_accepted
+    np.testing.assert_allclose(logp.cpu().numpy()[same], new.logdensity[same], rtol=1e-4, atol=5e-2)
+    np.testing.assert_allclose(grad.cpu().numpy()[same], new.logdensity_grad[same], rtol=1e-3, atol=5e-2)
+    if mode == "rwmh":
+        tot = stats["n_att_inv"] + stats["n_att_fwd"]
+        assert abs(ns.float().mean().item() - tot.mean()) < 0.1 * tot.mean()
+    ctx.close()
+
+
+def test_pines_shape_is_served_by_the_wide_family_automatically():
+    """BASELINE configs[4]: d = 1024 (32 x 32 grid), hidden width 1024 does not fit the 16-chain LDS tile: mfm_create picks
+    the wide family by itself.  One MALA step + training step + CNF round trip at the full width."""
+    import torch
+    from tests import gpu_util as gu
+    B, d = 64, 1024
+    args, dist, k, model, state = gu.lgcp_setup(n=32, B=B, hidden=1024, F=128)
+    params = _tamed(model, 2, 0.2, 0.02)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)           # kernel_family = AUTO
+    x32 = dist.init_params.astype(np.float32)
+    pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+    ctx.mala_init(pos, 1.0, logp, grad)
+    vg = targets.Tempered(dist, 1.0).value_and_grad
+    st = mala.init(x32.astype(np.float64), vg)
+    np.testing.assert_allclose(logp.cpu().numpy(), st.logdensity, rtol=1e-5)
+    acc = torch.empty(B, device="cuda")
+    ctx.mala_step(prng.PRNGKey(3), 1.0, args.step_size, pos, logp, grad, acc)
+    new, info, _ = mala.kernel(prng.split(prng.PRNGKey(3), B), st, vg, args.step_size)
+    np.testing.assert_allclose(acc.cpu().numpy(), info.acceptance_rate, atol=5e-3)
+    out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
+    ctx.ode_transform(1, _dev(x32), out, ldj, key=prng.PRNGKey(4), nsteps=ns)
+    assert np.abs(out.cpu().numpy() - x32).max() > 1e-2 and ns.min().item() >= 1
+    back = torch.empty(B, d, device="cuda"); l2 = torch.empty(B, device="cuda")
+    ctx.ode_transform(-1, out, back, l2, key=prng.PRNGKey(4))
+    assert np.abs(back.cpu().numpy() - x32).max() < 2e-3 * max(1.0, np.abs(x32).max())
+    ctx.close()
