@@ -29,22 +29,30 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 (matrix), de
 PEAK_HBM_GBS = 8000.0
 
 
-def make_args(n_total, learning_iter):
+WORKLOADS = {   # name: (example, dim, hidden width, MALA step size, chains per GPU, K)
+    "phi-four": ("phi-four", 256, 128, 1e-4, 4096, 100),       # BASELINE configs[2] (the headline; configs[3] = 8 x this)
+    "pines": ("pines", 1024, 1024, 1e-2, 1024, 100),            # BASELINE configs[4]: 8192 chains over 8 GPUs
+}
+
+
+def make_args(n_total, learning_iter, workload="phi-four"):
     from types import SimpleNamespace
+    ex, dim, h, eps, _, K = WORKLOADS[workload]
     return SimpleNamespace(
-        example="phi-four", dim=256, num_chain=n_total, seed=1, sigma=1e-4, fourier_dim=128, fourier_std=1.0, hutchs=True,
-        ref_dist="stdgauss", cond_flow=True, ot_cond_flow=False, num_importance_samples=0, mcmc_per_flow_steps=100.0,
+        example=ex, dim=dim, num_chain=n_total, seed=1, sigma=1e-4, fourier_dim=128, fourier_std=1.0, hutchs=True,
+        ref_dist="stdgauss", cond_flow=True, ot_cond_flow=False, num_importance_samples=0, mcmc_per_flow_steps=float(K),
         learning_iter=learning_iter, eval_iter=1, alpha=0.95, anneal_iter=200, num_anneal_temp=200, non_linearity="relu",
-        hidden_x=[128, 128], hidden_t=[128, 128], hidden_xt=[128, 128], step_size=1e-4, learning_rate=1e-3,
+        hidden_x=[h, h], hidden_t=[h, h], hidden_xt=[h, h], step_size=eps, learning_rate=1e-3,
         weight_decay=1e-4, adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8, gradient_clip=1.0, warmup_steps=0,
         rtol=1e-5, atol=1e-5, mxstep=1000.0)
 
 
-def flops_per_chain(d=256, h=128, F=128):
+def flops_per_chain(d=256, h=128, F=128, lgcp=False):
     P_w = 2 * F * h + 5 * h * h + 3 * d * h                 # all kernels
     P_x = 2 * d * h + 3 * h * h                             # weights on the x-tangent path
     dgrad = 2 * d * h + 5 * h * h                           # out, gate (d*h each), j1 (2h*h), j2, x2, t2 (h*h each)
-    return dict(fwd=2 * P_w, fm_fwd_bwd=2 * P_w + 2 * dgrad, wgrad=2 * P_w, field_eval=2 * P_w + 2 * P_x)
+    kinv = 2 * d * d if lgcp else 0                         # grad log pi of the LGCP target: one K^-1 contraction per evaluation
+    return dict(fwd=2 * P_w + kinv, fm_fwd_bwd=2 * P_w + 2 * dgrad + kinv, wgrad=2 * P_w, field_eval=2 * P_w + 2 * P_x + kinv)
 
 
 def cpu_baseline(params_flat, fourier, steps_mala, chains, seed=1):
@@ -107,7 +115,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=202)       # two full (K+1)-cycles
     ap.add_argument("--warmup", type=int, default=101)      # one full cycle, incl. one flow step
-    ap.add_argument("--chains-per-gpu", type=int, default=4096)
+    ap.add_argument("--chains-per-gpu", type=int, default=0)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="phi-four",
+                    help="phi-four: BASELINE configs[2] (the metric's configuration, default); pines: configs[4] per-GPU shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -126,12 +136,17 @@ def main():
 
     from mfm_amd import exe_flow_matching as E, random as jr
     from mfm_amd._lib import FLOW_RWMH
-    from mfm_amd.distributions import PhiFour
+    from mfm_amd.distributions import LogGaussianCoxPines, PhiFour
     from mfm_amd.engine import Engine
 
+    wl_example, wl_dim, wl_h, _, wl_chains, wl_K = WORKLOADS[a.workload]
+    if not a.chains_per_gpu:
+        a.chains_per_gpu = wl_chains
+    if a.workload == "pines" and a.steps == 202 and a.warmup == 101:      # a pines flow step is seconds: one cycle, short warm-up
+        a.steps, a.warmup = 101, 100
     n_total = a.chains_per_gpu * world            # weak scaling: per-GPU work fixed
-    args = make_args(n_total, learning_iter=10000)
-    dist = PhiFour(256)
+    args = make_args(n_total, learning_iter=10000, workload=a.workload)
+    dist = PhiFour(wl_dim) if a.workload == "phi-four" else LogGaussianCoxPines(wl_dim)
     key_target, key_sample, key_init, key_dist, key_fourier, key_gen = jr.split(jr.PRNGKey(args.seed), 6)
     dist.initialize_model(key_dist, n_total)
     fourier = args.fourier_std * jr.normal(key_fourier, (args.fourier_dim,))
@@ -192,7 +207,7 @@ def main():
     value = n_total * a.steps / dt
 
     if rank == 0:
-        fl = flops_per_chain()
+        fl = flops_per_chain(wl_dim, wl_h, 128, lgcp=a.workload == "pines")
         B = eng.n_local
         natt_mean = natt_sum.item() / max(1, n_flow[0] * n_total)               # attempted Dopri5 steps per chain per flow step (2 solves)
         alg = {  # algorithmic FLOPs per launch
@@ -204,23 +219,24 @@ def main():
         if dom is not None and prof[dom]["launches"]:
             avg_ms = prof[dom]["ms"] / prof[dom]["launches"]
             ach = alg[dom] / (avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic(dom)
+            traffic, traffic_src = pmc_traffic(dom) if a.workload == "phi-four" else (None, None)
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(avg_ms, 5), "algorithmic_flop_per_launch": alg[dom]}
         out = {
-            "metric": "MFM train-steps/s x chains (phi-four d=256, 4096 chains per GPU)", "value": round(value, 1),
+            "metric": "MFM train-steps/s x chains (phi-four d=256, 4096 chains per GPU)" if a.workload == "phi-four" else "MFM train-steps/s x chains (pines d=1024, 1024 chains per GPU)", "value": round(value, 1),
             "unit": "chain-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "phi-four d=256, 4096 chains/GPU, mcmc_per_flow_steps=100, --hutch, beta=1 (BASELINE configs[2])",
+            "config": {"workload": ("phi-four d=256, 4096 chains/GPU, mcmc_per_flow_steps=100, --hutch, beta=1 (BASELINE configs[2])" if a.workload == "phi-four" else
+                                    f"pines LGCP d={wl_dim} (32x32), hidden {wl_h}, {a.chains_per_gpu} chains/GPU, mcmc_per_flow_steps=100, --hutch, beta=1 (BASELINE configs[4] per-GPU shape; wide kernel family)"),
                        "chains_total": n_total, "chains_per_gpu": B, "parallelism": f"chains sharded x{world}, RCCL grad all-reduce" if world > 1 else "single GPU",
                        "flow_steps_timed": n_flow[0], "dopri_attempts_per_chain_per_flow_step": round(natt_mean, 2),
-                       "chain_dim_updates_per_s": round(value * 256, 1)},
+                       "chain_dim_updates_per_s": round(value * wl_dim, 1)},
             "roofline": roof,
             "kernels_ms_total": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in prof.items()},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload == "phi-four":
             try:
                 from threadpoolctl import threadpool_limits
                 cores = os.cpu_count() or 1

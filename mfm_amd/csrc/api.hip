@@ -329,6 +329,16 @@ static MalaArgs mala_args(mfm_ctx* x, double beta) {
   return a;
 }
 
+// LGCP dimensions beyond the fused tile kernel (d > 1024) go through the wide family's propose / K^-1 GEMM / accept split
+static int wide_mala_lgcp(mfm_ctx* x, const LgcpArgs& l) {
+  if (!x->wide) return -3;
+  wide::LgcpMala m; memset(&m, 0, sizeof m);
+  m.T = l.T; m.mode = l.mode; m.key = l.key; m.n_total = l.n_total; m.chain_offset = l.chain_offset; m.rows = l.B; m.d = l.T.dim; m.dp = l.dp;
+  m.beta = l.beta; m.eps = l.eps; m.textbook = l.textbook;
+  m.pos = l.pos; m.logp = l.logp; m.grad = l.grad; m.acc_prob = l.acc_prob; m.accepted = l.accepted; m.proposed = l.proposed; m.prop_weight = l.prop_weight;
+  return wide::mala_lgcp(x->wide, x->net, m, x->stream);
+}
+
 extern "C" int mfm_mala_init(mfm_ctx* x, const float* d_pos, double beta, double* d_logp, float* d_grad) {
   NEED_TARGET();
   if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
@@ -336,7 +346,7 @@ extern "C" int mfm_mala_init(mfm_ctx* x, const float* d_pos, double beta, double
     LgcpArgs l; memset(&l, 0, sizeof l);
     l.T = x->net.T; l.dp = x->net.dp; l.mode = 0; l.n_total = x->cfg.n_chain_total; l.chain_offset = x->cfg.chain_offset;
     l.B = x->cfg.n_chain_local; l.beta = beta; l.eps = 1.0; l.pos = const_cast<float*>(d_pos); l.logp = d_logp; l.grad = d_grad;
-    if (launch_mala_lgcp(l, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large for the LGCP MALA kernel", x->cfg.dim);
+    if (launch_mala_lgcp(l, x->stream) && wide_mala_lgcp(x, l)) return fail(MFM_ETOOLARGE, "dim %d too large for the LGCP MALA kernel", x->cfg.dim);
     LAUNCHCHK();
     return MFM_OK;
   }
@@ -358,7 +368,7 @@ extern "C" int mfm_mala_step(mfm_ctx* x, uint32_t k0, uint32_t k1, double beta, 
     l.chain_offset = x->cfg.chain_offset; l.B = x->cfg.n_chain_local; l.beta = beta; l.eps = step; l.textbook = textbook;
     l.pos = d_pos; l.logp = d_logp; l.grad = d_grad; l.acc_prob = d_acc; l.accepted = d_isacc; l.proposed = d_prop; l.prop_weight = d_pw;
     ProfScope ps_(x, PROF_MALA);
-    if (launch_mala_lgcp(l, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large for the LGCP MALA kernel", x->cfg.dim);
+    if (launch_mala_lgcp(l, x->stream) && wide_mala_lgcp(x, l)) return fail(MFM_ETOOLARGE, "dim %d too large for the LGCP MALA kernel", x->cfg.dim);
     LAUNCHCHK();
     return MFM_OK;
   }

@@ -662,6 +662,82 @@ __global__ __launch_bounds__(256) void flow_accept_kernel(FlowGlue a) {
   }
 }
 
+// ---- MALA step / init for the LGCP target beyond the fused tile kernel's dimension (lgcp.hip handles d <= 1024; the
+//      reference's own pines default is the 40 x 40 grid, multi_modal.py:89).  Same arithmetic as mala_lgcp_kernel, split
+//      around the K^-1 GEMM: propose -> K^-1 (x' - mu) -> energies / accept. ----
+struct LgcpMala {
+  TargetDev T; int mode; Key2 key; uint32_t n_total, chain_offset; int rows, d, dp; double beta, eps; int textbook;
+  float* Y; const float* KV; double* th1;
+  float* pos; double* logp; float* grad; float* acc_prob; uint8_t* accepted; float* proposed; float* prop_weight;
+};
+__global__ __launch_bounds__(256) void lgcp_propose_kernel(LgcpMala a) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.rows) return;
+  const Key2 kb = split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);           // exe_flow_matching.py:303
+  const Key2 k_int = split_at(kb, 2, 0);                                              // mala.py:93
+  const double s2e = sqrt(2.0 * a.eps);
+  double th1 = 0.0;
+  for (int col = lane; col < a.dp; col += 64) {
+    float xn = 0.f;
+    if (col < a.d) {
+      const size_t o = (size_t)b * a.d + col;
+      const float x = a.pos[o];
+      if (a.mode == 1) {
+        const double th = s2e * normal64(k_int, (uint32_t)col, (uint32_t)a.d);        // util.py:80-82
+        th1 += th * th;
+        xn = (float)((double)x + a.eps * (double)a.grad[o] + th);                     // diffusions.py:25-30
+      } else {
+        xn = x;
+      }
+    }
+    a.Y[(size_t)b * a.dp + col] = xn;
+  }
+  th1 = wave_sum(th1);
+  if (lane == 0) a.th1[b] = th1;
+}
+__global__ __launch_bounds__(256) void lgcp_accept_kernel(LgcpMala a) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.rows) return;
+  double lik = 0.0, quad = 0.0, th2 = 0.0;
+  for (int col = lane; col < a.d; col += 64) {
+    const float xv = a.Y[(size_t)b * a.dp + col], y = a.KV[(size_t)b * a.dp + col], ex = expf(xv);
+    const float gv = (float)a.beta * (a.T.counts[col] - a.T.poisson_a * ex) - y;
+    lik += (double)xv * (double)a.T.counts[col] - (double)a.T.poisson_a * (double)ex;
+    quad += (double)(xv - a.T.mu) * (double)y;
+    const double t = (double)a.pos[(size_t)b * a.d + col] - (double)xv - a.eps * (double)gv;
+    th2 += t * t;
+  }
+  lik = wave_sum(lik); quad = wave_sum(quad); th2 = wave_sum(th2);
+  const double lpn = a.beta * lik - 0.5 * quad + (double)a.T.log_norm;
+  bool acc = true;
+  if (a.mode == 1) {
+    const double lp = a.logp[b], inv4e = 0.25 / a.eps;
+    const double new_E = -lp + inv4e * a.th1[b], prev_E = -lpn + inv4e * th2;      // mala.py:68-79, proposal.py:157-158
+    double delta = prev_E - new_E;                                                 // proposal.py:104
+    if (a.textbook) delta = -delta;
+    if (isnan(delta)) delta = -INFINITY;                                           // proposal.py:105
+    const double p = fmin(exp(delta), 1.0);                                        // proposal.py:178
+    const Key2 kb = split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);
+    acc = uniform01(split_at(kb, 2, 1), 0, 1) < p;                                 // proposal.py:179
+    if (lane == 0) {
+      if (a.acc_prob) a.acc_prob[b] = (float)p;
+      if (a.accepted) a.accepted[b] = acc ? 1 : 0;
+      if (a.prop_weight) a.prop_weight[b] = (float)exp(lpn + inv4e * th2);         // mala.py:104-113
+    }
+  }
+  for (int col = lane; col < a.d; col += 64) {
+    const size_t o = (size_t)b * a.d + col;
+    const float xv = a.Y[(size_t)b * a.dp + col];
+    if (a.mode == 1 && a.proposed) a.proposed[o] = xv;
+    if (acc) {
+      const float gv = (float)a.beta * (a.T.counts[col] - a.T.poisson_a * expf(xv)) - a.KV[(size_t)b * a.dp + col];
+      if (a.mode == 1) a.pos[o] = xv;
+      a.grad[o] = gv;
+    }
+  }
+  if (lane == 0 && acc) a.logp[b] = lpn;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -962,6 +1038,16 @@ static int vf_apply(Ctx* w, const NetDev& n, const float* x, const float* t, con
     hipLaunchKernelGGL(vf_out_kernel, dim3(grid_el((size_t)rows * n.d)), dim3(256), 0, s, rows, n.d, n.dp, w->out, w->outT, w->gate, w->gc, w->hz,
                        v + (size_t)r0 * n.d, jvp ? jvp + (size_t)r0 * n.d : nullptr);
   }
+  return 0;
+}
+
+
+static int mala_lgcp(Ctx* w, const NetDev& n, LgcpMala a, hipStream_t s) {
+  if (a.rows > w->R) return -3;
+  a.Y = w->Y; a.KV = w->kv; a.th1 = reinterpret_cast<double*>(w->K);          // K (stage buffer) is free outside a solve
+  hipLaunchKernelGGL(lgcp_propose_kernel, dim3(grid4(a.rows)), dim3(256), 0, s, a);
+  launch_gemm(kinv(n, w->Y, w->kv, (a.rows + 15) & ~15, true), s);
+  hipLaunchKernelGGL(lgcp_accept_kernel, dim3(grid4(a.rows)), dim3(256), 0, s, a);
   return 0;
 }
 

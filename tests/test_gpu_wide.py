@@ -204,3 +204,49 @@ def test_pines_shape_is_served_by_the_wide_family_automatically():
     ctx.ode_transform(-1, out, back, l2, key=prng.PRNGKey(4))
     assert np.abs(back.cpu().numpy() - x32).max() < 2e-3 * max(1.0, np.abs(x32).max())
     ctx.close()
+
+
+def test_wide_lgcp_mala_at_the_reference_default_grid():
+    """The reference's own pines default is the 40 x 40 grid (multi_modal.py:89, d = 1600): beyond the fused LGCP MALA tile,
+    served by the wide family's propose / K^-1 GEMM / accept split.  MALAState and MALAInfo vs the oracle."""
+    import torch
+    from tests import gpu_util as gu
+    B, d = 32, 1600
+    args, dist, k, model, state = gu.lgcp_setup(n=40, B=B, hidden=1024, F=128)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=state.params)
+    x32 = dist.init_params.astype(np.float32)
+    beta = 0.6
+    pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+    ctx.mala_init(pos, beta, logp, grad)
+    vg = targets.Tempered(dist, beta).value_and_grad
+    st = mala.init(x32.astype(np.float64), vg)
+    np.testing.assert_allclose(logp.cpu().numpy(), st.logdensity, rtol=1e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), st.logdensity_grad, rtol=1e-3, atol=2e-3)
+    st = mala.MALAState(st.position, logp.cpu().numpy(), grad.cpu().numpy().astype(np.float64))
+    key = prng.PRNGKey(5)
+    acc = torch.empty(B, device="cuda"); isacc = torch.empty(B, dtype=torch.uint8, device="cuda"); prop = torch.empty(B, d, device="cuda")
+    ctx.mala_step(key, beta, args.step_size, pos, logp, grad, acc, isacc, prop)
+    new, info, u = mala.kernel(prng.split(key, B), st, vg, args.step_size)
+    np.testing.assert_allclose(prop.cpu().numpy(), info.proposed_position, atol=1e-5)
+    np.testing.assert_allclose(acc.cpu().numpy(), info.acceptance_rate, atol=5e-3)
+    sure = np.abs(u - info.acceptance_rate) > 1e-2
+    np.testing.assert_array_equal(isacc.cpu().numpy().astype(bool)[sure], info.is_accepted[sure])
+    same = isacc.cpu().numpy().astype(bool) == info.is_accepted
+    np.testing.assert_allclose(pos.cpu().numpy()[same], new.position[same], atol=1e-5)
+    np.testing.assert_allclose(logp.cpu().numpy()[same], new.logdensity[same], rtol=1e-5)
+    ctx.close()
+
+
+def test_wide_pines_loop_matches_oracle(monkeypatch):
+    """The whole loop (annealing, MALA, flow-MH steps, training) on the LGCP target through the wide family."""
+    from mfm_amd import _lib
+    from tests.test_gpu_loop import _run_both
+    monkeypatch.setenv("MFM_KERNEL_FAMILY", str(_lib.FAMILY_WIDE))
+    out, res, ex = _run_both("pines", 64, 32, 8, 3, step_size=0.01)
+    assert ex["engine"].ctx.cfg.kernel_family == _lib.FAMILY_WIDE
+    tr, m = out["trace"], ex["metrics"]
+    np.testing.assert_allclose(m[:3, 0], tr["loss"][:3], rtol=1e-5)
+    np.testing.assert_allclose(m[:, 0], tr["loss"], rtol=2e-2)
+    np.testing.assert_allclose(ex["betas"], tr["beta"], rtol=2e-3)
+    assert np.isfinite(res).all()
+    ex["engine"].close()
