@@ -94,6 +94,13 @@ int mfm_mala_step(mfm_ctx* ctx, uint32_t key0, uint32_t key1, double beta, doubl
                   float* d_pos, double* d_logp, float* d_grad,
                   float* d_acceptance_rate, uint8_t* d_is_accepted, float* d_proposed_position,
                   float* d_proposed_weight);
+/* the same kernel for a caller that vmaps over its OWN per-chain keys (bblackjax/smc/base.py:122-123 ->
+ * tempered.py:126-137): d_keys is uint32[n_chain_local][2], chain b uses d_keys[b] where mfm_mala_step uses
+ * split(key, n_chain_total)[chain_offset + b]. */
+int mfm_mala_step_keys(mfm_ctx* ctx, const uint32_t* d_keys, double beta, double step_size, int textbook,
+                       float* d_pos, double* d_logp, float* d_grad,
+                       float* d_acceptance_rate, uint8_t* d_is_accepted, float* d_proposed_position,
+                       float* d_proposed_weight);
 /* vmap(dist.loglik) (exe_flow_matching.py:418) */
 int mfm_loglik(mfm_ctx* ctx, const float* d_pos, double* d_out);
 
@@ -149,6 +156,18 @@ int mfm_cis_select(mfm_ctx* ctx, uint32_t key0, uint32_t key1, int n_is, const f
  *      returns it).  beta is the reference's argument (default -1/2).  Synchronise; results on the host. ---- */
 int mfm_stein_disc(mfm_ctx* ctx, const float* d_x, const float* d_grad, int n, double beta, double h_u_v[2]);
 int mfm_max_mean_disc(mfm_ctx* ctx, const float* d_x, const float* d_y, int m, double* h_out);
+
+/* ---- adaptive tempered SMC baseline on the same MALA kernels (exe_others.py:79-111 -> bblackjax/smc/*) ---------------
+ * mfm_smc_delta   : ess.ess_solver + solver.dichotomy (ess.py:46-89, solver.py:20-82) on n log-likelihoods, clipped to
+ *                   [0, max_delta] (adaptive_tempered.py:61-72); synchronises, result on the host.
+ * mfm_smc_weights : weights = softmax(delta * loglik) (float64, [n]) and log normalising constant (base.py:125-128).
+ * mfm_smc_resample: resampling.systematic (resampling.py:50-52,124-135); d_scratch: n doubles (the cumulative sum).
+ * mfm_gather_rows : particles[idx] (base.py:120); dst != src. */
+int mfm_smc_delta(mfm_ctx* ctx, const double* d_loglik, int n, double target_ess, double max_delta, double* h_delta);
+int mfm_smc_weights(mfm_ctx* ctx, const double* d_loglik, int n, double delta, double* d_weights, double* h_lognorm);
+int mfm_smc_resample(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const double* d_weights, int n, double* d_scratch,
+                     int32_t* d_idx);
+int mfm_gather_rows(mfm_ctx* ctx, const float* d_src, const int32_t* d_idx, int n, int dim, float* d_dst);
 
 int mfm_profile(mfm_ctx* ctx, int enable);                      /* enable resets the record */
 int mfm_profile_read(mfm_ctx* ctx, double ms_total[8], int64_t launches[8]);   /* synchronises */

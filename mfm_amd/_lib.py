@@ -51,7 +51,12 @@ _SIGS = {
     "mfm_reset_optimizer": (C.c_int, [_P]),
     "mfm_mala_init": (C.c_int, [_P, _P, C.c_double, _P, _P]),
     "mfm_mala_step": (C.c_int, [_P, _U32, _U32, C.c_double, C.c_double, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "mfm_mala_step_keys": (C.c_int, [_P, _P, C.c_double, C.c_double, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "mfm_loglik": (C.c_int, [_P, _P, _P]),
+    "mfm_smc_delta": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+    "mfm_smc_weights": (C.c_int, [_P, _P, C.c_int, C.c_double, _P, C.POINTER(C.c_double)]),
+    "mfm_smc_resample": (C.c_int, [_P, _U32, _U32, _P, C.c_int, _P, _P]),
+    "mfm_gather_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "mfm_fm_loss_grad": (C.c_int, [_P, _U32, _U32, _P, _P, _P]),
     "mfm_fm_loss": (C.c_int, [_P, _U32, _U32, _P, C.c_int, C.c_int, C.c_int, _P]),
     "mfm_adamw_step": (C.c_int, [_P, _P]),
@@ -198,8 +203,32 @@ class Context:
                                     _ptr(pos, F32), _ptr(logp, F64), _ptr(grad, F32), _ptr(acc, F32), _ptr(is_acc, U8),
                                     _ptr(proposed, F32), _ptr(weight, F32)))
 
+    def mala_step_keys(self, keys, beta, step_size, pos, logp, grad, acc=None, is_acc=None, proposed=None, weight=None,
+                       textbook=False):
+        """``keys``: int32/uint32 device tensor [n_chain_local, 2], one key per chain (the caller vmaps over its own keys)."""
+        _chk(self.lib.mfm_mala_step_keys(self.h, _ptr(keys, I32), float(beta), float(step_size), int(textbook),
+                                         _ptr(pos, F32), _ptr(logp, F64), _ptr(grad, F32), _ptr(acc, F32), _ptr(is_acc, U8),
+                                         _ptr(proposed, F32), _ptr(weight, F32)))
+
     def loglik(self, pos, out):
         _chk(self.lib.mfm_loglik(self.h, _ptr(pos, F32), _ptr(out, F64)))
+
+    # ---- adaptive tempered SMC pieces (bblackjax/smc) -----------------------------------------------------------
+    def smc_delta(self, logliks, target_ess, max_delta):
+        out = C.c_double()
+        _chk(self.lib.mfm_smc_delta(self.h, _ptr(logliks, F64), logliks.shape[0], float(target_ess), float(max_delta), C.byref(out)))
+        return out.value
+
+    def smc_weights(self, logliks, delta, weights):
+        out = C.c_double()
+        _chk(self.lib.mfm_smc_weights(self.h, _ptr(logliks, F64), logliks.shape[0], float(delta), _ptr(weights, F64), C.byref(out)))
+        return out.value
+
+    def smc_resample(self, key, weights, scratch, idx):
+        _chk(self.lib.mfm_smc_resample(self.h, int(key[0]), int(key[1]), _ptr(weights, F64), weights.shape[0], _ptr(scratch, F64), _ptr(idx, I32)))
+
+    def gather_rows(self, src, idx, dst):
+        _chk(self.lib.mfm_gather_rows(self.h, _ptr(src, F32), _ptr(idx, I32), src.shape[0], src.shape[1], _ptr(dst, F32)))
 
     def fm_loss_grad(self, key, pos, loss, grads):
         self._p()

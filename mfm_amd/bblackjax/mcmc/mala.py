@@ -8,11 +8,14 @@ Same names and argument meaning as the reference (``MALAState`` / ``MALAInfo`` `
   ``state.position`` is ``[n_chain_local, dim]`` (CUDA float32) and ``rng_key`` is the key BEFORE that split;
 * ``logdensity_fn`` must be built from ``dist.loglik / dist.logprior / dist.logprob`` of one of the built targets
   (``mfm_amd.distributions``); arbitrary closures raise ``NotImplementedError`` (no CPU fallback);
-* ``logdensity`` is float64, positions and gradients float32.
+* ``logdensity`` is float64, positions and gradients float32;
+* a caller that vmaps over its OWN keys (``bblackjax/smc/base.py:122-123``) passes ``rng_key`` of shape ``[n_chain, 2]``.
 
 The acceptance rule is the reference's AS WRITTEN.  ``build_kernel(textbook=True)`` flips it.
 """
 from typing import Callable, NamedTuple
+
+import numpy as np
 
 from ...distributions import resolve_logdensity
 from ..base import SamplingAlgorithm
@@ -60,7 +63,11 @@ def build_kernel(textbook: bool = False):
         isacc = t.empty(n, device=pos.device, dtype=t.uint8)
         prop = t.empty_like(pos)
         w = t.empty(n, device=pos.device, dtype=t.float32)
-        eng.ctx.mala_step(rng_key, beta, step_size, pos, logp, grad, acc, isacc, prop, w, textbook=textbook)
+        if getattr(rng_key, "ndim", 1) == 2:          # [n_chain, 2]: the caller already split its key per chain (smc/base.py:122-123)
+            keys = rng_key if t.is_tensor(rng_key) else t.as_tensor(np.ascontiguousarray(rng_key, dtype=np.uint32).view(np.int32), device=pos.device)
+            eng.ctx.mala_step_keys(keys, beta, step_size, pos, logp, grad, acc, isacc, prop, w, textbook=textbook)
+        else:
+            eng.ctx.mala_step(rng_key, beta, step_size, pos, logp, grad, acc, isacc, prop, w, textbook=textbook)
         return MALAState(pos, logp, grad), MALAInfo(acc, isacc.bool(), prop, w)
 
     return kernel

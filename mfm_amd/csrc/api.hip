@@ -17,6 +17,7 @@
 #include "metrics.hip"
 #include "cis.hip"
 #include "wide.hip"
+#include "smc.hip"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -333,7 +334,7 @@ static MalaArgs mala_args(mfm_ctx* x, double beta) {
 static int wide_mala_lgcp(mfm_ctx* x, const LgcpArgs& l) {
   if (!x->wide) return -3;
   wide::LgcpMala m; memset(&m, 0, sizeof m);
-  m.T = l.T; m.mode = l.mode; m.key = l.key; m.n_total = l.n_total; m.chain_offset = l.chain_offset; m.rows = l.B; m.d = l.T.dim; m.dp = l.dp;
+  m.T = l.T; m.mode = l.mode; m.key = l.key; m.keys = l.keys; m.n_total = l.n_total; m.chain_offset = l.chain_offset; m.rows = l.B; m.d = l.T.dim; m.dp = l.dp;
   m.beta = l.beta; m.eps = l.eps; m.textbook = l.textbook;
   m.pos = l.pos; m.logp = l.logp; m.grad = l.grad; m.acc_prob = l.acc_prob; m.accepted = l.accepted; m.proposed = l.proposed; m.prop_weight = l.prop_weight;
   return wide::mala_lgcp(x->wide, x->net, m, x->stream);
@@ -357,14 +358,14 @@ extern "C" int mfm_mala_init(mfm_ctx* x, const float* d_pos, double beta, double
   return MFM_OK;
 }
 
-extern "C" int mfm_mala_step(mfm_ctx* x, uint32_t k0, uint32_t k1, double beta, double step, int textbook, float* d_pos,
-                             double* d_logp, float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, float* d_pw) {
+static int mala_step_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const uint32_t* d_keys, double beta, double step, int textbook, float* d_pos,
+                            double* d_logp, float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, float* d_pw) {
   NEED_TARGET();
   if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
   if (!(step > 0)) return fail(MFM_EINVAL, "step_size must be positive");
   if (x->net.T.kind == MFM_TARGET_LGCP) {
     LgcpArgs l; memset(&l, 0, sizeof l);
-    l.T = x->net.T; l.dp = x->net.dp; l.mode = 1; l.key = Key2{k0, k1}; l.n_total = x->cfg.n_chain_total;
+    l.T = x->net.T; l.dp = x->net.dp; l.mode = 1; l.key = Key2{k0, k1}; l.keys = d_keys; l.n_total = x->cfg.n_chain_total;
     l.chain_offset = x->cfg.chain_offset; l.B = x->cfg.n_chain_local; l.beta = beta; l.eps = step; l.textbook = textbook;
     l.pos = d_pos; l.logp = d_logp; l.grad = d_grad; l.acc_prob = d_acc; l.accepted = d_isacc; l.proposed = d_prop; l.prop_weight = d_pw;
     ProfScope ps_(x, PROF_MALA);
@@ -373,13 +374,23 @@ extern "C" int mfm_mala_step(mfm_ctx* x, uint32_t k0, uint32_t k1, double beta, 
     return MFM_OK;
   }
   MalaArgs a = mala_args(x, beta);
-  a.key = Key2{k0, k1}; a.eps = step; a.textbook = textbook;
+  a.key = Key2{k0, k1}; a.keys = d_keys; a.eps = step; a.textbook = textbook;
   a.pos = d_pos; a.logp = d_logp; a.grad = d_grad;
   a.acc_prob = d_acc; a.accepted = d_isacc; a.proposed = d_prop; a.prop_weight = d_pw;
   ProfScope ps_(x, PROF_MALA);
   if (launch_mala_step(a, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large for the MALA kernel", x->cfg.dim);
   LAUNCHCHK();
   return MFM_OK;
+}
+
+extern "C" int mfm_mala_step(mfm_ctx* x, uint32_t k0, uint32_t k1, double beta, double step, int textbook, float* d_pos,
+                             double* d_logp, float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, float* d_pw) {
+  return mala_step_common(x, k0, k1, nullptr, beta, step, textbook, d_pos, d_logp, d_grad, d_acc, d_isacc, d_prop, d_pw);
+}
+extern "C" int mfm_mala_step_keys(mfm_ctx* x, const uint32_t* d_keys, double beta, double step, int textbook, float* d_pos,
+                                  double* d_logp, float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, float* d_pw) {
+  if (!d_keys) return fail(MFM_EINVAL, "null key array");
+  return mala_step_common(x, 0, 0, d_keys, beta, step, textbook, d_pos, d_logp, d_grad, d_acc, d_isacc, d_prop, d_pw);
 }
 
 extern "C" int mfm_loglik(mfm_ctx* x, const float* d_pos, double* d_out) {
@@ -623,6 +634,44 @@ extern "C" int mfm_max_mean_disc(mfm_ctx* x, const float* d_x, const float* d_y,
   rc = pair_call(x, 1, d_x, nullptr, d_y, nullptr, m, m, 0.f, xy); if (rc) return rc;
   const double m2 = (double)m * (double)m;
   *h_out = (xx[0] - m) / (m2 - m) - 2.0 * xy[0] / m2 + (yy[0] - m) / (m2 - m);      /* mcmc_utils.py:106-110 */
+  return MFM_OK;
+}
+
+// ---- N4: adaptive tempered SMC pieces (bblackjax/smc; exe_others.py:79-111) -------------------------------------------
+extern "C" int mfm_smc_delta(mfm_ctx* x, const double* d_ll, int n, double target_ess, double max_delta, double* h_delta) {
+  if (!x || !d_ll || !h_delta) return fail(MFM_EINVAL, "null argument");
+  if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
+  hipLaunchKernelGGL(smc_delta_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, d_ll, n, target_ess, max_delta, x->beta_out);
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(h_delta, x->beta_out, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  HIPCHK(hipStreamSynchronize(x->stream));
+  return MFM_OK;
+}
+extern "C" int mfm_smc_weights(mfm_ctx* x, const double* d_ll, int n, double delta, double* d_weights, double* h_lognorm) {
+  if (!x || !d_ll || !d_weights) return fail(MFM_EINVAL, "null argument");
+  if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
+  hipLaunchKernelGGL(smc_weights_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, d_ll, n, delta, d_weights, x->beta_out + 1);
+  LAUNCHCHK();
+  if (h_lognorm) {
+    HIPCHK(hipMemcpyAsync(h_lognorm, x->beta_out + 1, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(hipStreamSynchronize(x->stream));
+  }
+  return MFM_OK;
+}
+extern "C" int mfm_smc_resample(mfm_ctx* x, uint32_t k0, uint32_t k1, const double* d_weights, int n, double* d_scratch, int32_t* d_idx) {
+  if (!x || !d_weights || !d_scratch || !d_idx) return fail(MFM_EINVAL, "null argument");
+  if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
+  hipLaunchKernelGGL(smc_resample_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, Key2{k0, k1}, d_weights, n, d_scratch, d_idx);
+  LAUNCHCHK();
+  return MFM_OK;
+}
+extern "C" int mfm_gather_rows(mfm_ctx* x, const float* d_src, const int32_t* d_idx, int n, int dim, float* d_dst) {
+  if (!x || !d_src || !d_idx || !d_dst) return fail(MFM_EINVAL, "null argument");
+  if (n <= 0 || dim <= 0) return fail(MFM_EINVAL, "n and dim must be positive");
+  if (d_src == d_dst) return fail(MFM_EINVAL, "gather_rows is not in-place");
+  const size_t tot = (size_t)n * dim;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096)), dim3(256), 0, x->stream, d_src, d_idx, n, dim, d_dst);
+  LAUNCHCHK();
   return MFM_OK;
 }
 

@@ -14,7 +14,7 @@
 struct LgcpArgs {
   TargetDev T; int dp;
   int mode;
-  Key2 key; uint32_t n_total, chain_offset;
+  Key2 key; const uint32_t* keys; uint32_t n_total, chain_offset;
   int B; double beta, eps; int textbook;
   float* pos; double* logp; float* grad;
   float* acc_prob; uint8_t* accepted; float* proposed; float* prop_weight;
@@ -32,7 +32,8 @@ __global__ __launch_bounds__(LGCP_NW * 64) void mala_lgcp_kernel(LgcpArgs a) {
   Key2 k_int[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const Key2 kb = split_at(a.key, a.n_total, a.chain_offset + (uint32_t)(b0 + 4 * g + i));     // exe_flow_matching.py:303
+    const int bi = b0 + 4 * g + i;
+    const Key2 kb = a.keys ? Key2{a.keys[2 * bi], a.keys[2 * bi + 1]} : split_at(a.key, a.n_total, a.chain_offset + (uint32_t)bi);     // exe_flow_matching.py:303
     k_int[i] = split_at(kb, 2, 0);                                                                // mala.py:93
   }
   double lp_old[4];        // read BEFORE any wave can publish an accepted log-density for the same chain
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(LGCP_NW * 64) void mala_lgcp_kernel(LgcpArgs a) {
       if (a.textbook) delta = -delta;
       if (isnan(delta)) delta = -INFINITY;                                           // proposal.py:105
       const double p = fmin(exp(delta), 1.0);                                        // proposal.py:178
-      const Key2 kb = split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);
+      const Key2 kb = a.keys ? Key2{a.keys[2 * b], a.keys[2 * b + 1]} : split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);
       acc[i] = uniform01(split_at(kb, 2, 1), 0, 1) < p;                              // proposal.py:179
       if (wave == 0 && c == 0) {
         if (a.acc_prob) a.acc_prob[b] = (float)p;

@@ -19,6 +19,7 @@
 struct MalaArgs {
   TargetDev T;
   Key2 key;
+  const uint32_t* keys;   // non-null: one key per chain [B][2] (a caller that vmaps over its own keys: bblackjax/smc/base.py:122-123)
   uint32_t n_total, chain_offset;
   int B;
   double beta;      // annealing temperature: logprob = beta * loglik + logprior
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(MALA_WAVES * 64) void mala_step_kernel(MalaArgs a) 
   Key2 k_int = {0, 0}, k_rmh = {0, 0};
   if (lane == 0) { xs[-1] = 0.f; xs[d] = 0.f; }
   if (live) {
-    const Key2 kb = split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);     // exe_flow_matching.py:303
+    const Key2 kb = a.keys ? Key2{a.keys[2 * b], a.keys[2 * b + 1]} : split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);     // exe_flow_matching.py:303
     k_int = split_at(kb, 2, 0);                                                    // mala.py:93
     k_rmh = split_at(kb, 2, 1);
     const double s2e = sqrt(2.0 * a.eps);

@@ -666,14 +666,14 @@ __global__ __launch_bounds__(256) void flow_accept_kernel(FlowGlue a) {
 //      reference's own pines default is the 40 x 40 grid, multi_modal.py:89).  Same arithmetic as mala_lgcp_kernel, split
 //      around the K^-1 GEMM: propose -> K^-1 (x' - mu) -> energies / accept. ----
 struct LgcpMala {
-  TargetDev T; int mode; Key2 key; uint32_t n_total, chain_offset; int rows, d, dp; double beta, eps; int textbook;
+  TargetDev T; int mode; Key2 key; const uint32_t* keys; uint32_t n_total, chain_offset; int rows, d, dp; double beta, eps; int textbook;
   float* Y; const float* KV; double* th1;
   float* pos; double* logp; float* grad; float* acc_prob; uint8_t* accepted; float* proposed; float* prop_weight;
 };
 __global__ __launch_bounds__(256) void lgcp_propose_kernel(LgcpMala a) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.rows) return;
-  const Key2 kb = split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);           // exe_flow_matching.py:303
+  const Key2 kb = a.keys ? Key2{a.keys[2 * b], a.keys[2 * b + 1]} : split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);           // exe_flow_matching.py:303
   const Key2 k_int = split_at(kb, 2, 0);                                              // mala.py:93
   const double s2e = sqrt(2.0 * a.eps);
   double th1 = 0.0;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void lgcp_accept_kernel(LgcpMala a) {
     if (a.textbook) delta = -delta;
     if (isnan(delta)) delta = -INFINITY;                                           // proposal.py:105
     const double p = fmin(exp(delta), 1.0);                                        // proposal.py:178
-    const Key2 kb = split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);
+    const Key2 kb = a.keys ? Key2{a.keys[2 * b], a.keys[2 * b + 1]} : split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);
     acc = uniform01(split_at(kb, 2, 1), 0, 1) < p;                                 // proposal.py:179
     if (lane == 0) {
       if (a.acc_prob) a.acc_prob[b] = (float)p;

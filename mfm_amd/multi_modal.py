@@ -4,7 +4,8 @@ overrides, ``multi_modal.py:21-101,147-220``), running the MFM loop on MI355X.
 Additions (defaults leave the reference behaviour untouched): ``--force_dim`` / ``--force_num_chain`` override the
 values ``main`` hard-codes per example (needed for BASELINE.json's phi-four d=256 / 4096-chain configuration;
 ``multi_modal.py:52,55`` fix 64 / 1024), ``--log_every`` sets how often metrics are copied to the host.
-Baselines (``--do_flowmc`` ... ``--do_fab``, ``exe_others.py``) are outside the hot-path scope and raise.
+``--do_smc`` runs the tempered-SMC baseline on the same MALA kernel (``exe_others.py:79-111``); the other baselines
+(``--do_flowmc`` ... ``--do_fab``) wrap third-party samplers outside the hot-path scope and raise.
 
 Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node N -m mfm_amd.multi_modal ...``; chains are
 sharded over ranks and the flow-matching gradient is all-reduced over RCCL.
@@ -18,6 +19,7 @@ from . import random as jr
 from . import wandb_shim as wandb
 from .distributions import GaussianMixture, LogGaussianCoxPines, PhiFour
 from .exe_flow_matching import run
+from .exe_others import run as run_others
 
 
 def _dirichlet(key, alpha):
@@ -61,8 +63,9 @@ def main(args):
         raise Exception("Example not found.")
     if args.force_num_chain:
         args.num_chain = args.force_num_chain
-    if args.do_flowmc or args.do_pocomc or args.do_dds or args.do_smc or args.do_fab:
-        raise NotImplementedError("baseline runners (exe_others.py) are outside the hot-path scope (SURVEY.md section 2)")
+    if args.do_flowmc or args.do_pocomc or args.do_dds or args.do_fab:
+        raise NotImplementedError("the flowMC / pocoMC / DDS / FAB runners (exe_others.py) wrap third-party samplers outside the "
+                                  "hot-path scope (SURVEY.md section 2); --do_smc (tempered SMC on the MALA kernel) is built")
 
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch
@@ -73,12 +76,17 @@ def main(args):
 
     N_PARAM = args.dim
     job_type = "mcmc_per_flow_steps=" + str(args.mcmc_per_flow_steps) + ",learning_iter=" + str(args.learning_iter) + (",hutchs" if args.hutchs else "")
+    if args.do_smc:
+        job_type = "Adaptive tempered SMC"                                              # :110-111
     seeds = [args.seed] if args.seed else [i ** 10 for i in range(10)]                  # :118
     res, res_ = [], []
     for seed in seeds:
         args.seed = seed
         wandb.init(project=args.example, config=args, group="dim=" + str(N_PARAM), job_type=job_type)
-        _res, _res_ = run(dist, args, dist.sample_model, log_every=args.log_every)      # :129
+        if args.do_smc:
+            _res, _res_ = run_others(dist, args, dist.sample_model)                     # :126-127
+        else:
+            _res, _res_ = run(dist, args, dist.sample_model, log_every=args.log_every)  # :129
         res.append(_res); res_.append(_res_)
     res, res_ = np.array(res), np.array(res_)
     print(job_type)
