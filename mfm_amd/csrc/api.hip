@@ -340,6 +340,15 @@ static int wide_mala_lgcp(mfm_ctx* x, const LgcpArgs& l) {
   return wide::mala_lgcp(x->wide, x->net, m, x->stream);
 }
 
+// The fused LGCP tile kernel runs one workgroup per 16 chains and streams K^-1 once per workgroup: right for few chains,
+// but 1024 chains are only 64 workgroups on 256 CUs.  With the wide family present and >= 128 chains the K^-1 contraction
+// goes through the wide GEMM (every CU busy) between a propose and an accept kernel; it also serves d > 1024.
+static int lgcp_mala_dispatch(mfm_ctx* x, const LgcpArgs& l) {
+  if (x->wide && l.B >= 128 && wide_mala_lgcp(x, l) == 0) return 0;
+  if (launch_mala_lgcp(l, x->stream) == 0) return 0;
+  return wide_mala_lgcp(x, l);
+}
+
 extern "C" int mfm_mala_init(mfm_ctx* x, const float* d_pos, double beta, double* d_logp, float* d_grad) {
   NEED_TARGET();
   if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
@@ -347,7 +356,7 @@ extern "C" int mfm_mala_init(mfm_ctx* x, const float* d_pos, double beta, double
     LgcpArgs l; memset(&l, 0, sizeof l);
     l.T = x->net.T; l.dp = x->net.dp; l.mode = 0; l.n_total = x->cfg.n_chain_total; l.chain_offset = x->cfg.chain_offset;
     l.B = x->cfg.n_chain_local; l.beta = beta; l.eps = 1.0; l.pos = const_cast<float*>(d_pos); l.logp = d_logp; l.grad = d_grad;
-    if (launch_mala_lgcp(l, x->stream) && wide_mala_lgcp(x, l)) return fail(MFM_ETOOLARGE, "dim %d too large for the LGCP MALA kernel", x->cfg.dim);
+    if (lgcp_mala_dispatch(x, l)) return fail(MFM_ETOOLARGE, "dim %d too large for the LGCP MALA kernel", x->cfg.dim);
     LAUNCHCHK();
     return MFM_OK;
   }
@@ -369,7 +378,7 @@ static int mala_step_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const uint32_t
     l.chain_offset = x->cfg.chain_offset; l.B = x->cfg.n_chain_local; l.beta = beta; l.eps = step; l.textbook = textbook;
     l.pos = d_pos; l.logp = d_logp; l.grad = d_grad; l.acc_prob = d_acc; l.accepted = d_isacc; l.proposed = d_prop; l.prop_weight = d_pw;
     ProfScope ps_(x, PROF_MALA);
-    if (launch_mala_lgcp(l, x->stream) && wide_mala_lgcp(x, l)) return fail(MFM_ETOOLARGE, "dim %d too large for the LGCP MALA kernel", x->cfg.dim);
+    if (lgcp_mala_dispatch(x, l)) return fail(MFM_ETOOLARGE, "dim %d too large for the LGCP MALA kernel", x->cfg.dim);
     LAUNCHCHK();
     return MFM_OK;
   }

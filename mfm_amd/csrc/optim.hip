@@ -120,7 +120,10 @@ __device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool app
 void launch_adamw(const AdamArgs& a, hipStream_t stream) {
   const int n = a.net.n_params;
   const int nb = (n + 255) / 256;
-  dim3 grid(nb < 256 ? nb : 256), block(256);      // a ticket atomic per workgroup: ~11 ns each on one word, keep them few
+  // a ticket atomic per workgroup: ~11 ns each on one word, keep them few -- unless the network is large enough (the pines
+  // widths: 8.65 M parameters) for the elementwise pass itself to need the whole chip
+  const int cap = n > (1 << 21) ? 2048 : 256;
+  dim3 grid(nb < cap ? nb : cap), block(256);
   hipLaunchKernelGGL(finite_decide_kernel, grid, block, 0, stream, a.grads, a.n_slabs, n, a.st, a.flag, a.lr0, a.learning_iter, a.warmup, a.max_err);
   hipLaunchKernelGGL(adamw_kernel, grid, block, 0, stream, a);
 }

@@ -96,14 +96,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm a) {
       }
     }
   };
-  // two ping-pong fragment sets: the loads of block kb + 1 are in flight while block kb is multiplied
-  Frag fa, fb;
-  load(fa, 0);
-  for (int kb = 0; kb < a.KB; kb += 2) {
-    if (kb + 1 < a.KB) load(fb, kb + 1);
-    mac(fa, kb);
-    if (kb + 2 < a.KB) load(fa, kb + 2);
-    if (kb + 1 < a.KB) mac(fb, kb + 1);
+  // a ring of four fragment sets: the loads of block kb + 3 are issued before block kb is multiplied, i.e. three blocks
+  // (3 x 16 MTW NTW MFMA issue slots) of latency cover for a wave that is often alone on its SIMD (the launch is ~one
+  // workgroup per CU at the pines shape)
+  Frag f[4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    if (j < a.KB) load(f[j], j);
+  for (int kb = 0; kb < a.KB; kb += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (kb + j + 3 < a.KB) load(f[(j + 3) & 3], kb + j + 3);
+      if (kb + j < a.KB) mac(f[j], kb + j);
+    }
   }
   // epilogue: lane (g, c) holds features 16 nt + 4 g .. + 3 of row 16 mt + c
 #pragma unroll

@@ -183,7 +183,7 @@ def test_pines_shape_is_served_by_the_wide_family_automatically():
     the wide family by itself.  One MALA step + training step + CNF round trip at the full width."""
     import torch
     from tests import gpu_util as gu
-    B, d = 64, 1024
+    B, d = 128, 1024             # >= 128 chains: the MALA step takes the wide propose / K^-1 GEMM / accept split as well
     args, dist, k, model, state = gu.lgcp_setup(n=32, B=B, hidden=1024, F=128)
     params = _tamed(model, 2, 0.2, 0.02)
     ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)           # kernel_family = AUTO
