@@ -1,0 +1,153 @@
+"""Size-independent properties at BASELINE.json's FULL sizes (the oracle finishes only small cases in seconds):
+phi-four d = 256 with 4096 chains (configs[2], one GPU's share of configs[3]), the 409,600-sample eval batch of the
+gaussian-mixture example (configs[1]) and the pines per-GPU shape (configs[4]: 1024 chains, 32 x 32 grid, hidden 1024).
+Round trips, shard invariance (bit-exact for the chain state), linearity of the summed loss / gradient over shards, and
+agreement between kernels that evaluate the same quantity by different routes."""
+import numpy as np
+import pytest
+
+from oracle import fm, prng
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x, dtype=None):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda()
+
+
+def _tamed(model, seed=9, out_scale=0.3, gate=1e-3):
+    from tests import gpu_util as gu
+    p = gu.rand_params(model, seed=seed, out_scale=out_scale)
+    p[4]["kernel"] *= gate; p[4]["bias"] *= gate
+    return p
+
+
+def test_phi4_4096_chains_mala_and_loss_are_shard_invariant():
+    import torch
+    from tests import gpu_util as gu
+    B, d = 4096, 256
+    args, dist, k, model, state = gu.phi4_setup(d=d, B=B)
+    params = _tamed(model)
+    x32 = dist.init_params.astype(np.float32)
+    key, kfm = prng.PRNGKey(5), prng.PRNGKey(6)
+    res = {}
+    for name, (n_local, off) in {"full": (B, 0), "lo": (B // 2, 0), "hi": (B // 2, B // 2)}.items():
+        ctx = gu.make_ctx(dist, args, n_local=n_local, n_total=B, offset=off, fourier=model.f, params=params)
+        pos = _dev(x32[off:off + n_local]); logp = torch.empty(n_local, dtype=torch.float64, device="cuda"); grad = torch.empty(n_local, d, device="cuda")
+        ctx.mala_init(pos, 1.0, logp, grad)
+        for it in range(3):
+            ctx.mala_step(prng.split(key, 3)[it], 1.0, args.step_size, pos, logp, grad)
+        loss = torch.zeros(1, dtype=torch.float64, device="cuda"); g = torch.zeros(ctx.n_params, device="cuda")
+        ctx.fm_loss_grad(kfm, pos, loss, g)
+        res[name] = (pos.cpu().numpy(), logp.cpu().numpy(), loss.item(), g.cpu().numpy().astype(np.float64))
+        ctx.close()
+    # chain trajectories do not depend on the sharding: bit-exact
+    np.testing.assert_array_equal(np.concatenate([res["lo"][0], res["hi"][0]]), res["full"][0])
+    np.testing.assert_array_equal(np.concatenate([res["lo"][1], res["hi"][1]]), res["full"][1])
+    # the loss and its gradient are SUMS over chains (exe_flow_matching.py:178): shards add up
+    assert abs(res["lo"][2] + res["hi"][2] - res["full"][2]) < 1e-9 * abs(res["full"][2])
+    gs = res["lo"][3] + res["hi"][3]
+    assert np.abs(gs - res["full"][3]).max() < 2e-5 * np.abs(res["full"][3]).max()
+
+
+def test_phi4_4096_chains_zero_init_loss_is_target_norm():
+    import torch
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.phi4_setup(d=256, B=4096)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=state.params)          # flax-style init: v == 0
+    x32 = dist.init_params.astype(np.float32)
+    key = prng.PRNGKey(2)
+    t, cond, target = fm.cond_flow_batch(key, x32.astype(np.float64), args.sigma)
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctx.n_params, device="cuda")
+    ctx.fm_loss_grad(key, _dev(x32), loss, grads)
+    assert abs(loss.item() - (target ** 2).sum()) < 1e-5 * (target ** 2).sum()
+    ctx.close()
+
+
+def test_phi4_4096_chains_flow_round_trip_and_step_consistency():
+    import torch
+    from mfm_amd import _lib
+    from tests import gpu_util as gu
+    B, d = 4096, 256
+    args, dist, k, model, state = gu.phi4_setup(d=d, B=B)
+    params = _tamed(model, out_scale=0.5)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+    x32 = dist.init_params.astype(np.float32)
+    x = _dev(x32)
+    out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
+    ctx.ode_transform(1, x, out, ldj, key=prng.PRNGKey(4), nsteps=ns)
+    assert (out - x).abs().max().item() > 1e-2 and ns.min().item() >= 1
+    back = torch.empty(B, d, device="cuda"); l2 = torch.empty(B, device="cuda")
+    ctx.ode_transform(-1, out, back, l2, key=prng.PRNGKey(4))
+    assert (back - x).abs().max().item() < 2e-3                                  # inverse(transform(x)) == x
+    assert (l2 + ldj).abs().max().item() < 0.15 * max(1.0, ldj.abs().max().item())
+    # the same solve twice is bit-identical (no atomics, no order-dependent reductions)
+    out2 = torch.empty_like(out); ldj2 = torch.empty_like(ldj)
+    ctx.ode_transform(1, x, out2, ldj2, key=prng.PRNGKey(4))
+    assert torch.equal(out, out2) and torch.equal(ldj, ldj2)
+    # one flow-MH step: accepted chains sit at their proposal with the target re-evaluated there, rejected ones are untouched
+    beta = 0.9
+    pos = x.clone(); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+    ctx.mala_init(pos, beta, logp, grad)
+    pos0, logp0, grad0 = pos.clone(), logp.clone(), grad.clone()
+    acc = torch.empty(B, device="cuda"); isacc = torch.empty(B, dtype=torch.uint8, device="cuda"); prop = torch.empty(B, d, device="cuda")
+    ctx.flow_step(_lib.FLOW_RWMH, prng.PRNGKey(31), beta, pos, logp, grad, acc, isacc, prop, ns)
+    a = isacc.bool()
+    assert 0 < a.sum().item() < B
+    assert torch.equal(pos[a], prop[a]) and torch.equal(pos[~a], pos0[~a])
+    assert torch.equal(logp[~a], logp0[~a]) and torch.equal(grad[~a], grad0[~a])
+    lp2 = torch.empty(B, dtype=torch.float64, device="cuda"); g2 = torch.empty(B, d, device="cuda")
+    ctx.mala_init(pos, beta, lp2, g2)                                            # the MALA kernel's evaluation of the same target
+    assert (lp2 - logp).abs().max().item() < 1e-6 * logp.abs().max().item()
+    assert (g2 - grad).abs().max().item() < 1e-4 * max(1.0, grad.abs().max().item())
+    ctx.close()
+
+
+def test_gaussian_mixture_eval_batch_is_a_sum_of_its_chunks():
+    """configs[1]: eval_step on eval_iter * num_chain = 100 * 4096 exact samples (exe_flow_matching.py:370-374)."""
+    import torch
+    from tests import gpu_util as gu
+    B, n_eval = 4096, 409600
+    args, dist, k, model, state = gu.gmm4_setup(B=B, hidden=128, F=128)
+    params = gu.rand_params(model, seed=3)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, max_eval=n_eval)
+    rng = np.random.default_rng(0)
+    xs = _dev((8.0 * rng.choice([-1.0, 1.0], size=(n_eval, 2)) + rng.standard_normal((n_eval, 2))).astype(np.float32))
+    key = prng.PRNGKey(12)
+    full = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ctx.fm_loss(key, xs, full, n_total=n_eval, offset=0)
+    part = torch.zeros(1, dtype=torch.float64, device="cuda"); tot = 0.0
+    for c in range(0, n_eval, 16 * B):
+        ctx.fm_loss(key, xs[c:c + 16 * B], part, n_total=n_eval, offset=c)
+        tot += part.item()
+    assert np.isfinite(full.item()) and abs(tot - full.item()) < 1e-9 * abs(full.item())
+    ctx.close()
+
+
+def test_pines_1024_chains_round_trip_and_shard_sum():
+    """configs[4] per-GPU shape on the wide kernel family."""
+    import torch
+    from tests import gpu_util as gu
+    B, d = 1024, 1024
+    args, dist, k, model, state = gu.lgcp_setup(n=32, B=B, hidden=1024, F=128)
+    params = _tamed(model, seed=2, out_scale=0.2, gate=0.02)
+    x32 = dist.init_params.astype(np.float32)
+    key = prng.PRNGKey(8)
+    res = {}
+    for name, (n_local, off) in {"full": (B, 0), "lo": (B // 2, 0), "hi": (B // 2, B // 2)}.items():
+        ctx = gu.make_ctx(dist, args, n_local=n_local, n_total=B, offset=off, fourier=model.f, params=params)
+        loss = torch.zeros(1, dtype=torch.float64, device="cuda"); g = torch.zeros(ctx.n_params, device="cuda")
+        ctx.fm_loss_grad(key, _dev(x32[off:off + n_local]), loss, g)
+        res[name] = (loss.item(), g.cpu().numpy().astype(np.float64))
+        if name == "full":
+            x = _dev(x32)
+            out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
+            ctx.ode_transform(1, x, out, ldj, key=prng.PRNGKey(4), nsteps=ns)
+            back = torch.empty(B, d, device="cuda"); l2 = torch.empty(B, device="cuda")
+            ctx.ode_transform(-1, out, back, l2, key=prng.PRNGKey(4))
+            assert (out - x).abs().max().item() > 1e-2
+            assert (back - x).abs().max().item() < 2e-3 * max(1.0, x.abs().max().item())
+        ctx.close()
+    assert abs(res["lo"][0] + res["hi"][0] - res["full"][0]) < 1e-9 * abs(res["full"][0])
+    assert np.abs(res["lo"][1] + res["hi"][1] - res["full"][1]).max() < 2e-5 * np.abs(res["full"][1]).max()
