@@ -36,6 +36,7 @@ enum { MFM_OK = 0, MFM_EINVAL = -1, MFM_EUNSUPPORTED = -2, MFM_ETOOLARGE = -3, M
 enum { MFM_PHI4 = 0, MFM_GMM = 1, MFM_LGCP = 2 };                 /* distributions.py:114,42,231 */
 enum { MFM_FLOW_RWMH = 0, MFM_FLOW_IMH = 1 };                      /* exe_flow_matching.py:264-278 / :246-260 */
 enum { MFM_FAMILY_AUTO = 0, MFM_FAMILY_TILE = 1, MFM_FAMILY_WIDE = 2 };
+enum { MFM_ACT_RELU = 0, MFM_ACT_TANH = 1, MFM_ACT_ELU = 2, MFM_ACT_GELU = 3, MFM_ACT_SWISH = 4 };   /* exe_flow_matching.py:39-45 */
 
 typedef struct mfm_config {
   int32_t dim;                 /* args.dim */
@@ -60,6 +61,8 @@ typedef struct mfm_config {
   int32_t kernel_family;       /* MFM_FAMILY_AUTO: fused 16-chain LDS tile kernels when the network fits them, else the wide
                                   family (per-layer MFMA GEMMs on HBM-resident activations: the "pines" widths of
                                   multi_modal.py:89-96); _TILE / _WIDE force one (ETOOLARGE if _TILE does not fit) */
+  int32_t activation;          /* MFM_ACT_*: args.non_linearity (multi_modal.py:177; table exe_flow_matching.py:39-45).  relu, tanh and elu
+                                  run on either kernel family; gelu and swish need stored pre-activations: wide family */
 } mfm_config;
 
 const char* mfm_last_error(void);

@@ -14,6 +14,7 @@ from .build import LIB
 PHI4, GMM, LGCP = 0, 1, 2
 FLOW_RWMH, FLOW_IMH = 0, 1
 FAMILY_AUTO, FAMILY_TILE, FAMILY_WIDE = 0, 1, 2
+ACTIVATIONS = {"relu": 0, "tanh": 1, "elu": 2, "gelu": 3, "swish": 4}          # exe_flow_matching.py:39-45
 
 
 class MfmError(RuntimeError):
@@ -30,7 +31,7 @@ class Config(C.Structure):
         ("learning_rate", C.c_double), ("adam_b1", C.c_double), ("adam_b2", C.c_double), ("adam_eps", C.c_double),
         ("weight_decay", C.c_double), ("update_clip", C.c_double),
         ("learning_iter", C.c_int32), ("warmup_steps", C.c_int32), ("max_eval_samples", C.c_int32),
-        ("kernel_family", C.c_int32),
+        ("kernel_family", C.c_int32), ("activation", C.c_int32),
     ]
 
 
@@ -130,7 +131,7 @@ class Context:
                         chain_offset=0, grad_clip=0.0, sigma=1e-4, cond_flow=1, hutch=0, rtol=1e-5, atol=1e-5,
                         mxstep=1000, n_ts=2, learning_rate=1e-3, adam_b1=0.9, adam_b2=0.999, adam_eps=1e-8,
                         weight_decay=1e-4, update_clip=1.0, learning_iter=400, warmup_steps=0, max_eval_samples=0,
-                        kernel_family=int(os.environ.get("MFM_KERNEL_FAMILY", FAMILY_AUTO)))
+                        kernel_family=int(os.environ.get("MFM_KERNEL_FAMILY", FAMILY_AUTO)), activation=0)
         defaults.update(kw)
         defaults.setdefault("n_chain_total", defaults["n_chain_local"])
         for k, v in defaults.items():

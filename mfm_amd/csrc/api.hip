@@ -130,6 +130,7 @@ static void build_net(const mfm_config& c, NetDev& n) {
   }
   n.n_packed = wo; n.n_bias = bo; n.n_params = mo;
   n.grad_clip = c.grad_clip;
+  n.act = c.activation;
 }
 
 static void build_ws(const NetDev& n, WsLayout& w) {
@@ -162,7 +163,15 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
   build_net(c, x->net);
   build_ws(x->net, x->ws);
   NetDev& n = x->net;
+  if (c.activation < MFM_ACT_RELU || c.activation > MFM_ACT_SWISH) { delete x; return fail(MFM_EINVAL, "unknown activation %d", c.activation); }
   bool use_wide = c.kernel_family == MFM_FAMILY_WIDE;
+  if (c.activation >= MFM_ACT_GELU) {      // gelu / swish: the backward pass needs the pre-activations, which only the wide family keeps
+    if (c.kernel_family == MFM_FAMILY_TILE) {
+      delete x;
+      return fail(MFM_EUNSUPPORTED, "gelu / swish run on the wide kernel family (the fused tile keeps activations, not pre-activations, in LDS)");
+    }
+    use_wide = true;
+  }
   {
     const FmLds L = fm_lds_layout(n, true);
     size_t sm_ode; int tpw_ode;

@@ -186,7 +186,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
       f32x4 v;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        v[i] = fmaxf(acc[i] + bias, 0.f);
+        v[i] = act_f(acc[i] + bias, n.act);
         out[(4 * g + i) * ldo + coff + nt * 16 + c] = v[i];
       }
       if (TRAIN) store_packed(a.acts, a_tile + nt, nbb, bb, lane, v);
@@ -272,7 +272,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
 #pragma unroll
                      for (int i = 0; i < 4; ++i) {
                        const int row = 4 * g + i, col = nt * 16 + c;
-                       z[i] = bJ2[row * L.ldj2 + col] > 0.f ? acc[i] : 0.f;
+                       z[i] = mask_out(bJ2[row * L.ldj2 + col], acc[i], n.act);
                        bD1[row * L.ldd1 + col] = z[i];
                      }
                      store_packed(a.dzs, a.ws.z_j2 + nt, nbb, bb, lane, z);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
 #pragma unroll
                      for (int i = 0; i < 4; ++i) {
                        const int row = 4 * g + i, col = nt * 16 + c;
-                       z[i] = bJ1[row * L.ldj1 + col] > 0.f ? acc[i] : 0.f;
+                       z[i] = mask_out(bJ1[row * L.ldj1 + col], acc[i], n.act);
                        bD2[row * L.ldd2 + col] = z[i];
                      }
                      store_packed(a.dzs, a.ws.z_j1 + nt, nbb, bb, lane, z);
@@ -300,7 +300,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
 #pragma unroll
                      for (int i = 0; i < 4; ++i) {
                        const int row = 4 * g + i;
-                       z[i] = is_sx ? (bCat[row * L.ldcat + col] > 0.f ? acc[i] : 0.f) : acc[i];
+                       z[i] = is_sx ? mask_out(bCat[row * L.ldcat + col], acc[i], n.act) : acc[i];
                        bDC[row * L.ldcat + col] = z[i];
                      }
                      if (is_sx) store_packed(a.dzs, a.ws.z_x2 + nt, nbb, bb, lane, z);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                      for (int i = 0; i < 4; ++i) {
                        const int row = 4 * g + i, col = n.hx2 + nt * 16 + c;
                        const float ds = acc[i] + bDC[row * L.ldcat + col];
-                       z[i] = bCat[row * L.ldcat + col] > 0.f ? ds : 0.f;
+                       z[i] = mask_out(bCat[row * L.ldcat + col], ds, n.act);
                        bDC[row * L.ldcat + col] = z[i];
                      }
                      store_packed(a.dzs, a.ws.z_t2 + nt, nbb, bb, lane, z);
@@ -325,14 +325,14 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
 #pragma unroll
-                     for (int i = 0; i < 4; ++i) z[i] = bX1[(4 * g + i) * L.ldx1 + nt * 16 + c] > 0.f ? acc[i] : 0.f;
+                     for (int i = 0; i < 4; ++i) z[i] = mask_out(bX1[(4 * g + i) * L.ldx1 + nt * 16 + c], acc[i], n.act);
                      store_packed(a.dzs, a.ws.z_x1 + nt, nbb, bb, lane, z);
                    });
   layer_gemm<1, MLP_WAVES_FM>(bDC + n.hx2, L.ldcat, n.WpT + n.L[1].w_off, nullptr, n.L[1].Np / 16, n.L[1].Kp / 16, wave, lane,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
 #pragma unroll
-                     for (int i = 0; i < 4; ++i) z[i] = bT1[(4 * g + i) * L.ldt1 + nt * 16 + c] > 0.f ? acc[i] : 0.f;
+                     for (int i = 0; i < 4; ++i) z[i] = mask_out(bT1[(4 * g + i) * L.ldt1 + nt * 16 + c], acc[i], n.act);
                      store_packed(a.dzs, a.ws.z_t1 + nt, nbb, bb, lane, z);
                    });
 }

@@ -46,8 +46,40 @@ struct NetDev {
   const float* bias;
   const float* fourier;  // [F]
   float grad_clip;       // 0: no clip  (exe_flow_matching.py:351: gradient_clip if dim > 128 else None)
+  int act;               // MFM_ACT_*: the hidden non-linearity (exe_flow_matching.py:39-45, multi_modal.py:177)
   TargetDev T;           // UNTEMPERED target for grad log pi (exe_flow_matching.py:351)
 };
+
+// ---- hidden non-linearities (exe_flow_matching.py:39-45: jax.nn.relu / tanh / elu / gelu (tanh approximation, the jax
+//      default) / swish) with the derivatives the forward-mode tangent (from the pre-activation) and the backward pass
+//      (from the stored OUTPUT where the activation is invertible: relu, tanh, elu) need ----
+#include "../../include/mfm.h"     // MFM_ACT_*
+__device__ __forceinline__ float act_f(float z, int k) {
+  if (k == MFM_ACT_RELU) return fmaxf(z, 0.f);
+  if (k == MFM_ACT_TANH) return tanhf(z);
+  if (k == MFM_ACT_ELU) return z > 0.f ? z : expm1f(z);
+  if (k == MFM_ACT_GELU) return 0.5f * z * (1.f + tanhf(0.7978845608028654f * (z + 0.044715f * z * z * z)));
+  return z / (1.f + expf(-z));
+}
+__device__ __forceinline__ float dact_pre(float z, int k) {
+  if (k == MFM_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (k == MFM_ACT_TANH) { const float t = tanhf(z); return 1.f - t * t; }
+  if (k == MFM_ACT_ELU) return z > 0.f ? 1.f : expf(z);
+  if (k == MFM_ACT_GELU) {
+    const float c = 0.7978845608028654f, u = c * (z + 0.044715f * z * z * z), t = tanhf(u);
+    return 0.5f * (1.f + t) + 0.5f * z * (1.f - t * t) * c * (1.f + 3.f * 0.044715f * z * z);
+  }
+  const float s = 1.f / (1.f + expf(-z));
+  return s * (1.f + z * (1.f - s));
+}
+__device__ __forceinline__ float dact_out(float y, int k) {      // relu / tanh / elu only (f' as a function of f)
+  if (k == MFM_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (k == MFM_ACT_TANH) return 1.f - y * y;
+  return y > 0.f ? 1.f : y + 1.f;
+}
+// tangent / gradient through the activation: relu keeps the exact select of the tuned kernels (no 0 * inf)
+__device__ __forceinline__ float mask_pre(float pre, float t, int k) { return k == MFM_ACT_RELU ? (pre > 0.f ? t : 0.f) : t * dact_pre(pre, k); }
+__device__ __forceinline__ float mask_out(float y, float t, int k) { return k == MFM_ACT_RELU ? (y > 0.f ? t : 0.f) : t * dact_out(y, k); }
 
 __host__ __device__ __forceinline__ int pack_index(int k, int n, int KB) {
   int nt = n >> 4, c = n & 15, kb = k >> 4, r = k & 15, g = r >> 2, s = r & 3;

@@ -262,7 +262,7 @@ struct OdeTile {
     layer_gemm<1, NW, 1>(bFF(), L.ldff, N.Wp + N.L[0].w_off, N.bias + N.L[0].b_off, N.L[0].Kp / 16, N.L[0].Np / 16, wave, lane,
                      [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
-                       for (int i = 0; i < 4; ++i) bT1()[(4 * g + i) * L.ldt1 + nt * 16 + c] = fmaxf(acc[i] + b, 0.f);
+                       for (int i = 0; i < 4; ++i) bT1()[(4 * g + i) * L.ldt1 + nt * 16 + c] = act_f(acc[i] + b, N.act);
                      });
     layer_gemm<1, NW, 1>(bX() + 4, L.ldx, N.Wp + N.L[2].w_off, N.bias + N.L[2].b_off, N.L[2].Kp / 16, N.L[2].Np / 16, wave, lane,
                      [&](int q, int nt, int m, f32x4 acc, float b) {
@@ -270,9 +270,9 @@ struct OdeTile {
                        for (int i = 0; i < 4; ++i) {
                          const float pre = acc[i] + b;
                          const int o = (4 * g + i) * L.ldx1 + nt * 16 + c;
-                         bX1()[o] = fmaxf(pre, 0.f);
+                         bX1()[o] = act_f(pre, N.act);
                          const float tz = (q == 0) ? tz1[0][i] : tz1[1][i];
-                         bX1()[16 * L.ldx1 + o] = pre > 0.f ? tz : 0.f;
+                         bX1()[16 * L.ldx1 + o] = mask_pre(pre, tz, N.act);
                        }
                      });
     MFM_STAMP(4);
@@ -283,7 +283,7 @@ struct OdeTile {
     layer_gemm<1, NW, 1>(bT1(), L.ldt1, N.Wp + N.L[1].w_off, N.bias + N.L[1].b_off, N.L[1].Kp / 16, N.L[1].Np / 16, wave, lane,
                      [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
-                       for (int i = 0; i < 4; ++i) bCat()[(4 * g + i) * L.ldcat + N.hx2 + nt * 16 + c] = fmaxf(acc[i] + b, 0.f);
+                       for (int i = 0; i < 4; ++i) bCat()[(4 * g + i) * L.ldcat + N.hx2 + nt * 16 + c] = act_f(acc[i] + b, N.act);
                      });
     {
       f32x4 keep = {0, 0, 0, 0};   // value pre-activation of the same tile, handed from m = 0 to m = 1
@@ -292,8 +292,8 @@ struct OdeTile {
 #pragma unroll
                          for (int i = 0; i < 4; ++i) {
                            const int o = (4 * g + i) * L.ldcat + nt * 16 + c;
-                           if (m == 0) { keep[i] = acc[i] + b; bCat()[o] = fmaxf(keep[i], 0.f); }
-                           else bCat()[16 * L.ldcat + o] = keep[i] > 0.f ? acc[i] : 0.f;
+                           if (m == 0) { keep[i] = acc[i] + b; bCat()[o] = act_f(keep[i], N.act); }
+                           else bCat()[16 * L.ldcat + o] = mask_pre(keep[i], acc[i], N.act);
                          }
                        });
     }
@@ -318,8 +318,8 @@ struct OdeTile {
 #pragma unroll
                          for (int i = 0; i < 4; ++i) {
                            const int o = (4 * g + i) * L.ldj1 + nt * 16 + c;
-                           if (m == 0) { keep[i] = acc[i] + b; bJ1()[o] = fmaxf(keep[i], 0.f); }
-                           else bJ1()[16 * L.ldj1 + o] = keep[i] > 0.f ? acc[i] : 0.f;
+                           if (m == 0) { keep[i] = acc[i] + b; bJ1()[o] = act_f(keep[i], N.act); }
+                           else bJ1()[16 * L.ldj1 + o] = mask_pre(keep[i], acc[i], N.act);
                          }
                        });
     }
@@ -333,8 +333,8 @@ struct OdeTile {
 #pragma unroll
                          for (int i = 0; i < 4; ++i) {
                            const int o = (4 * g + i) * L.ldj2 + nt * 16 + c;
-                           if (m == 0) { keep[i] = acc[i] + b; bJ2()[o] = fmaxf(keep[i], 0.f); }
-                           else bJ2()[16 * L.ldj2 + o] = keep[i] > 0.f ? acc[i] : 0.f;
+                           if (m == 0) { keep[i] = acc[i] + b; bJ2()[o] = act_f(keep[i], N.act); }
+                           else bJ2()[16 * L.ldj2 + o] = mask_pre(keep[i], acc[i], N.act);
                          }
                        });
     }

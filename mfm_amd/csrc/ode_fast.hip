@@ -893,7 +893,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
 
 // ---- dispatch --------------------------------------------------------------------------------------------------
 static bool shape_ok(const NetDev& n, int hutch) {
-  if (!hutch || n.T.kind != MFM_TARGET_PHI4) return false;
+  if (!hutch || n.T.kind != MFM_TARGET_PHI4 || n.act != MFM_ACT_RELU) return false;
   if (n.F != F || n.ht1 != H || n.ht2 != H || n.hx1 != H || n.hx2 != H || n.hj1 != H || n.hj2 != H) return false;
   return n.d == 256 || n.d == 128;
 }

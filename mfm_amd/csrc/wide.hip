@@ -37,8 +37,11 @@ struct Gemm {
   float* Y; int ldy; int ycol;           // value output (+ column offset, e.g. the st half of [sx | st])
   float* YT;                             // tangent output (same ld / offset) or null
   int rows;                              // multiple of 16
-  int relu;                              // y = max(pre, 0); tangent masked by pre > 0
-  const float* mask; int ldm, mcol;      // backward: y = (mask > 0) ? pre : 0
+  int act;                               // 0: linear; k + 1: y = act_k(pre), tangent scaled by act_k'(pre)  (MFM_ACT_*)
+  float* P;                              // optional copy of the pre-activations (same ld / offset as Y): what the backward
+                                         // pass differentiates through for the non-invertible activations (gelu, swish)
+  const float* mask; int ldm, mcol;      // backward: y = pre * act'(.) with act' from the stored OUTPUT (relu / tanh / elu)
+  int mask_kind, mask_is_pre;            // ... or from the stored PRE-ACTIVATION (mask_is_pre)
   const float* add; int lda, acol;       // backward: pre += add (second contribution to the same activation)
 };
 
@@ -127,20 +130,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm a) {
       if (a.mask) {
         const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + row * a.ldm + a.mcol + f0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pre[i] = mk[i] > 0.f ? pre[i] : 0.f;
+        for (int i = 0; i < 4; ++i) pre[i] = a.mask_is_pre ? mask_pre(mk[i], pre[i], a.mask_kind) : mask_out(mk[i], pre[i], a.mask_kind);
       }
       f32x4 y = pre;
-      if (a.relu) {
+      if (a.act) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = fmaxf(pre[i], 0.f);
+        for (int i = 0; i < 4; ++i) y[i] = act_f(pre[i], a.act - 1);
+        if (a.P) *reinterpret_cast<f32x4*>(a.P + row * a.ldy + a.ycol + f0) = pre;
       }
       *reinterpret_cast<f32x4*>(a.Y + row * a.ldy + a.ycol + f0) = y;
       if (a.YT) {
         f32x4 t = acT[j][m];
         if (a.TS) t = *reinterpret_cast<const f32x4*>(a.TS + row * a.ldts + f0);
-        if (a.relu) {
+        if (a.act) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) t[i] = pre[i] > 0.f ? t[i] : 0.f;
+          for (int i = 0; i < 4; ++i) t[i] = mask_pre(pre[i], t[i], a.act - 1);
         }
         *reinterpret_cast<f32x4*>(a.YT + row * a.ldy + a.ycol + f0) = t;
       }
@@ -322,6 +326,21 @@ __global__ __launch_bounds__(256) void target_kernel(TgtArgs a) {
     (void)r0;
     a.GC[idx] = gc;
     if (a.HZ) a.HZ[idx] = hz;
+  }
+}
+
+// x[r][c] *= act'(.) for c < cols (in place, float4 wide): the sx half of d[sx | st]
+struct ElemMask { int rows, cols, ld; float* x; const float* m; int kind, is_pre; };
+__global__ void elem_mask_kernel(ElemMask a) {
+  const int c4 = a.cols / 4;
+  const size_t tot = (size_t)a.rows * c4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+    const size_t o = (i / c4) * a.ld + (i % c4) * 4;
+    f32x4 v = *reinterpret_cast<f32x4*>(a.x + o);
+    const f32x4 mk = *reinterpret_cast<const f32x4*>(a.m + o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = a.is_pre ? mask_pre(mk[j], v[j], a.kind) : mask_out(mk[j], v[j], a.kind);
+    *reinterpret_cast<f32x4*>(a.x + o) = v;
   }
 }
 
@@ -756,6 +775,8 @@ struct Ctx {
   float *zp, *tz1, *kz, *hz, *x1T, *catT, *j1T, *j2T, *outT;
   // backward
   float *dv, *dg, *dj2, *dj1, *dcat, *dx1, *dt1;
+  // pre-activations of the six hidden layers (allocated for gelu / swish only): t1, [sx | st], x1, j1, j2
+  float *pt1 = nullptr, *pcat = nullptr, *px1 = nullptr, *pj1 = nullptr, *pj2 = nullptr;
   // ODE
   float *Y, *K, *rsf; int* rsi; RowState rs;
   float *vol0, *lqref; int* natt_tot;
@@ -779,6 +800,9 @@ static int create(const NetDev& n, int rows_cap, Ctx** out) {
                o_outT = take(R * n.dp), o_dv = take(R * n.dp), o_dg = take(R * n.dp), o_dj2 = take(R * n.hj2), o_dj1 = take(R * n.hj1),
                o_dcat = take(R * w->cat), o_dx1 = take(R * n.hx1), o_dt1 = take(R * n.ht1), o_Y = take(R * n.dp), o_K = take(7 * R * n.dp),
                o_rsf = take(12 * R), o_vol0 = take(R), o_lq = take(R);
+  const bool need_pre = n.act >= MFM_ACT_GELU;
+  const size_t o_pt1 = need_pre ? take(R * n.ht1) : 0, o_pcat = need_pre ? take(R * w->cat) : 0, o_px1 = need_pre ? take(R * n.hx1) : 0,
+               o_pj1 = need_pre ? take(R * n.hj1) : 0, o_pj2 = need_pre ? take(R * n.hj2) : 0;
   w->pool_floats = o;
   if (hipMalloc((void**)&w->pool, o * sizeof(float)) != hipSuccess) { delete w; return -4; }
   (void)hipMemset(w->pool, 0, o * sizeof(float));
@@ -788,6 +812,7 @@ static int create(const NetDev& n, int rows_cap, Ctx** out) {
   w->kz = p + o_kz; w->hz = p + o_hz; w->x1T = p + o_x1T; w->catT = p + o_catT; w->j1T = p + o_j1T; w->j2T = p + o_j2T; w->outT = p + o_outT;
   w->dv = p + o_dv; w->dg = p + o_dg; w->dj2 = p + o_dj2; w->dj1 = p + o_dj1; w->dcat = p + o_dcat; w->dx1 = p + o_dx1; w->dt1 = p + o_dt1;
   w->Y = p + o_Y; w->K = p + o_K; w->rsf = p + o_rsf; w->vol0 = p + o_vol0; w->lqref = p + o_lq;
+  if (need_pre) { w->pt1 = p + o_pt1; w->pcat = p + o_pcat; w->px1 = p + o_px1; w->pj1 = p + o_pj1; w->pj2 = p + o_pj2; }
   w->rs.t = w->rsf; w->rs.dt = w->rsf + R; w->rs.h0 = w->rsf + 2 * R; w->rs.d1 = w->rsf + 3 * R; w->rs.ell = w->rsf + 4 * R; w->rs.kl = w->rsf + 5 * R;
   if (hipMalloc((void**)&w->rsi, 3 * R * sizeof(int)) != hipSuccess) return -4;
   w->rs.natt = w->rsi; w->rs.done = w->rsi + R; w->natt_tot = w->rsi + 2 * R;
@@ -817,11 +842,11 @@ static void destroy(Ctx* w) {
   delete w;
 }
 
-static Gemm fwd(const NetDev& n, int layer, const float* X, int ldx, float* Y, int ldy, int ycol, int rows, int relu) {
+static Gemm fwd(const NetDev& n, int layer, const float* X, int ldx, float* Y, int ldy, int ycol, int rows, int activate) {
   Gemm g; memset(&g, 0, sizeof g);
   const LayerDesc& L = n.L[layer];
   g.W = n.Wp + L.w_off; g.KB = L.Kp / 16; g.NT = L.Np / 16; g.bias = n.bias + L.b_off;
-  g.X = X; g.ldx = ldx; g.Y = Y; g.ldy = ldy; g.ycol = ycol; g.rows = rows; g.relu = relu;
+  g.X = X; g.ldx = ldx; g.Y = Y; g.ldy = ldy; g.ycol = ycol; g.rows = rows; g.act = activate ? n.act + 1 : 0;
   return g;
 }
 static Gemm bwd(const NetDev& n, int layer, const float* dZ, int ldz, float* dA, int lda, int acol, int rows) {
@@ -849,22 +874,22 @@ static void target_eval(Ctx* w, const NetDev& n, const float* X, const float* Z,
 
 // time branch: ffat -> t1 -> st (into [sx | st]) -> gate
 static void time_branch(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
-  launch_gemm(fwd(n, 0, w->ffat, n.F2p, w->t1, n.ht1, 0, rows, 1), s);
-  launch_gemm(fwd(n, 1, w->t1, n.ht1, w->catv, w->cat, n.hx2, rows, 1), s);
+  Gemm g = fwd(n, 0, w->ffat, n.F2p, w->t1, n.ht1, 0, rows, 1); g.P = w->pt1; launch_gemm(g, s);
+  g = fwd(n, 1, w->t1, n.ht1, w->catv, w->cat, n.hx2, rows, 1); g.P = w->pcat; launch_gemm(g, s);
   launch_gemm(fwd(n, 4, w->catv + n.hx2, w->cat, w->gate, n.dp, 0, rows, 0), s);
 }
 // x branch + joint layers on value rows X (and tangent rows: z in w->zp, z W_x1 in w->tz1)
 static void x_branch(Ctx* w, const NetDev& n, const float* X, bool tangent, int rows, hipStream_t s) {
-  Gemm g = fwd(n, 2, X, n.dp, w->x1, n.hx1, 0, rows, 1);
+  Gemm g = fwd(n, 2, X, n.dp, w->x1, n.hx1, 0, rows, 1); g.P = w->px1;
   if (tangent) { g.YT = w->x1T; g.TS = w->tz1; g.ldts = n.hx1; }
   launch_gemm(g, s);
-  g = fwd(n, 3, w->x1, n.hx1, w->catv, w->cat, 0, rows, 1);
+  g = fwd(n, 3, w->x1, n.hx1, w->catv, w->cat, 0, rows, 1); g.P = w->pcat;
   if (tangent) { g.XT = w->x1T; g.KBT = g.KB; g.YT = w->catT; }
   launch_gemm(g, s);
-  g = fwd(n, 5, w->catv, w->cat, w->j1, n.hj1, 0, rows, 1);
+  g = fwd(n, 5, w->catv, w->cat, w->j1, n.hj1, 0, rows, 1); g.P = w->pj1;
   if (tangent) { g.XT = w->catT; g.KBT = n.hx2 / 16; g.YT = w->j1T; }          // the st half of the tangent is zero
   launch_gemm(g, s);
-  g = fwd(n, 6, w->j1, n.hj1, w->j2, n.hj2, 0, rows, 1);
+  g = fwd(n, 6, w->j1, n.hj1, w->j2, n.hj2, 0, rows, 1); g.P = w->pj2;
   if (tangent) { g.XT = w->j1T; g.KBT = g.KB; g.YT = w->j2T; }
   launch_gemm(g, s);
   g = fwd(n, 7, w->j2, n.hj2, w->out, n.dp, 0, rows, 0);
@@ -901,15 +926,30 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
   hipLaunchKernelGGL(loss_kernel, dim3(grid4(rows)), dim3(256), 0, s, l);
   if (!train) return 0;
   // ---- backward: data gradients (the reverse sweep jax.value_and_grad performs at :364-365) ----
-  Gemm g = bwd(n, 7, w->dv, n.dp, w->dj2, n.hj2, 0, rows); g.mask = w->j2; g.ldm = n.hj2; launch_gemm(g, s);
-  g = bwd(n, 6, w->dj2, n.hj2, w->dj1, n.hj1, 0, rows); g.mask = w->j1; g.ldm = n.hj1; launch_gemm(g, s);
-  // d [sx | st] through j1, ReLU-masked on both halves; the st half then receives the gate path and is masked again
-  // ((m a + b) m = (a + b) m for a 0/1 mask m)
-  g = bwd(n, 5, w->dj1, n.hj1, w->dcat, w->cat, 0, rows); g.mask = w->catv; g.ldm = w->cat; launch_gemm(g, s);
-  g = bwd(n, 4, w->dg, n.dp, w->dcat, w->cat, n.hx2, rows);
-  g.add = w->dcat; g.lda = w->cat; g.acol = n.hx2; g.mask = w->catv; g.ldm = w->cat; g.mcol = n.hx2; launch_gemm(g, s);
-  g = bwd(n, 3, w->dcat, w->cat, w->dx1, n.hx1, 0, rows); g.mask = w->x1; g.ldm = n.hx1; launch_gemm(g, s);
-  g = bwd(n, 1, w->dcat + n.hx2, w->cat, w->dt1, n.ht1, 0, rows); g.mask = w->t1; g.ldm = n.ht1; launch_gemm(g, s);
+  // the derivative of the activation comes from the stored output (relu / tanh / elu) or, for gelu / swish, from the
+  // stored pre-activation
+  const bool pre = n.act >= MFM_ACT_GELU;
+  auto masked = [&](Gemm g, const float* out, const float* prebuf, int ld, int col) {
+    g.mask = pre ? prebuf : out; g.ldm = ld; g.mcol = col; g.mask_kind = n.act; g.mask_is_pre = pre ? 1 : 0;
+    return g;
+  };
+  launch_gemm(masked(bwd(n, 7, w->dv, n.dp, w->dj2, n.hj2, 0, rows), w->j2, w->pj2, n.hj2, 0), s);
+  launch_gemm(masked(bwd(n, 6, w->dj2, n.hj2, w->dj1, n.hj1, 0, rows), w->j1, w->pj1, n.hj1, 0), s);
+  // d [sx | st] through j1 (not yet through the activations of sx / st)
+  launch_gemm(bwd(n, 5, w->dj1, n.hj1, w->dcat, w->cat, 0, rows), s);
+  // st half: += dgate W_gate^T, then through the activation of st (GEMM epilogue); sx half: through the activation of sx
+  // by one thin elementwise pass (it is both the input of the x2 data-gradient GEMM and the dZ of x2's weight gradient)
+  {
+    Gemm g = bwd(n, 4, w->dg, n.dp, w->dcat, w->cat, n.hx2, rows);
+    g.add = w->dcat; g.lda = w->cat; g.acol = n.hx2;
+    launch_gemm(masked(g, w->catv, w->pcat, w->cat, n.hx2), s);
+  }
+  {
+    ElemMask e; e.rows = rows; e.cols = n.hx2; e.ld = w->cat; e.x = w->dcat; e.m = pre ? w->pcat : w->catv; e.kind = n.act; e.is_pre = pre ? 1 : 0;
+    hipLaunchKernelGGL(elem_mask_kernel, dim3(grid_el((size_t)rows * n.hx2 / 4)), dim3(256), 0, s, e);
+  }
+  launch_gemm(masked(bwd(n, 3, w->dcat, w->cat, w->dx1, n.hx1, 0, rows), w->x1, w->px1, n.hx1, 0), s);
+  launch_gemm(masked(bwd(n, 1, w->dcat + n.hx2, w->cat, w->dt1, n.ht1, 0, rows), w->t1, w->pt1, n.ht1, 0), s);
   // ---- weight gradients, straight into the canonical flat gradient vector ----
   WgArgs a; memset(&a, 0, sizeof a);
   const float* A[MLP_NLAYER] = {w->ffat, w->t1, w->cond, w->x1, w->catv + n.hx2, w->catv, w->j1, w->j2};

@@ -105,8 +105,8 @@ class Engine:
         self.dim = int(args.dim)
         if len(args.hidden_x) != 2 or len(args.hidden_t) != 2 or len(args.hidden_xt) != 2:
             raise NotImplementedError("the fused MLP kernels are built for two hidden layers per branch")
-        if getattr(args, "non_linearity", "relu") != "relu":
-            raise NotImplementedError("only the default relu non-linearity is built (multi_modal.py:177)")
+        if getattr(args, "non_linearity", "relu") not in _lib.ACTIVATIONS:
+            raise NotImplementedError(f"unknown non_linearity {args.non_linearity!r} (exe_flow_matching.py:39-45)")
         if getattr(args, "ref_dist", "stdgauss") != "stdgauss":
             raise NotImplementedError("only ref_dist='stdgauss' is built (multi_modal.py:161)")
         if getattr(args, "ot_cond_flow", False):
@@ -122,7 +122,8 @@ class Engine:
             learning_rate=float(args.learning_rate), adam_b1=float(args.adam_beta1), adam_b2=float(args.adam_beta2),
             adam_eps=float(args.adam_epsilon), weight_decay=float(args.weight_decay),
             update_clip=float(args.gradient_clip), learning_iter=int(args.learning_iter),
-            warmup_steps=int(args.warmup_steps), max_eval_samples=int(max_eval_samples))
+            warmup_steps=int(args.warmup_steps), max_eval_samples=int(max_eval_samples),
+            activation=_lib.ACTIVATIONS[getattr(args, "non_linearity", "relu")])
         kind, blk = dist.target_block()
         self.ctx.set_target(kind, blk)
         self.dist = dist

@@ -23,7 +23,7 @@ from .engine import Engine, allreduce_sum_
 
 logger = logging.getLogger(__name__)
 
-non_lins = {"relu": "relu"}                                   # :40-46 (only the default is built)
+non_lins = {"tanh": "tanh", "elu": "elu", "relu": "relu", "gelu": "gelu", "swish": "swish"}     # :39-45 (names: evaluated in the kernels)
 ref_dists = {"stdgauss": lambda dim: IndepGaussian(dim)}      # :48-54 (only the default is built)
 
 
@@ -56,8 +56,8 @@ class VectorFieldNet:
     ``jax.grad(dist.logprob)``, :351); the gradient is evaluated inside the kernels."""
 
     def __init__(self, fourier_random, grad_logporob, hidden_x, hidden_t, hidden_xt, act_fn="relu", grad_clip=None):
-        if act_fn != "relu":
-            raise NotImplementedError("only relu is built")
+        if act_fn not in non_lins:
+            raise NotImplementedError(f"unknown activation {act_fn!r}")
         self.fourier_random = np.asarray(fourier_random, dtype=np.float64)
         self.dist = getattr(grad_logporob, "__self__", None)
         if self.dist is None:

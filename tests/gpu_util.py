@@ -52,7 +52,8 @@ def make_ctx(dist, args, n_local=None, n_total=None, offset=0, fourier=None, par
         hutch=int(args.hutchs), rtol=args.rtol, atol=args.atol, mxstep=int(args.mxstep), n_ts=args.n_ts,
         learning_rate=args.learning_rate, adam_b1=args.adam_beta1, adam_b2=args.adam_beta2, adam_eps=args.adam_epsilon,
         weight_decay=args.weight_decay, update_clip=args.gradient_clip, learning_iter=args.learning_iter,
-        warmup_steps=args.warmup_steps, max_eval_samples=max_eval, **({} if family is None else {"kernel_family": family}))
+        warmup_steps=args.warmup_steps, max_eval_samples=max_eval, activation=_lib.ACTIVATIONS[args.non_linearity],
+        **({} if family is None else {"kernel_family": family}))
     kind, blk = target_block(dist)
     ctx.set_target(kind, blk)
     if fourier is not None:
