@@ -172,7 +172,10 @@ int mfm_smc_resample(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const double* d
                      int32_t* d_idx);
 int mfm_gather_rows(mfm_ctx* ctx, const float* d_src, const int32_t* d_idx, int n, int dim, float* d_dst);
 
-int mfm_profile(mfm_ctx* ctx, int enable);                      /* enable resets the record */
+/* class_mask: 0 = off; otherwise bit c enables class c (-1: all) and the record is reset.  Two event records per launch
+ * cost ~6 us of stream time each side on this runtime, so a caller that is itself being timed enables only the class it
+ * needs (bench.py: the flow step during the timed region, every class in a separate instrumented pass). */
+int mfm_profile(mfm_ctx* ctx, int class_mask);
 int mfm_profile_read(mfm_ctx* ctx, double ms_total[8], int64_t launches[8]);   /* synchronises */
 
 /* ---- test helpers (host only, no GPU needed) ------------------------------------------------------------------- */

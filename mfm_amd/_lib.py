@@ -268,8 +268,10 @@ class Context:
 
     PROF_CLASSES = ("mala_step", "fm_fwd_bwd", "wgrad", "adamw", "flow_step", "fm_eval", "reduce", "_")
 
-    def profile(self, enable=True):
-        _chk(self.lib.mfm_profile(self.h, int(enable)))
+    def profile(self, enable=True, classes=None):
+        """HIP-event timing of the kernel classes named in ``classes`` (default: all) on the context's stream."""
+        mask = 0 if not enable else (-1 if classes is None else sum(1 << self.PROF_CLASSES.index(c) for c in classes))
+        _chk(self.lib.mfm_profile(self.h, mask))
 
     def profile_read(self):
         ms, cnt = (C.c_double * 8)(), (C.c_int64 * 8)()

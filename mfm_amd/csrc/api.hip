@@ -33,6 +33,7 @@ static int fail(int code, const char* fmt, ...) {
 enum { PROF_MALA = 0, PROF_FM = 1, PROF_WGRAD = 2, PROF_ADAM = 3, PROF_FLOW = 4, PROF_EVAL = 5, PROF_REDUCE = 6, PROF_NCLS = 8 };
 struct Prof {
   bool on = false;
+  unsigned mask = ~0u;            // classes that are bracketed by events
   std::vector<hipEvent_t> ev;     // pairs
   std::vector<int> cls;
   size_t used = 0;
@@ -73,7 +74,7 @@ extern "C" int mfm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t 
 
 ProfScope::ProfScope(mfm_ctx* x_, int cls) : x(x_), active(false) {
   Prof* p = x->prof;
-  if (!p || !p->on || p->used + 2 > p->ev.size()) return;
+  if (!p || !p->on || !(p->mask >> cls & 1u) || p->used + 2 > p->ev.size()) return;
   active = true;
   p->cls.push_back(cls);
   (void)hipEventRecord(p->ev[p->used], x->stream);
@@ -94,6 +95,7 @@ extern "C" int mfm_profile(mfm_ctx* x, int enable) {
     for (auto& e : p->ev) HIPCHK(hipEventCreate(&e));
   }
   p->on = enable != 0;
+  p->mask = (unsigned)enable;
   if (enable) { p->used = 0; p->cls.clear(); }
   return MFM_OK;
 }
