@@ -37,7 +37,7 @@ struct FS {                                         // float offsets (LDS, packe
   // a constant that fits the 16-bit DS offset field.  (Constants beyond 64 KB each cost a register, and the compiler
   // hoists all of them out of the solver loop: with the row state at 135 KB that alone spilled ~250 registers.)
   static constexpr int BTOT = 6 * H + 2 * D;
-  static constexpr int RS = 0, RED = RS + 256, DLP = RED + 4 * 128, BIAS = DLP + 8 * 128;
+  static constexpr int RS = 0, RED = RS + 384, DLP = RED + 6 * 128, BIAS = DLP + 8 * 128;   // 24 row-state fields, 6 reduction slots
   static constexpr int XB0 = BIAS + BTOT, XB1 = XB0 + 16 * LDX, ZB = XB1 + 16 * LDX, R = ZB + 16 * LDX;
   // region R, x branch (32 rows each): A1 (x1 out), SX at R; J1, J2 at R2 = R + 64 LDH.  Time batch (80 rows each):
   // FH (Fourier features, later st) at R, T1 at R2 + 16 LDH
@@ -159,6 +159,11 @@ __device__ __forceinline__ void run_job(const float* arow, __amdgpu_buffer_rsrc_
 
 __device__ static const float C5[5] = {1.f / 5, 3.f / 10, 4.f / 5, 8.f / 9, 1.f};     // stage times of DP_TAB rows 2..6
 
+// Row-state fields beyond ode.hip's RS_* (0..15), used by the flow step's per-row solve phases (solve2): every chain of a
+// tile runs its OWN sequence inverse solve -> proposal -> forward solve; the tile only shares the attempt clock.
+enum { RS_MODE = 16, RS_SOLVE = 17, RS_SIGN = 18, RS_VOL0 = 19, RS_NTOT = 20, RS_LQ = 21, RS_SW = 22, RS_TILE = 23 };
+enum { RM_INIT0 = 0, RM_INIT1 = 1, RM_ATT = 2, RM_DONE = 3 };
+
 template <int D>
 struct FTile {
   using S = FS<D>;
@@ -222,6 +227,7 @@ struct FTile {
   // Entry: P = first group of W0 tile `wave`; row state visible.  Exit: P = first group of W2 tile `wave` (x1), and a
   // barrier has passed since every LDS access of this routine (region R is free for the x branch; a stage input written
   // by the caller BEFORE this call is visible).
+  template <bool ROWMODE = false>
   __device__ __forceinline__ void tbatch(int phase, f32x4 (&P)[4], f32x4 (&Q)[4]) {
 #ifdef MFM_STAMPS
     sec_t0 = __builtin_amdgcn_s_memtime();
@@ -229,14 +235,19 @@ struct FTile {
     {
       float sv[5][4];
       const f32x4 t4 = rs_get(RS_T), h4 = rs_get(phase == 1 ? RS_H0 : RS_DT);
+      f32x4 md4 = {2.f, 2.f, 2.f, 2.f}, sg4 = {(float)sign, (float)sign, (float)sign, (float)sign};
+      if constexpr (ROWMODE) { md4 = rs_get(RS_MODE); sg4 = rs_get(RS_SIGN); }
       const double f = (double)ffreq;
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
         const float cs = phase == 0 ? 0.f : (phase == 1 ? 1.f : C5[s]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float tt = t4[i] + h4[i] * cs;
-          const double te = sign > 0 ? (double)tt : 1.0 - (double)tt;          // :229
+          // a row in its initial-step phases rides along the attempt: INIT0 has dt = 0 (every slot is t0), INIT1 has
+          // dt = h0 and takes the extra evaluation of the step-size heuristic in slot 0 at t0 + h0
+          const float csr = ROWMODE ? (md4[i] == (float)RM_INIT1 ? (s == 0 ? 1.f : 0.f) : cs) : cs;
+          const float tt = t4[i] + h4[i] * csr;
+          const double te = sg4[i] > 0.f ? (double)tt : 1.0 - (double)tt;          // :229
           double ft = f * te;
           ft -= rint(ft);
           float cv;
@@ -314,7 +325,8 @@ struct FTile {
   // Entry: X[cur] visible to the workgroup, P = first group of W2 tile `wave`.  Exit: kv = dx/dt of this lane's
   // elements (row 4g+i, col 16 (wave + 8 q) + c); this wave's divergence partials in DLP[dst]; P = first group of
   // `wnext` (W2: another evaluation follows, W0: a time batch follows).
-  __device__ __forceinline__ void eval(int slot, int cur, int dst, bool next_is_tbatch, f32x4 (&P)[4], f32x4 (&Q)[4], float (&kv)[TPW][4]) {
+  __device__ __forceinline__ void eval(int slot, int cur, int dst, bool next_is_tbatch, f32x4 (&P)[4], f32x4 (&Q)[4], float (&kv)[TPW][4],
+                                       const f32x4 sg) {
 #ifdef MFM_STAMPS
     sec_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -424,11 +436,11 @@ struct FTile {
           const float v = acc[q][0][i] + b + gt[q][i] * gc[q][i];
           const float jz = acc[q][1][i] + gt[q][i] * hz[q][i];
           dp[i] += zz[q][i] * jz;
-          kv[q][i] = sign > 0 ? v : -v;
+          kv[q][i] = sg[i] > 0.f ? v : -v;
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dp[i] = sign > 0 ? -dp[i] : dp[i];          // :218 / :239
+      for (int i = 0; i < 4; ++i) dp[i] = sg[i] > 0.f ? -dp[i] : dp[i];          // :218 / :239
       part_put(S::DLP + dst * 128, dp);
       FSEC(17);
     }
@@ -497,7 +509,8 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
 #endif
     float kv[TPW][4];
     const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
-    T.eval(phase < 2 ? 0 : (phase == 7 ? 4 : phase - 2), cur, dst, phase == 7 || phase < 2, P, Q, kv);
+    T.eval(phase < 2 ? 0 : (phase == 7 ? 4 : phase - 2), cur, dst, phase == 7 || phase < 2, P, Q, kv,
+           f32x4{(float)T.sign, (float)T.sign, (float)T.sign, (float)T.sign});
 #ifdef MFM_STAMPS
     T.cyc_eval += __builtin_amdgcn_s_memtime() - c1_; T.n_eval += 1;
 #endif
@@ -678,6 +691,243 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
   }
 }
 
+// ---- the flow step's two solves with PER-ROW phases ------------------------------------------------------------------
+// flow_step = inverse solve of the current position, latent proposal, forward solve of the proposal (:264-278 / :246-260).
+// Run as two tile-wide solves, a tile waits for its slowest inverse solve AND then for its slowest forward solve
+// (max_i inv_i + max_i fwd_i attempted steps; the two are uncorrelated across chains: tools/natt_split.py).  Here every
+// row carries its own (solve, mode) and switches to its forward solve as soon as ITS inverse solve ends, so a tile takes
+// max_i (inv_i + fwd_i) attempts (+ ~4 per row: see below).  The tile shares only the attempt clock: the loop body is
+// always one Dormand-Prince attempt (time batch + six x-branch evaluations).  A row that starts a solve spends two
+// attempts on jax's initial-step heuristic instead of two evaluations: INIT0 rides with dt = 0 (slot 0 evaluates f(y, t0)),
+// INIT1 with dt = h0 and unit stage coefficients in slot 0 (the extra evaluation at t0 + h0); their remaining slots are
+// ignored.  Per-row arithmetic (controller, interpolation, step sizes) is that of solve() bit for bit.
+// On return: y = proposal x' at t = 1 of the forward solve, row state holds ell (forward), vol0 (inverse), lq, counts.
+template <int D>
+__device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const FlowArgs& f, int b0, float (&y)[FTile<D>::TPW][4]) {
+  using S = FS<D>;
+  constexpr int TPW = FTile<D>::TPW, LDX = S::LDX;
+  const int g = T.g, c = T.c, wave = T.wave;
+  const float rtol = a.rtol, atol = a.atol;
+  const int max_attempts = a.max_attempts;
+  const float inv_n = 1.f / (float)(D + 1);
+  const float scale = 2.38f / sqrtf((float)D);                                                  // :262
+  float k[7][TPW][4];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) k[j][q][i] = 0.f;
+  {
+    const float z4[4] = {0.f, 0.f, 0.f, 0.f}, m1[4] = {-1.f, -1.f, -1.f, -1.f};
+    __syncthreads();
+#pragma unroll
+    for (int fld = 0; fld < 24; ++fld) T.rs_put(fld, z4);      // mode INIT0, solve 0, t = 0, dt = 0
+    T.rs_put(RS_SIGN, m1);                                     // inverse solve first (:267 / :251)
+  }
+  f32x4 P[4], Q[4];
+  load_group<1, 0>(P, T.wr, T.W(S::W2, wave, D / 16), T.lane);
+  __syncthreads();
+  T.precompute_tz1(P, Q);
+
+  int phase = 2, cur = 0;
+#pragma unroll 1
+  for (;;) {
+    // ---- stage input -> X[cur] ----
+    float hs[4];
+    const f32x4 md4 = T.rs_get(RS_MODE);
+    {
+      float cf[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) cf[j] = DP_TAB[phase][j];
+      const f32x4 h4 = T.rs_get(RS_DT);
+      const int xsel = cur ? S::XB1 * 4 : S::XB0 * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        hs[i] = h4[i];
+        const bool att = md4[i] == (float)RM_ATT, in1 = md4[i] == (float)RM_INIT1;
+        const float c0 = (in1 && phase == 2) ? 1.f : cf[0];
+        const float he = (att || phase == 2) ? hs[i] : 0.f;      // rows in their initial-step phases only use slot 0
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+          float acc = c0 * k[0][q][i];
+#pragma unroll
+          for (int j = 1; j < 6; ++j) acc += cf[j] * k[j][q][i];
+          *T.at(T.o_xo + xsel, i * LDX + 128 * q) = y[q][i] + he * acc;
+        }
+      }
+    }
+    if (phase == 2) T.template tbatch<true>(2, P, Q); else __syncthreads();
+    float kv[TPW][4];
+    const int dst = phase - 1;
+    T.eval(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN));
+    cur ^= 1;
+#pragma unroll
+    for (int j = 1; j < 7; ++j)
+      if (j == dst) {
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) k[j][q][i] = kv[q][i];
+      }
+    if (phase < 7) { phase += 1; continue; }
+
+    // ---- end of an attempt: per-lane partials of every norm a row may need in its mode ----
+    {
+      float p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0}, p2[4] = {0, 0, 0, 0}, e2[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < TPW; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float sc = atol + fabsf(y[q][i]) * rtol;                    // initial-step norms (Hairer II.4)
+          const float a0 = y[q][i] / sc, a1 = k[1][q][i] / sc, a2 = (k[1][q][i] - k[0][q][i]) / sc;
+          p0[i] += a0 * a0; p1[i] += a1 * a1; p2[i] += a2 * a2;
+          float acc = 0.f, er = 0.f;                                       // error norm of the attempted step
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * k[j][q][i];
+          const float y1 = y[q][i] + hs[i] * acc;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) er += DP_E[j] * k[j][q][i];
+          er *= hs[i];
+          const float tol = atol + rtol * fmaxf(fabsf(y[q][i]), fabsf(y1));
+          const float rr = er / tol;
+          e2[i] += rr * rr;
+        }
+      T.part_put(S::RED + 0 * 128, p0); T.part_put(S::RED + 1 * 128, p1); T.part_put(S::RED + 2 * 128, p2); T.part_put(S::RED + 3 * 128, e2);
+    }
+    if (threadIdx.x == 0) *T.at(0, S::RS + RS_TILE * 16) = 0.f;            // "some row switched solves in this attempt"
+    __syncthreads();
+    int any = 0;
+    if (wave == 0 && T.lane < 16) {        // row leaders
+      auto sum8 = [&](int base) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(T.at(T.o_l8, base)), v = *reinterpret_cast<const f32x4*>(T.at(T.o_l8, base + 4));
+        return ((u[0] + u[1]) + (u[2] + u[3])) + ((v[0] + v[1]) + (v[2] + v[3]));
+      };
+      auto R1 = [&](int field) -> float& { return *T.at(T.o_l1, S::RS + field * 16); };
+      const float mode = R1(RS_MODE);
+      float flag = 0.f, sw = 0.f;
+      if (mode == (float)RM_INIT0) {
+        // f0 sits in k[1] (slot 0 of the attempt): initial step size, part 1
+        if (R1(RS_SOLVE) != 0.f && f.mode == MFM_FLOW_IMH)                 // ref.logprob(u0) - ref.logprob(up)  (:254-255)
+          R1(RS_LQ) = -0.5f * (sum8(S::RED + 4 * 128) - sum8(S::RED + 5 * 128));
+        const float dl0 = sum8(S::DLP + 1 * 128);
+        const float a1 = dl0 / atol;
+        const float d0 = sqrtf(sum8(S::RED + 0 * 128)), d1 = sqrtf(sum8(S::RED + 1 * 128) + a1 * a1);
+        const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+        R1(RS_H0) = h0; R1(RS_D1) = d1; R1(RS_KL + 0) = dl0;
+        R1(RS_DT) = h0; R1(RS_MODE) = (float)RM_INIT1;
+        flag = 3.f;
+      } else if (mode == (float)RM_INIT1) {
+        const float h0 = R1(RS_H0), d1 = R1(RS_D1);
+        const float a2 = (sum8(S::DLP + 1 * 128) - R1(RS_KL + 0)) / atol;
+        const float d2 = sqrtf(sum8(S::RED + 2 * 128) + a2 * a2) / h0;
+        const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
+        const float dt = fminf(100.f * h0, h1);
+        R1(RS_DT) = dt; R1(RS_MODE) = (float)RM_ATT;
+        flag = 0.f;
+      } else if (mode == (float)RM_ATT) {
+        float kl[7];
+        kl[0] = R1(RS_KL + 0);
+#pragma unroll
+        for (int j = 1; j < 7; ++j) kl[j] = sum8(S::DLP + j * 128);
+        const float e2 = sum8(S::RED + 3 * 128);
+        const float t0 = R1(RS_T), dti = R1(RS_DT), ell0 = R1(RS_ELL), na = R1(RS_NATT);
+        const bool active = na < (float)max_attempts && dti > 0.f;
+        float sl = 0.f, el = 0.f, lm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sl += DP_TAB[7][j] * kl[j];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) el += DP_E[j] * kl[j];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) lm += DP_M[j] * kl[j];
+        const float l1 = ell0 + dti * sl;
+        el *= dti;
+        const float tol = atol + rtol * fmaxf(fabsf(ell0), fabsf(l1));
+        const float rr = el / tol;
+        const float ratio = sqrtf((e2 + rr * rr) * inv_n);
+        const bool acc = active && ratio <= 1.f;
+        const float dfac = ratio < 1.f ? 1.f : 0.2f;
+        const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
+        const float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+        const float tn = t0 + dti;
+        const bool fin = acc && tn >= 1.f, adv = acc && !(tn >= 1.f);
+        const float sfrac = (1.f - t0) / (tn - t0);
+        const float y0 = ell0, ym = y0 + dti * lm, f0 = dti * kl[0], f1 = dti * kl[6];
+        const float pa = -2.f * f0 + 2.f * f1 - 8.f * y0 - 8.f * l1 + 16.f * ym;
+        const float pb = 5.f * f0 - 3.f * f1 + 18.f * y0 + 14.f * l1 - 32.f * ym;
+        const float pc = -4.f * f0 + f1 - 11.f * y0 - 5.f * l1 + 16.f * ym;
+        const float li = (((pa * sfrac + pb) * sfrac + pc) * sfrac + f0) * sfrac + y0;
+        const float dt_n = active ? ndt : dti, na_n = active ? na + 1.f : na;
+        const float ell_n = fin ? li : (adv ? l1 : ell0);
+        // the solve ends when t reaches 1, or (as in odeint's while_loop) when the step budget / step size runs out
+        const bool over = fin || !(na_n < (float)max_attempts && dt_n > 0.f);
+        flag = fin ? 2.f : (adv ? 1.f : 0.f);
+        R1(RS_SFRAC) = sfrac;
+        if (!over) {
+          R1(RS_T) = acc ? tn : t0; R1(RS_DT) = dt_n; R1(RS_ELL) = ell_n; R1(RS_KL + 0) = adv ? kl[6] : kl[0]; R1(RS_NATT) = na_n;
+        } else if (R1(RS_SOLVE) == 0.f) {
+          // inverse solve done: keep vol0, start this row's forward solve (:268-269 / :249-250)
+          R1(RS_VOL0) = ell_n; R1(RS_NTOT) = na_n;
+          R1(RS_T) = 0.f; R1(RS_DT) = 0.f; R1(RS_ELL) = 0.f; R1(RS_KL + 0) = 0.f; R1(RS_NATT) = 0.f;
+          R1(RS_SOLVE) = 1.f; R1(RS_SIGN) = 1.f; R1(RS_MODE) = (float)RM_INIT0;
+          sw = 1.f;
+          *T.at(0, S::RS + RS_TILE * 16) = 1.f;
+        } else {
+          R1(RS_ELL) = ell_n; R1(RS_NATT) = na_n; R1(RS_MODE) = (float)RM_DONE;
+        }
+      }
+      R1(RS_FLAG) = flag; R1(RS_SW) = sw;
+      any = R1(RS_MODE) != (float)RM_DONE ? 1 : 0;
+    }
+    const int go = __syncthreads_or(any);
+    // ---- every lane: apply the decision of its rows (branch-free selects) ----
+    const bool tile_sw = *T.at(0, S::RS + RS_TILE * 16) != 0.f;
+    {
+      const f32x4 fl4 = T.rs_get(RS_FLAG), sf4 = T.rs_get(RS_SFRAC), sw4 = T.rs_get(RS_SW);
+      float r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dti = hs[i], sfrac = sf4[i];
+        const bool fin = fl4[i] == 2.f, adv = fl4[i] == 1.f, ini = fl4[i] == 3.f, swr = sw4[i] != 0.f;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+          float acc = 0.f, km = 0.f;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * k[j][q][i];
+#pragma unroll
+          for (int j = 0; j < 7; ++j) km += DP_M[j] * k[j][q][i];
+          const float x0 = y[q][i], x1 = x0 + dti * acc, xm = x0 + dti * km, g0 = dti * k[0][q][i], g1 = dti * k[6][q][i];
+          const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
+          const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
+          const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
+          const float xi = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
+          float yn = fin ? xi : (adv ? x1 : x0);
+          k[0][q][i] = ini ? k[1][q][i] : (adv ? k[6][q][i] : k[0][q][i]);
+          if (tile_sw && swr) {              // this row starts its forward solve: latent proposal, forward probe
+            const int col = 16 * (wave + NW * q) + c;
+            const size_t o = (size_t)(b0 + 4 * g + i) * D + col;
+            const float nz = a.zgen[o];
+            if (f.mode == MFM_FLOW_RWMH) yn = yn + scale * nz;                                        // :268
+            else { r0[i] += yn * yn; r1[i] += nz * nz; yn = nz; }                                      // :249
+            *T.at(T.o_xo, S::ZB + i * LDX + 128 * q) = a.z2[o];                                        // key_hutch1
+#pragma unroll
+            for (int j = 0; j < 7; ++j) k[j][q][i] = 0.f;
+          }
+          y[q][i] = yn;
+        }
+      }
+      if (tile_sw) {                         // tile-uniform
+        if (f.mode == MFM_FLOW_IMH) { T.part_put(S::RED + 4 * 128, r0); T.part_put(S::RED + 5 * 128, r1); }
+        __syncthreads();                     // the new probe rows are visible
+        load_group<1, 0>(P, T.wr, T.W(S::W2, wave, D / 16), T.lane);
+        T.precompute_tz1(P, Q);              // z W_x1 of every row (unchanged rows recompute the same values)
+      }
+    }
+    if (!go) break;
+    phase = 2;
+  }
+}
+
 template <int D>
 __device__ __forceinline__ void tile_init(FTile<D>& T, const NetDev& n, float* lds, f32x4* scr_wg) {
   using S = FS<D>;
@@ -766,48 +1016,20 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
 #endif
   tile_init(T, a.net, lds, scratch + (size_t)blockIdx.x * SCR_F4_PER_WG);
   const int b0 = blockIdx.x * 16, g = T.g, c = T.c, wave = T.wave;
-  float y[TPW][4], ell[4], vol0[4] = {0, 0, 0, 0}, lq_ref[4] = {0, 0, 0, 0};
-  int natt[4], natt_tot[4] = {0, 0, 0, 0};
-#pragma unroll 1
-  for (int ph = 0; ph < 2; ++ph) {       // ONE call site of the solver: inverse solve, then forward solve of the proposal
-    if (ph == 0) {
+  float y[TPW][4], ell[4], vol0[4], lq_ref[4];
+  int natt_tot[4];
 #pragma unroll
-      for (int q = 0; q < TPW; ++q) {
-        const int col = 16 * (wave + NW * q) + c;
+  for (int q = 0; q < TPW; ++q) {
+    const int col = 16 * (wave + NW * q) + c;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[q][i] = f.pos[(size_t)(b0 + 4 * g + i) * D + col];                 // :267 / :251
-      }
-    } else {
-      float r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
-      const float scale = 2.38f / sqrtf((float)D);                                                  // :262
+    for (int i = 0; i < 4; ++i) y[q][i] = f.pos[(size_t)(b0 + 4 * g + i) * D + col];                 // :267 / :251
+  }
+  fill_probe(T, a.z1, b0);               // key_hutch2: probe of the inverse solve (the forward probe is loaded per row)
+  solve2<D>(T, a, f, b0, y);             // inverse solve -> proposal -> forward solve, per row
+  {
+    const f32x4 e4 = T.rs_get(RS_ELL), v4 = T.rs_get(RS_VOL0), l4 = T.rs_get(RS_LQ), n0 = T.rs_get(RS_NTOT), n1 = T.rs_get(RS_NATT);
 #pragma unroll
-      for (int q = 0; q < TPW; ++q) {
-        const int col = 16 * (wave + NW * q) + c;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float nz = a.zgen[(size_t)(b0 + 4 * g + i) * D + col];
-          if (f.mode == MFM_FLOW_RWMH) y[q][i] = y[q][i] + scale * nz;                              // :268
-          else { r0[i] += y[q][i] * y[q][i]; y[q][i] = nz; r1[i] += nz * nz; }                      // :249
-        }
-      }
-      if (f.mode == MFM_FLOW_IMH) {     // ref.logprob(u0) - ref.logprob(up) = -(|u0|^2 - |up|^2) / 2   (:254-255)
-        __syncthreads();
-        T.part_put(S::RED + 0 * 128, r0); T.part_put(S::RED + 1 * 128, r1);
-        __syncthreads();
-        T.part_get(S::RED + 0 * 128, r0); T.part_get(S::RED + 1 * 128, r1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) lq_ref[i] = -0.5f * (r0[i] - r1[i]);
-      }
-      __syncthreads();
-    }
-    fill_probe(T, ph == 0 ? a.z1 : a.z2, b0);       // key_hutch2 for the inverse, key_hutch1 for the forward solve
-    T.sign = ph == 0 ? -1 : 1;
-    solve<D>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (ph == 0) vol0[i] = ell[i];
-      natt_tot[i] += natt[i];
-    }
+    for (int i = 0; i < 4; ++i) { ell[i] = e4[i]; vol0[i] = v4[i]; lq_ref[i] = l4[i]; natt_tot[i] = (int)n0[i] + (int)n1[i]; }
   }
   // ---- target at the proposal (:270 / :252), tempered: beta * loglik (logprior = 0) ----
   __syncthreads();

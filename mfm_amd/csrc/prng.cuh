@@ -66,5 +66,9 @@ __device__ __forceinline__ double normal64(Key2 key, uint32_t idx, uint32_t size
   double u = bits_to_unit(random_bits64(key, idx, size));
   u = __dadd_rn(__dmul_rn(u, span), lo);
   u = fmax(lo, u);
+#ifdef MFM_EXP_FAKE_NORMAL            // development probe: how much of a kernel is the float64 erfinv?
+  return u;
+#else
   return 1.4142135623730951 * erfinv(u);
+#endif
 }

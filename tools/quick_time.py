@@ -30,5 +30,5 @@ timeit("mala_step", lambda: ctx.mala_step(key, 1.0, 1e-4, pos, logp, grad, acc),
 timeit("fm_loss_grad", lambda: ctx.fm_loss_grad(key, pos, loss, grads), 20)
 timeit("fm_loss(eval)", lambda: ctx.fm_loss(key, pos, loss), 20)
 timeit("adamw", lambda: ctx.adamw_step(grads), 20)
-timeit("flow_step", lambda: ctx.flow_step(_lib.FLOW_RWMH, key, 1.0, pos, logp, grad, acc, None, None, ns), 3)
+if not os.environ.get("QT_NOFLOW"): timeit("flow_step", lambda: ctx.flow_step(_lib.FLOW_RWMH, key, 1.0, pos, logp, grad, acc, None, None, ns), 3)
 print("mean attempts/2 solves", ns.float().mean().item())
