@@ -128,11 +128,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         sys.exit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+    # MFM_BENCH_SHARE_GPU=1 + MFM_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a ONE-GPU box (all ranks on device 0,
+    # gloo instead of RCCL, which refuses two ranks on one device); never used by the driver's runs
+    torch.cuda.set_device(0 if os.environ.get("MFM_BENCH_SHARE_GPU") else local_rank)
     td = None
     if world > 1:
         import torch.distributed as td
-        td.init_process_group("nccl")           # RCCL on ROCm
+        td.init_process_group(os.environ.get("MFM_BENCH_BACKEND", "nccl"))           # "nccl" = RCCL on ROCm
 
     from mfm_amd import exe_flow_matching as E, random as jr
     from mfm_amd._lib import FLOW_RWMH
