@@ -160,7 +160,7 @@ int mfm_cis_select(mfm_ctx* ctx, uint32_t key0, uint32_t key1, int n_is, const f
 int mfm_stein_disc(mfm_ctx* ctx, const float* d_x, const float* d_grad, int n, double beta, double h_u_v[2]);
 int mfm_max_mean_disc(mfm_ctx* ctx, const float* d_x, const float* d_y, int m, double* h_out);
 
-/* ---- adaptive tempered SMC baseline on the same MALA kernels (exe_others.py:79-111 -> bblackjax/smc/*) ---------------
+/* ---- adaptive tempered SMC baseline on the same MALA kernels (exe_others.py:79-111 -> bblackjax/smc) ----------------
  * mfm_smc_delta   : ess.ess_solver + solver.dichotomy (ess.py:46-89, solver.py:20-82) on n log-likelihoods, clipped to
  *                   [0, max_delta] (adaptive_tempered.py:61-72); synchronises, result on the host.
  * mfm_smc_weights : weights = softmax(delta * loglik) (float64, [n]) and log normalising constant (base.py:125-128).

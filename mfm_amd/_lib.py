@@ -87,6 +87,11 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB):
             raise MfmError(f"{LIB} not found: build it with `python -m mfm_amd.build` (hipcc, gfx950)")
+        # torch first: libmfm_hip.so depends on libamdhip64 by SONAME, and PyTorch-ROCm bundles its own copy.  Loaded after
+        # torch the dependency resolves to the runtime torch already initialised (one HIP runtime per process: device
+        # pointers and streams are shared with torch); loaded BEFORE torch it would bind /opt/rocm's copy, and the second
+        # runtime in the process finds no device ("no HIP device available" from mfm_create).
+        import torch  # noqa: F401
         lib = C.CDLL(os.environ.get("MFM_LIB", LIB))      # MFM_LIB: development override (A/B of kernel variants)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
