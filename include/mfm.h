@@ -160,6 +160,18 @@ int mfm_cis_select(mfm_ctx* ctx, uint32_t key0, uint32_t key1, int n_is, const f
 int mfm_stein_disc(mfm_ctx* ctx, const float* d_x, const float* d_grad, int n, double beta, double h_u_v[2]);
 int mfm_max_mean_disc(mfm_ctx* ctx, const float* d_x, const float* d_y, int m, double* h_out);
 
+/* ---- draws of the coming iterations, produced ahead of time (noise.hip) -------------------------------------------------
+ * Slot j holds the Gaussian / uniform draws of the MALA step keyed h_keys_gn[j] and of the flow-matching batch keyed
+ * h_keys_step[j] (uint32 [n_slots][2] each, the keys later passed to mfm_mala_step / mfm_fm_loss_grad).  The request arms
+ * the NEXT mfm_flow_step: the workgroups of its kernel whose tile of chains has finished produce the draws until the slowest
+ * tile is done (the launch lasts as long as its slowest chain), so the work rides in otherwise idle CU time;
+ * mfm_mala_step / mfm_fm_loss_grad then recognise their key and read the stored draws (the values they would draw in line:
+ * results are bit-identical).  Call it right BEFORE mfm_flow_step with the keys of the following K iterations.  Served by the
+ * shape-specialised flow-step kernel (headline network shape, PhiFour, --hutch); otherwise EUNSUPPORTED and nothing changes.
+ * mfm_noise_drop forgets armed / stored draws (the kernels draw in line again). */
+int mfm_noise_prefetch(mfm_ctx* ctx, int n_slots, const uint32_t* h_keys_gn, const uint32_t* h_keys_step);
+int mfm_noise_drop(mfm_ctx* ctx);
+
 /* ---- adaptive tempered SMC baseline on the same MALA kernels (exe_others.py:79-111 -> bblackjax/smc) ----------------
  * mfm_smc_delta   : ess.ess_solver + solver.dichotomy (ess.py:46-89, solver.py:20-82) on n log-likelihoods, clipped to
  *                   [0, max_delta] (adaptive_tempered.py:61-72); synchronises, result on the host.

@@ -70,6 +70,8 @@ _SIGS = {
     "mfm_cis_select": (C.c_int, [_P, _U32, _U32, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfm_stein_disc": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     "mfm_max_mean_disc": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_double)]),
+    "mfm_noise_prefetch": (C.c_int, [_P, C.c_int, C.POINTER(_U32), C.POINTER(_U32)]),
+    "mfm_noise_drop": (C.c_int, [_P]),
     "mfm_profile": (C.c_int, [_P, C.c_int]),
     "mfm_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mfm_pack_index": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -270,6 +272,23 @@ class Context:
         self._p()
         _chk(self.lib.mfm_flow_step(self.h, mode, int(key[0]), int(key[1]), float(beta), _ptr(pos, F32), _ptr(logp, F64), _ptr(grad, F32),
                                     _ptr(acc, F32), _ptr(is_acc, U8), _ptr(proposed, F32), _ptr(nsteps, I32)))
+
+    def noise_prefetch(self, keys_gn, keys_step):
+        """Produce the draws of the iterations keyed ``keys_gn[j]`` (MALA step) / ``keys_step[j]`` (training batch) on the side
+        stream; returns False where the configuration is not served (the kernels then draw in line as always)."""
+        kg = np.ascontiguousarray(keys_gn, dtype=np.uint32).reshape(-1, 2)
+        ks = np.ascontiguousarray(keys_step, dtype=np.uint32).reshape(-1, 2)
+        assert kg.shape == ks.shape
+        if kg.shape[0] == 0:
+            return False
+        rc = self.lib.mfm_noise_prefetch(self.h, kg.shape[0], kg.ctypes.data_as(C.POINTER(_U32)), ks.ctypes.data_as(C.POINTER(_U32)))
+        if rc == -2:            # MFM_EUNSUPPORTED
+            return False
+        _chk(rc)
+        return True
+
+    def noise_drop(self):
+        _chk(self.lib.mfm_noise_drop(self.h))
 
     PROF_CLASSES = ("mala_step", "fm_fwd_bwd", "wgrad", "adamw", "flow_step", "fm_eval", "reduce", "_")
 

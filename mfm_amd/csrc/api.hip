@@ -12,6 +12,7 @@
 #include "lgcp.hip"
 #include "fm.hip"
 #include "optim.hip"
+#include "noise.hip"
 #include "ode.hip"
 #include "anneal.hip"
 #include "metrics.hip"
@@ -39,8 +40,21 @@ struct Prof {
   size_t used = 0;
 };
 
+// draws of the coming MALA + training iterations, produced in the tail of the flow-step kernel (noise.hip)
+struct NoiseWs {
+  int cap = 0;                                  // slots allocated
+  double *mala_n = nullptr, *mala_u = nullptr, *fm_x0 = nullptr, *fm_eps = nullptr;
+  float* fm_t = nullptr; uint32_t* d_keys = nullptr;      // [2][cap][2]
+  int* counter = nullptr;
+  std::vector<uint32_t> h_keys;                 // staging copy of the keys
+  std::vector<Key2> gn, st;                     // keys of the slots
+  int n_armed = 0;                              // slots the NEXT flow step will fill
+  int n_valid = 0, cur_gn = 0, cur_st = 0;      // slots filled by the last flow step, consumption cursors
+};
+
 struct mfm_ctx {
   Prof* prof;
+  NoiseWs* noise;
   mfm_config cfg;
   hipStream_t stream;
   NetDev net;
@@ -232,6 +246,11 @@ extern "C" int mfm_destroy(mfm_ctx* x) {
   for (void* p : ps) if (p) hipFree(p);
   ode_ws_free(x->ode);
   wide::destroy(x->wide);
+  if (x->noise) {
+    NoiseWs* w = x->noise;
+    for (void* p : {(void*)w->mala_n, (void*)w->mala_u, (void*)w->fm_x0, (void*)w->fm_eps, (void*)w->fm_t, (void*)w->d_keys, (void*)w->counter}) if (p) (void)hipFree(p);
+    delete w;
+  }
   if (x->prof) { for (auto& e : x->prof->ev) (void)hipEventDestroy(e); delete x->prof; }
   delete x;
   return MFM_OK;
@@ -332,6 +351,7 @@ extern "C" int mfm_reset_optimizer(mfm_ctx* x) {
   return MFM_OK;
 }
 
+static int noise_take(mfm_ctx* x, Key2 key, bool step);
 #define NEED_TARGET() do { if (!x) return fail(MFM_EINVAL, "null ctx"); if (!x->has_target) return fail(MFM_ENOTARGET, "mfm_set_target has not been called"); } while (0)
 
 static MalaArgs mala_args(mfm_ctx* x, double beta) {
@@ -395,6 +415,13 @@ static int mala_step_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const uint32_t
   }
   MalaArgs a = mala_args(x, beta);
   a.key = Key2{k0, k1}; a.keys = d_keys; a.eps = step; a.textbook = textbook;
+  if (!d_keys) {
+    const int slot = noise_take(x, Key2{k0, k1}, false);
+    if (slot >= 0) {
+      const size_t B = (size_t)x->cfg.n_chain_local;
+      a.pre_n = x->noise->mala_n + (size_t)slot * B * x->cfg.dim; a.pre_u = x->noise->mala_u + (size_t)slot * B;
+    }
+  }
   a.pos = d_pos; a.logp = d_logp; a.grad = d_grad;
   a.acc_prob = d_acc; a.accepted = d_isacc; a.proposed = d_prop; a.prop_weight = d_pw;
   ProfScope ps_(x, PROF_MALA);
@@ -421,6 +448,18 @@ extern "C" int mfm_loglik(mfm_ctx* x, const float* d_pos, double* d_out) {
   if (launch_loglik(a, d_out, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large", x->cfg.dim);
   LAUNCHCHK();
   return MFM_OK;
+}
+
+// slot of the prefetched draws for `key` (consumed in order), or -1; the first consumer after a prefetch makes the
+// context's stream wait for the side stream
+static int noise_take(mfm_ctx* x, Key2 key, bool step) {
+  NoiseWs* w = x->noise;
+  if (!w || w->n_valid == 0) return -1;
+  int& cur = step ? w->cur_st : w->cur_gn;
+  const std::vector<Key2>& ks = step ? w->st : w->gn;
+  for (int j = cur; j < w->n_valid; ++j)
+    if (ks[j].k0 == key.k0 && ks[j].k1 == key.k1) { cur = j + 1; return j; }      // same stream as the producer: ordered
+  return -1;
 }
 
 static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_samples, int n, int n_total, int offset, bool train,
@@ -453,6 +492,14 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
       LAUNCHCHK();
     }
     return MFM_OK;
+  }
+  if (train && x->cfg.cond_flow) {
+    const int slot = noise_take(x, key, true);
+    if (slot >= 0) {
+      const size_t B = (size_t)x->cfg.n_chain_local;
+      a.pre_x0 = x->noise->fm_x0 + (size_t)slot * B * x->cfg.dim; a.pre_eps = x->noise->fm_eps + (size_t)slot * B * x->cfg.dim;
+      a.pre_t = x->noise->fm_t + (size_t)slot * B;
+    }
   }
   int rc;
   { ProfScope ps_(x, train ? PROF_FM : PROF_EVAL); rc = launch_fm(a, train, x->stream); }
@@ -565,6 +612,24 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
   f.mode = mode; f.key = Key2{k0, k1}; f.n_total = x->cfg.n_chain_total; f.chain_offset = x->cfg.chain_offset;
   f.beta = beta; f.pos = d_pos; f.logp = d_logp; f.grad = d_grad; f.acc_prob = d_acc; f.accepted = d_isacc;
   f.proposed = d_prop; f.nsteps = d_nsteps;
+  // draws of the following iterations, produced by the workgroups of this launch whose tile is done (noise.hip); only the
+  // shape-specialised kernel carries that tail: elsewhere the request is dropped and the consumers draw in line
+  NoiseArgs nz; memset(&nz, 0, sizeof nz);
+  if (x->noise) {
+    NoiseWs* w = x->noise;
+    w->n_valid = 0;
+    const bool fast_path = !x->wide && fast::shape_ok(x->net, x->cfg.hutch) && !getenv("MFM_GENERIC_ODE");
+    if (w->n_armed > 0 && fast_path) {
+      const int B = x->cfg.n_chain_local;
+      nz.gn = w->d_keys; nz.st = w->d_keys + 2 * (size_t)w->n_armed; nz.n_slots = w->n_armed;
+      nz.n_total = (uint32_t)x->cfg.n_chain_total; nz.chain_offset = (uint32_t)x->cfg.chain_offset; nz.B = B; nz.d = x->cfg.dim;
+      nz.mala_n = w->mala_n; nz.mala_u = w->mala_u; nz.fm_x0 = w->fm_x0; nz.fm_eps = w->fm_eps; nz.fm_t = w->fm_t;
+      nz.counter = w->counter; nz.groups = (B + 7) / 8; nz.n_items = nz.groups * w->n_armed;
+      HIPCHK(hipMemsetAsync(w->counter, 0, sizeof(int), x->stream));
+      w->n_valid = w->n_armed; w->cur_gn = w->cur_st = 0;
+    }
+    w->n_armed = 0;
+  }
   ProfScope ps_(x, PROF_FLOW);
   if (x->wide) {
     launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 0, a.n, x->net.d, const_cast<float*>(a.zgen), x->stream);     // key_gen
@@ -579,7 +644,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
     LAUNCHCHK();
     return MFM_OK;
   }
-  int rc = launch_flow_step(a, f, x->stream);
+  int rc = launch_flow_step(a, f, nz, x->stream);
   if (rc) return fail(rc, "flow step cannot be launched for this configuration");
   LAUNCHCHK();
   return MFM_OK;
@@ -654,6 +719,43 @@ extern "C" int mfm_max_mean_disc(mfm_ctx* x, const float* d_x, const float* d_y,
   rc = pair_call(x, 1, d_x, nullptr, d_y, nullptr, m, m, 0.f, xy); if (rc) return rc;
   const double m2 = (double)m * (double)m;
   *h_out = (xx[0] - m) / (m2 - m) - 2.0 * xy[0] / m2 + (yy[0] - m) / (m2 - m);      /* mcmc_utils.py:106-110 */
+  return MFM_OK;
+}
+
+// ---- noise prefetch (noise.hip) -------------------------------------------------------------------------------------------
+extern "C" int mfm_noise_prefetch(mfm_ctx* x, int n_slots, const uint32_t* h_keys_gn, const uint32_t* h_keys_step) {
+  NEED_TARGET();
+  if (!h_keys_gn || !h_keys_step || n_slots <= 0) return fail(MFM_EINVAL, "bad arguments");
+  if (x->wide || !x->cfg.cond_flow || !fast::shape_ok(x->net, x->cfg.hutch))
+    return fail(MFM_EUNSUPPORTED, "the noise prefetch rides in the tail of the shape-specialised flow-step kernel (headline network shape, PhiFour, --hutch)");
+  if (!x->noise) x->noise = new NoiseWs();
+  NoiseWs* w = x->noise;
+  const size_t B = (size_t)x->cfg.n_chain_local, d = (size_t)x->cfg.dim;
+  if (n_slots > w->cap) {
+    HIPCHK(hipStreamSynchronize(x->stream));
+    for (void* p : {(void*)w->mala_n, (void*)w->mala_u, (void*)w->fm_x0, (void*)w->fm_eps, (void*)w->fm_t, (void*)w->d_keys}) if (p) (void)hipFree(p);
+    w->cap = n_slots; w->n_valid = 0;
+    ALLOC(w->mala_n, (size_t)n_slots * B * d); ALLOC(w->mala_u, (size_t)n_slots * B);
+    ALLOC(w->fm_x0, (size_t)n_slots * B * d); ALLOC(w->fm_eps, (size_t)n_slots * B * d); ALLOC(w->fm_t, (size_t)n_slots * B);
+    ALLOC(w->d_keys, (size_t)4 * n_slots);
+    if (!w->counter) ALLOC(w->counter, 4);
+  }
+  // the key upload is ordered on the context's stream before the flow step that consumes it; the staging copy must outlive
+  // the asynchronous copy of a pageable source, which HIP stages synchronously
+  w->h_keys.assign(h_keys_gn, h_keys_gn + 2 * (size_t)n_slots);
+  w->h_keys.insert(w->h_keys.end(), h_keys_step, h_keys_step + 2 * (size_t)n_slots);
+  HIPCHK(hipMemcpyAsync(w->d_keys, w->h_keys.data(), w->h_keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice, x->stream));
+  w->gn.resize(n_slots); w->st.resize(n_slots);
+  for (int j = 0; j < n_slots; ++j) {
+    w->gn[j] = Key2{h_keys_gn[2 * j], h_keys_gn[2 * j + 1]};
+    w->st[j] = Key2{h_keys_step[2 * j], h_keys_step[2 * j + 1]};
+  }
+  w->n_armed = n_slots; w->n_valid = 0;
+  return MFM_OK;
+}
+extern "C" int mfm_noise_drop(mfm_ctx* x) {
+  if (!x) return fail(MFM_EINVAL, "null ctx");
+  if (x->noise) { x->noise->n_valid = 0; x->noise->n_armed = 0; }
   return MFM_OK;
 }
 

@@ -25,6 +25,7 @@ struct FmArgs {
   float* acts;           // packed activations (TRAIN only)
   float* dzs;            // packed pre-activation gradients (TRAIN only)
   double* loss_part;     // [gridDim.x] partial sums of squared residuals
+  const double* pre_x0; const double* pre_eps; const float* pre_t;   // non-null: the batch's draws, produced ahead of time by noise_kernel
 };
 
 struct FmLds {           // float offsets into dynamic LDS
@@ -96,6 +97,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     bglob[i] = a.chain_offset + (uint32_t)(b0 + 4 * g + i);
+    if (a.pre_t) { tt[i] = a.pre_t[b0 + 4 * g + i]; kref[i] = Key2{0, 0}; continue; }
     tt[i] = (float)uniform01(a.key_time, bglob[i], a.n_total);                  // :154 / :142
     kref[i] = split_at(a.key_ref, a.n_total, bglob[i]);                         // :155
   }
@@ -113,8 +115,9 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
         const double t = tt[i];
         double cnd, tg;
         if (a.cond_flow) {
-          const double x0 = normal64(kref[i], (uint32_t)col, (uint32_t)d);
-          const double ne = normal64(a.key_gauss, bglob[i] * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);  // :166
+          const size_t po = (size_t)(b0 + row) * d + col;
+          const double x0 = a.pre_x0 ? a.pre_x0[po] : normal64(kref[i], (uint32_t)col, (uint32_t)d);
+          const double ne = a.pre_x0 ? a.pre_eps[po] : normal64(a.key_gauss, bglob[i] * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);  // :166
           cnd = (double)a.sigma * ne + t * x1v + (1.0 - t) * x0;               // :167
           tg = x1v - x0;                                                       // :168
         } else {

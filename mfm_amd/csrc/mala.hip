@@ -27,6 +27,7 @@ struct MalaArgs {
   int textbook;
   float* pos; double* logp; float* grad;                    // state, updated in place
   float* acc_prob; uint8_t* accepted; float* proposed; float* prop_weight;   // info (may be null)
+  const double* pre_n; const double* pre_u;   // non-null: the step's Gaussian / uniform draws, produced ahead of time by noise_kernel
 };
 
 // value (float64, wave-reduced) and gradient of the tempered target for the row staged in `xs`.
@@ -132,9 +133,11 @@ __global__ __launch_bounds__(MALA_WAVES * 64) void mala_step_kernel(MalaArgs a) 
   Key2 k_int = {0, 0}, k_rmh = {0, 0};
   if (lane == 0) { xs[-1] = 0.f; xs[d] = 0.f; }
   if (live) {
-    const Key2 kb = a.keys ? Key2{a.keys[2 * b], a.keys[2 * b + 1]} : split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);     // exe_flow_matching.py:303
-    k_int = split_at(kb, 2, 0);                                                    // mala.py:93
-    k_rmh = split_at(kb, 2, 1);
+    if (!a.pre_n) {
+      const Key2 kb = a.keys ? Key2{a.keys[2 * b], a.keys[2 * b + 1]} : split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);     // exe_flow_matching.py:303
+      k_int = split_at(kb, 2, 0);                                                    // mala.py:93
+      k_rmh = split_at(kb, 2, 1);
+    }
     const double s2e = sqrt(2.0 * a.eps);
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(MALA_WAVES * 64) void mala_step_kernel(MalaArgs a) 
       if (j < d) {
         x[it] = a.pos[row + j];
         g[it] = a.grad[row + j];
-        double n = normal64(k_int, (uint32_t)j, (uint32_t)d);                      // util.py:80-82
+        double n = a.pre_n ? a.pre_n[row + j] : normal64(k_int, (uint32_t)j, (uint32_t)d);   // util.py:80-82
         double th = s2e * n;
         th1 += th * th;
         xn[it] = (float)((double)x[it] + a.eps * (double)g[it] + th);              // diffusions.py:25-30
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(MALA_WAVES * 64) void mala_step_kernel(MalaArgs a) 
   if (a.textbook) delta = -delta;
   if (isnan(delta)) delta = -INFINITY;                                             // proposal.py:105
   const double p = fmin(exp(delta), 1.0);                                          // proposal.py:178
-  const double u = uniform01(k_rmh, 0, 1);
+  const double u = a.pre_u ? a.pre_u[b] : uniform01(k_rmh, 0, 1);
   const bool acc = u < p;                                                          // proposal.py:179
 
 #pragma unroll

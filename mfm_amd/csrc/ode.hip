@@ -1075,7 +1075,7 @@ int launch_vf_apply(const NetDev& n, const float* x, const float* t, const float
   ODE_LAUNCH(vf_apply_kernel, dim3(cnt / 16), n, x, t, tan, cnt, v, jvp);
   return 0;
 }
-int launch_flow_step(const OdeArgs& a, const FlowArgs& f, hipStream_t stream) {
+int launch_flow_step(const OdeArgs& a, const FlowArgs& f, const NoiseArgs& nz, hipStream_t stream) {
   size_t sm; int tpw;
   if (ode_check(a.net, sm, tpw)) return -3;
   launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 0, a.n, a.net.d, const_cast<float*>(a.zgen), stream);     // key_gen
@@ -1084,7 +1084,7 @@ int launch_flow_step(const OdeArgs& a, const FlowArgs& f, hipStream_t stream) {
     launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 2, a.n, a.net.d, const_cast<float*>(a.z2), stream);     // key_hutch1
   }
   if (fast::shape_ok(a.net, a.hutch) && !getenv("MFM_GENERIC_ODE"))
-    return a.net.d == 256 ? fast::launch_flow_t<256>(a, f, a.fast_scr, stream) : fast::launch_flow_t<128>(a, f, a.fast_scr, stream);
+    return a.net.d == 256 ? fast::launch_flow_t<256>(a, f, nz, a.fast_scr, stream) : fast::launch_flow_t<128>(a, f, nz, a.fast_scr, stream);
   ODE_LAUNCH(flow_step_kernel, dim3(a.n / 16), a, f);
   return 0;
 }

@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(NW * 64) void ode_transform_fast_kernel(OdeArgs a, 
 
 // One flow-based MH step per chain (random-walk in latent space :264-278, or independent :246-260), PhiFour target.
 template <int D>
-__global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, FlowArgs f, f32x4* scratch) {
+__global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, FlowArgs f, NoiseArgs nz, f32x4* scratch) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using S = FS<D>;
   constexpr int TPW = FTile<D>::TPW, LDX = S::LDX;
@@ -1103,6 +1103,8 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
       if (f.nsteps) f.nsteps[b] = natt_tot[i];
     }
   }
+  // this tile is done: until the slowest tile of the launch finishes, fill the idle CU with the draws of the coming iterations
+  if (nz.n_items > 0) noise_tail(nz, reinterpret_cast<volatile int*>(lds + S::RS));
 #ifdef MFM_STAMPS
   if (g_flow_dbg && (threadIdx.x == 0 || threadIdx.x == 256)) {
     unsigned long long* o = g_flow_dbg + (blockIdx.x + (threadIdx.x ? gridDim.x : 0)) * 32;
@@ -1122,10 +1124,10 @@ static bool shape_ok(const NetDev& n, int hutch) {
 static int max_wgs() { return ODE_FAST_MAX_WGS; }
 
 template <int D>
-static int launch_flow_t(const OdeArgs& a, const FlowArgs& f, f32x4* scratch, hipStream_t stream) {
+static int launch_flow_t(const OdeArgs& a, const FlowArgs& f, const NoiseArgs& nz, f32x4* scratch, hipStream_t stream) {
   const size_t sm = (size_t)FS<D>::TOTAL * sizeof(float);
   (void)hipFuncSetAttribute((const void*)flow_step_fast_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL((flow_step_fast_kernel<D>), dim3(a.n / 16), dim3(NW * 64), sm, stream, a, f, scratch);
+  hipLaunchKernelGGL((flow_step_fast_kernel<D>), dim3(a.n / 16), dim3(NW * 64), sm, stream, a, f, nz, scratch);
   return 0;
 }
 template <int D>

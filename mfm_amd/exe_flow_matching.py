@@ -290,8 +290,20 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     metrics = torch.zeros(learning_iter, 4, device=eng.dev, dtype=torch.float64)            # loss, acc mean, acc std, target loss
     betas, lrs = [], []
     n_reduced = 0
+    import os
+    K_int = int(args.mcmc_per_flow_steps) if args.mcmc_per_flow_steps >= 1 else 0
+    prefetch = K_int >= 1 and not use_real_samples and args.num_importance_samples <= 0 and not os.environ.get("MFM_NO_PREFETCH")
     for count in range(1, learning_iter + 1):                                               # :432
         key_sample, key_train_gn, key_train_step = jr.split(key_sample, 3)                  # :433
+        if prefetch and count % (K_int + 1) == 0:
+            # a flow step comes: let the workgroups of its kernel that finish early produce the random draws of the K
+            # MALA + training iterations that follow (noise.hip); their keys are the next K splits of key_sample
+            ks, kg, kt = key_sample, [], []
+            for _ in range(min(K_int, learning_iter - count)):
+                ks, a_, b_ = jr.split(ks, 3)
+                kg.append(a_); kt.append(b_)
+            if kg:
+                prefetch = eng.ctx.noise_prefetch(np.stack(kg), np.stack(kt))               # False: not served for this configuration
         train_states, infos = train_data_generator(key_train_gn, train_states, count, state.params, beta)    # :438
         loss = eng.train_step(key_train_step, train_states.position)                        # :439 (:362-368)
         lrs.append(learning_rate_fn(count - 1))                                             # :367 (pre-increment step)

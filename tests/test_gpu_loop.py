@@ -119,3 +119,23 @@ def test_cis_loop_runs_and_matches_oracle_before_first_flow_step():
     assert np.isfinite(m[:, 0]).all() and np.isfinite(tr["loss"]).all()
     np.testing.assert_allclose(m[:, 0], tr["loss"], rtol=0.05)               # afterwards: near-tie categorical draws may differ
     ex["engine"].close()
+
+
+def test_run_with_noise_prefetch_is_bit_identical(monkeypatch):
+    """Headline network shape (the shape-specialised flow kernel with the noise tail, noise.hip): run() with the draws of
+    the coming iterations produced inside the flow step equals run() drawing in line, bit for bit."""
+    from mfm_amd import distributions as D, exe_flow_matching as E
+    common = dict(example="phi-four", dim=256, num_chain=64, learning_iter=11, mcmc_per_flow_steps=3.0, hutchs=True, seed=7,
+                  eval_iter=1, step_size=1e-4)
+    out = []
+    for off in (True, False):
+        if off:
+            monkeypatch.setenv("MFM_NO_PREFETCH", "1")
+        else:
+            monkeypatch.delenv("MFM_NO_PREFETCH")
+        res, res_, ex = E.run(D.PhiFour(256), _args(**common), None, log_every=1000, return_extras=True)
+        out.append((ex["metrics"].copy(), ex["states"].position.cpu().numpy().copy(), ex["engine"].ctx.get_params()))
+        ex["engine"].close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])

@@ -121,3 +121,39 @@ def test_beta_bisection_matches_oracle():
     flat = -1.0 + 1e-3 * np.random.default_rng(0).standard_normal(512)
     assert abs(ctx.beta_update(0.3, _dev(flat), 0.95) - flow.beta_fn(0.3, flat, 0.95, 512)) < 1e-12
     ctx.close()
+
+
+def test_noise_prefetch_is_bit_identical_to_inline_draws():
+    """mfm_noise_prefetch (noise.hip): the draws of coming MALA steps / training batches, produced in the tail of the flow-step
+    kernel by the workgroups whose tile is done, are the ones the kernels make in line -- chain states, losses and gradients
+    are bit-identical with and without it."""
+    import torch
+    from mfm_amd import _lib
+    from tests import gpu_util as gu
+    B, d = 512, 256
+    args, dist, k, model, state = gu.phi4_setup(d=d, B=B)
+    params = gu.rand_params(model, seed=4, out_scale=0.3)
+    params[4]["kernel"] *= 1e-3; params[4]["bias"] *= 1e-3
+    x32 = dist.init_params.astype(np.float32)
+    keys = np.stack([prng.split(prng.PRNGKey(100 + i), 2) for i in range(6)]).astype(np.uint32)      # [6, 2, 2]: (gn, step) per iteration
+    res = []
+    for prefetch in (False, True):
+        ctx = gu.make_ctx(dist, args, n_local=B // 2, n_total=B, offset=B // 2, fourier=model.f, params=params)
+        n = B // 2
+        pos = torch.as_tensor(x32[n:]).cuda(); logp = torch.empty(n, dtype=torch.float64, device="cuda"); grad = torch.empty(n, d, device="cuda")
+        ctx.mala_init(pos, 1.0, logp, grad)
+        acc = torch.empty(n, device="cuda")
+        if prefetch:
+            assert ctx.noise_prefetch(keys[1:5, 0], keys[1:5, 1])        # iterations 1..4; iteration 5 draws in line
+        ctx.flow_step(_lib.FLOW_RWMH, keys[0, 0], 1.0, pos, logp, grad, acc)
+        loss = torch.zeros(1, dtype=torch.float64, device="cuda"); g = torch.zeros(ctx.n_params, device="cuda")
+        tr = []
+        for i in range(1, 6):
+            ctx.mala_step(keys[i, 0], 1.0, 1e-4, pos, logp, grad, acc)
+            ctx.fm_loss_grad(keys[i, 1], pos, loss, g)
+            tr.append((loss.item(), g.clone(), acc.clone()))
+        res.append((pos.clone(), logp.clone(), tr))
+        ctx.close()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for (l0, g0, a0), (l1, g1, a1) in zip(res[0][2], res[1][2]):
+        assert l0 == l1 and torch.equal(g0, g1) and torch.equal(a0, a1)
