@@ -63,6 +63,8 @@ typedef struct mfm_config {
                                   multi_modal.py:89-96); _TILE / _WIDE force one (ETOOLARGE if _TILE does not fit) */
   int32_t activation;          /* MFM_ACT_*: args.non_linearity (multi_modal.py:177; table exe_flow_matching.py:39-45).  relu, tanh and elu
                                   run on either kernel family; gelu and swish need stored pre-activations: wide family */
+  double ref_std;              /* std of the flow's reference distribution IndepGaussian(dim, var): 1 for args.ref_dist = 'stdgauss',
+                                  sqrt(5) for 'widegauss' (exe_flow_matching.py:48-54, distributions.py:80-97); 0 = 1 */
 } mfm_config;
 
 const char* mfm_last_error(void);

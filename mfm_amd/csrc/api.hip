@@ -180,6 +180,8 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
   build_ws(x->net, x->ws);
   NetDev& n = x->net;
   if (c.activation < MFM_ACT_RELU || c.activation > MFM_ACT_SWISH) { delete x; return fail(MFM_EINVAL, "unknown activation %d", c.activation); }
+  if (x->cfg.ref_std == 0.0) x->cfg.ref_std = 1.0;           // zero-initialised config: the default 'stdgauss'
+  if (!(x->cfg.ref_std > 0.0)) { delete x; return fail(MFM_EINVAL, "ref_std must be positive"); }
   bool use_wide = c.kernel_family == MFM_FAMILY_WIDE;
   if (c.activation >= MFM_ACT_GELU) {      // gelu / swish: the backward pass needs the pre-activations, which only the wide family keeps
     if (c.kernel_family == MFM_FAMILY_TILE) {
@@ -476,13 +478,14 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
     a.key_time = split_at(key, 2, 0); a.key_ref = split_at(key, 2, 1);
   }
   a.n_total = n_total; a.chain_offset = offset; a.B = n; a.sigma = x->cfg.sigma; a.cond_flow = x->cfg.cond_flow;
+  a.ref_std = x->cfg.ref_std;
   a.pos = d_samples; a.acts = x->acts; a.dzs = x->dzs; a.loss_part = x->loss_part;
   if (x->wide) {      // R rows per pass; the loss is accumulated over the passes
     wide::Ctx* w = x->wide;
     for (int r0 = 0; r0 < n; r0 += w->R) {
       wide::FmCall c;
       c.key_time = a.key_time; c.key_ref = a.key_ref; c.key_gauss = a.key_gauss; c.n_total = (uint32_t)n_total; c.chain_offset = (uint32_t)(offset + r0);
-      c.sigma = a.sigma; c.cond_flow = a.cond_flow; c.pos = d_samples + (size_t)r0 * x->cfg.dim; c.rows = n - r0 < w->R ? n - r0 : w->R;
+      c.sigma = a.sigma; c.cond_flow = a.cond_flow; c.ref_std = a.ref_std; c.pos = d_samples + (size_t)r0 * x->cfg.dim; c.rows = n - r0 < w->R ? n - r0 : w->R;
       int rcw;
       { ProfScope ps_(x, train ? PROF_FM : PROF_EVAL); rcw = wide::fm(w, x->net, c, train, train ? d_grads : nullptr, x->stream); }
       if (rcw) return fail(rcw, "wide fm kernels cannot be launched for this configuration");
@@ -610,7 +613,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
   a.n = x->cfg.n_chain_local;
   FlowArgs f; memset(&f, 0, sizeof f);
   f.mode = mode; f.key = Key2{k0, k1}; f.n_total = x->cfg.n_chain_total; f.chain_offset = x->cfg.chain_offset;
-  f.beta = beta; f.pos = d_pos; f.logp = d_logp; f.grad = d_grad; f.acc_prob = d_acc; f.accepted = d_isacc;
+  f.beta = beta; f.ref_std = (float)x->cfg.ref_std; f.pos = d_pos; f.logp = d_logp; f.grad = d_grad; f.acc_prob = d_acc; f.accepted = d_isacc;
   f.proposed = d_prop; f.nsteps = d_nsteps;
   // draws of the following iterations, produced by the workgroups of this launch whose tile is done (noise.hip); only the
   // shape-specialised kernel carries that tail: elsewhere the request is dropped and the consumers draw in line
@@ -636,7 +639,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
     launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 3, a.n, x->net.d, const_cast<float*>(a.z1), x->stream);       // key_hutch2
     launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 2, a.n, x->net.d, const_cast<float*>(a.z2), x->stream);       // key_hutch1
     wide::FlowCall c; memset(&c, 0, sizeof c);
-    c.mode = mode; c.key = f.key; c.n_total = f.n_total; c.chain_offset = f.chain_offset; c.beta = beta; c.rows = a.n;
+    c.mode = mode; c.key = f.key; c.n_total = f.n_total; c.chain_offset = f.chain_offset; c.beta = beta; c.rows = a.n; c.ref_std = f.ref_std;
     c.rtol = a.rtol; c.atol = a.atol; c.max_attempts = a.max_attempts; c.z_inv = a.z1; c.z_fwd = a.z2; c.zgen = a.zgen;
     c.pos = d_pos; c.logp = d_logp; c.grad = d_grad; c.acc_prob = d_acc; c.accepted = d_isacc; c.proposed = d_prop; c.nsteps = d_nsteps;
     const int rcw = wide::flow_step(x->wide, x->net, c, x->stream);
@@ -676,7 +679,7 @@ extern "C" int mfm_cis_select(mfm_ctx* x, uint32_t k0, uint32_t k1, int n_is, co
   if (n_is <= 0) return fail(MFM_EINVAL, "num_importance_samples must be positive");
   CisArgs a; memset(&a, 0, sizeof a);
   a.key = Key2{k0, k1}; a.n_total = x->cfg.n_chain_total; a.chain_offset = x->cfg.chain_offset;
-  a.B = x->cfg.n_chain_local; a.d = x->cfg.dim; a.n_is = n_is;
+  a.B = x->cfg.n_chain_local; a.d = x->cfg.dim; a.n_is = n_is; a.ref_std = x->cfg.ref_std;
   a.u0 = d_u0; a.vol0 = d_vol0; a.refs = d_refs; a.xs = d_xs; a.vols = d_vols; a.lps = d_lps;
   a.pos = d_pos; a.logp = d_logp; a.acc_prob = d_acc; a.accepted = d_isacc; a.proposed = d_prop; a.weight = d_weight;
   ProfScope ps_(x, PROF_FLOW);

@@ -20,16 +20,17 @@ struct CisArgs {
   const float* vols; const double* lps;        // [B n_is]: log-dets, tempered target log-densities
   float* pos; double* logp;                    // state (in / out); logdensity_grad is untouched (:295)
   float* acc_prob; uint8_t* accepted; float* proposed; float* weight;
+  double ref_std;                              // std of the flow's reference distribution IndepGaussian(dim, var) (distributions.py:80-97)
 };
 
 __global__ __launch_bounds__(256) void cis_select_kernel(CisArgs a) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.B) return;
   const int d = a.d, n = a.n_is;
-  const double c0 = -0.5 * (double)d * 1.8378770664093453;          // -d/2 log(2 pi)   (distributions.py:90)
+  const double c0 = -0.5 * (double)d * 1.8378770664093453 - (double)d * log(a.ref_std);          // -d/2 log(2 pi) - d log std   (distributions.py:90)
   auto refl = [&](const float* u) {
     double s = 0.0;
-    for (int j = lane; j < d; j += 64) { const double v = u[j]; s += v * v; }
+    for (int j = lane; j < d; j += 64) { const double v = (double)u[j] / a.ref_std; s += v * v; }
     return -0.5 * wave_sum(s) + c0;
   };
   // weights; the running (unnormalised) cumulative sum is recomputed in the second pass instead of being stored

@@ -25,6 +25,7 @@ struct FmArgs {
   float* acts;           // packed activations (TRAIN only)
   float* dzs;            // packed pre-activation gradients (TRAIN only)
   double* loss_part;     // [gridDim.x] partial sums of squared residuals
+  double ref_std;        // reference distribution of the flow: x0 = ref_std * normal (IndepGaussian(dim, var), distributions.py:93-97)
   const double* pre_x0; const double* pre_eps; const float* pre_t;   // non-null: the batch's draws, produced ahead of time by noise_kernel
 };
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
         double cnd, tg;
         if (a.cond_flow) {
           const size_t po = (size_t)(b0 + row) * d + col;
-          const double x0 = a.pre_x0 ? a.pre_x0[po] : normal64(kref[i], (uint32_t)col, (uint32_t)d);
+          const double x0 = a.ref_std * (a.pre_x0 ? a.pre_x0[po] : normal64(kref[i], (uint32_t)col, (uint32_t)d));
           const double ne = a.pre_x0 ? a.pre_eps[po] : normal64(a.key_gauss, bglob[i] * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);  // :166
           cnd = (double)a.sigma * ne + t * x1v + (1.0 - t) * x0;               // :167
           tg = x1v - x0;                                                       // :168

@@ -58,6 +58,7 @@ struct OdeArgs {
 struct FlowArgs {
   int mode; Key2 key; uint32_t n_total, chain_offset;
   double beta;
+  float ref_std;            // reference distribution IndepGaussian(dim, var): independent-MH proposals and their density (:249-255)
   float* pos; double* logp; float* grad;
   float* acc_prob; uint8_t* accepted; float* proposed; int* nsteps;
 };
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
           for (int i = 0; i < 4; ++i) {
             const float nz = a.zgen[(size_t)(b0 + 4 * g + i) * d + col];
             if (f.mode == MFM_FLOW_RWMH) y[q][i] = y[q][i] + scale * nz;                            // :268
-            else { r0[i] += y[q][i] * y[q][i]; y[q][i] = nz; r1[i] += nz * nz; }                    // :249
+            else { const float up = f.ref_std * nz; r0[i] += y[q][i] * y[q][i]; y[q][i] = up; r1[i] += up * up; }   // :249
           }
         }
       }
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
         __syncthreads();
         T.row_reduce(r0, 5); T.row_reduce(r1, 6);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lq_ref[i] = -0.5f * (r0[i] - r1[i]);
+        for (int i = 0; i < 4; ++i) lq_ref[i] = -0.5f * (r0[i] - r1[i]) / (f.ref_std * f.ref_std);
       }
       __syncthreads();
     }

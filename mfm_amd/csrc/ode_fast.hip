@@ -809,7 +809,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
       if (mode == (float)RM_INIT0) {
         // f0 sits in k[1] (slot 0 of the attempt): initial step size, part 1
         if (R1(RS_SOLVE) != 0.f && f.mode == MFM_FLOW_IMH)                 // ref.logprob(u0) - ref.logprob(up)  (:254-255)
-          R1(RS_LQ) = -0.5f * (sum8(S::RED + 4 * 128) - sum8(S::RED + 5 * 128));
+          R1(RS_LQ) = -0.5f * (sum8(S::RED + 4 * 128) - sum8(S::RED + 5 * 128)) / (f.ref_std * f.ref_std);
         const float dl0 = sum8(S::DLP + 1 * 128);
         const float a1 = dl0 / atol;
         const float d0 = sqrtf(sum8(S::RED + 0 * 128)), d1 = sqrtf(sum8(S::RED + 1 * 128) + a1 * a1);
@@ -908,7 +908,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
             const size_t o = (size_t)(b0 + 4 * g + i) * D + col;
             const float nz = a.zgen[o];
             if (f.mode == MFM_FLOW_RWMH) yn = yn + scale * nz;                                        // :268
-            else { r0[i] += yn * yn; r1[i] += nz * nz; yn = nz; }                                      // :249
+            else { const float up = f.ref_std * nz; r0[i] += yn * yn; r1[i] += up * up; yn = up; }      // :249
             *T.at(T.o_xo, S::ZB + i * LDX + 128 * q) = a.z2[o];                                        // key_hutch1
 #pragma unroll
             for (int j = 0; j < 7; ++j) k[j][q][i] = 0.f;

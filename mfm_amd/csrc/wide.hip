@@ -255,7 +255,7 @@ __device__ __forceinline__ void fourier_row(const float* __restrict__ fr, int F,
 
 struct FmPro {
   Key2 key_time, key_ref, key_gauss; uint32_t n_total, chain_offset;
-  int rows, d, dp, F, F2p; float sigma; int cond_flow;
+  int rows, d, dp, F, F2p; float sigma; int cond_flow; double ref_std;
   const float* pos; const float* fourier;
   float* cond; float* tgt; float* ffat;
 };
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void fm_prologue_kernel(FmPro a) {
       const double x1v = a.pos[(size_t)b * a.d + col];
       double cnd, tg;
       if (a.cond_flow) {
-        const double x0 = normal64(kref, (uint32_t)col, d);
+        const double x0 = a.ref_std * normal64(kref, (uint32_t)col, d);                      // ref_dist.sample_model (:155)
         const double ne = normal64(a.key_gauss, bg * d + (uint32_t)col, a.n_total * d);       // :166
         cnd = (double)a.sigma * ne + t * x1v + (1.0 - t) * x0;                                // :167
         tg = x1v - x0;                                                                        // :168
@@ -602,7 +602,7 @@ __global__ void vf_out_kernel(int n, int d, int dp, const float* out, const floa
 
 // ---- flow-MH step glue (exe_flow_matching.py:246-278) ----------------------------------------------------------------
 struct FlowGlue {
-  int mode; Key2 key; uint32_t n_total, chain_offset; double beta;
+  int mode; Key2 key; uint32_t n_total, chain_offset; double beta; float ref_std;
   int rows, d, dp;
   TargetDev T;
   float* Y;                  // [rows][dp]: u0 after the inverse solve -> proposal -> x' after the forward solve
@@ -622,12 +622,12 @@ __global__ __launch_bounds__(256) void flow_propose_kernel(FlowGlue a) {
     const size_t o = (size_t)b * a.dp + col;
     const float nz = a.zgen[(size_t)b * a.d + col], u0 = a.Y[o];
     if (a.mode == MFM_FLOW_RWMH) a.Y[o] = u0 + scale * nz;
-    else { r0 += u0 * u0; r1 += nz * nz; a.Y[o] = nz; }
+    else { const float up = a.ref_std * nz; r0 += u0 * u0; r1 += up * up; a.Y[o] = up; }             // ref_dist.sample_model (:249)
   }
   r0 = wave_sum(r0); r1 = wave_sum(r1);
   if (lane == 0) {
     a.vol0[b] = a.ell[b];
-    a.lqref[b] = a.mode == MFM_FLOW_IMH ? -0.5f * (r0 - r1) : 0.f;                                // :254-255
+    a.lqref[b] = a.mode == MFM_FLOW_IMH ? -0.5f * (r0 - r1) / (a.ref_std * a.ref_std) : 0.f;      // :254-255
     a.natt_tot[b] = a.natt[b];
   }
 }
@@ -905,7 +905,7 @@ static void probe_setup(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
 }
 
 struct FmCall {
-  Key2 key_time, key_ref, key_gauss; uint32_t n_total, chain_offset; float sigma; int cond_flow;
+  Key2 key_time, key_ref, key_gauss; uint32_t n_total, chain_offset; float sigma; int cond_flow; double ref_std;
   const float* pos; int rows;
 };
 // loss (+ gradient into d_grads, canonical layout) on `rows` samples; the per-workgroup loss partials land in w->loss_part
@@ -914,7 +914,7 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
   if (rows > w->R || rows % 16) return -3;
   FmPro p; memset(&p, 0, sizeof p);
   p.key_time = c.key_time; p.key_ref = c.key_ref; p.key_gauss = c.key_gauss; p.n_total = c.n_total; p.chain_offset = c.chain_offset;
-  p.rows = rows; p.d = n.d; p.dp = n.dp; p.F = n.F; p.F2p = n.F2p; p.sigma = c.sigma; p.cond_flow = c.cond_flow;
+  p.rows = rows; p.d = n.d; p.dp = n.dp; p.F = n.F; p.F2p = n.F2p; p.sigma = c.sigma; p.cond_flow = c.cond_flow; p.ref_std = c.ref_std;
   p.pos = c.pos; p.fourier = n.fourier; p.cond = w->cond; p.tgt = w->tgt; p.ffat = w->ffat;
   hipLaunchKernelGGL(fm_prologue_kernel, dim3(grid4(rows)), dim3(256), 0, s, p);
   time_branch(w, n, rows, s);
@@ -1038,7 +1038,7 @@ static int transform(Ctx* w, const NetDev& n, int direction, float rtol, float a
 }
 
 struct FlowCall {
-  int mode; Key2 key; uint32_t n_total, chain_offset; double beta; int rows;
+  int mode; Key2 key; uint32_t n_total, chain_offset; double beta; int rows; float ref_std;
   float rtol, atol; int max_attempts;
   const float *z_inv, *z_fwd, *zgen;          // [rows][d]: key_hutch2, key_hutch1, key_gen draws (:265 / :247)
   float* pos; double* logp; float* grad; float* acc_prob; uint8_t* accepted; float* proposed; int* nsteps;
@@ -1047,7 +1047,7 @@ static int flow_step(Ctx* w, const NetDev& n, const FlowCall& c, hipStream_t s) 
   const int rows = c.rows;
   if (rows > w->R || rows % 16) return -3;
   FlowGlue f; memset(&f, 0, sizeof f);
-  f.mode = c.mode; f.key = c.key; f.n_total = c.n_total; f.chain_offset = c.chain_offset; f.beta = c.beta;
+  f.mode = c.mode; f.key = c.key; f.n_total = c.n_total; f.chain_offset = c.chain_offset; f.beta = c.beta; f.ref_std = c.ref_std;
   f.rows = rows; f.d = n.d; f.dp = n.dp; f.T = n.T; f.Y = w->Y; f.zgen = c.zgen; f.ell = w->rs.ell; f.vol0 = w->vol0; f.lqref = w->lqref;
   f.natt_tot = w->natt_tot; f.natt = w->rs.natt; f.KV = w->kv;
   f.pos = c.pos; f.logp = c.logp; f.grad = c.grad; f.acc_prob = c.acc_prob; f.accepted = c.accepted; f.proposed = c.proposed; f.nsteps = c.nsteps;

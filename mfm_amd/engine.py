@@ -107,8 +107,10 @@ class Engine:
             raise NotImplementedError("the fused MLP kernels are built for two hidden layers per branch")
         if getattr(args, "non_linearity", "relu") not in _lib.ACTIVATIONS:
             raise NotImplementedError(f"unknown non_linearity {args.non_linearity!r} (exe_flow_matching.py:39-45)")
-        if getattr(args, "ref_dist", "stdgauss") != "stdgauss":
-            raise NotImplementedError("only ref_dist='stdgauss' is built (multi_modal.py:161)")
+        ref_vars = {"stdgauss": 1.0, "widegauss": 5.0}                               # exe_flow_matching.py:48-54, distributions.py:80-97
+        if getattr(args, "ref_dist", "stdgauss") not in ref_vars:
+            raise NotImplementedError(f"ref_dist={args.ref_dist!r}: of the reference's table (exe_flow_matching.py:48-54) only "
+                                      "'stdgauss' and 'widegauss' can be constructed, there as here")
         if getattr(args, "ot_cond_flow", False):
             raise NotImplementedError("ot_cond_flow is dead code in the reference (un-imported ott)")
         self.args = args
@@ -123,7 +125,8 @@ class Engine:
             adam_eps=float(args.adam_epsilon), weight_decay=float(args.weight_decay),
             update_clip=float(args.gradient_clip), learning_iter=int(args.learning_iter),
             warmup_steps=int(args.warmup_steps), max_eval_samples=int(max_eval_samples),
-            activation=_lib.ACTIVATIONS[getattr(args, "non_linearity", "relu")])
+            activation=_lib.ACTIVATIONS[getattr(args, "non_linearity", "relu")],
+            ref_std=float(np.sqrt(ref_vars[getattr(args, "ref_dist", "stdgauss")])))
         kind, blk = dist.target_block()
         self.ctx.set_target(kind, blk)
         self.dist = dist

@@ -24,7 +24,15 @@ from .engine import Engine, allreduce_sum_
 logger = logging.getLogger(__name__)
 
 non_lins = {"tanh": "tanh", "elu": "elu", "relu": "relu", "gelu": "gelu", "swish": "swish"}     # :39-45 (names: evaluated in the kernels)
-ref_dists = {"stdgauss": lambda dim: IndepGaussian(dim)}      # :48-54 (only the default is built)
+def _dead_ref(name):
+    def make(dim):
+        raise NotImplementedError(f"ref_dist={name!r} cannot be constructed in the reference either (exe_flow_matching.py:48-54: "
+                                  "GaussianMixture(dim) / FlatDistribution.sample_model / PhiFourBase do not fit their call sites)")
+    return make
+
+
+ref_dists = {"stdgauss": lambda dim: IndepGaussian(dim), "widegauss": lambda dim: IndepGaussian(dim, var=5.),      # :48-54
+             "bimodal": _dead_ref("bimodal"), "flat": _dead_ref("flat"), "phifour": _dead_ref("phifour")}
 
 
 # ---- parameters: flax-style pytree <-> canonical flat vector (include/mfm.h) ---------------------------------------
@@ -163,6 +171,7 @@ def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
     t = eng.torch
     n_is = int(args.num_importance_samples)
     mode = FLOW_IMH if n_is < 0 else FLOW_RWMH                                             # :298
+    ref_dist = ref_dists[getattr(args, "ref_dist", "stdgauss")](args.dim)                  # :244
     n, d = eng.n_local, eng.dim
     info = dict(acc=t.empty(n, device=eng.dev, dtype=t.float32), isacc=t.empty(n, device=eng.dev, dtype=t.uint8),
                 prop=t.empty(n, d, device=eng.dev, dtype=t.float32), w=t.zeros(n, device=eng.dev, dtype=t.float32),
@@ -190,6 +199,8 @@ def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
         kh = jr.split_rows(kk[:, 2], n_is).reshape(n * n_is, 2)                            # :286
         refs = t.empty(n * n_is, d, device=eng.dev, dtype=t.float32)
         eng.ctx.normal_rows(_keys_dev(ks), refs)                                           # :285
+        if ref_dist.std != 1.0 or ref_dist.mean != 0.0:
+            refs.mul_(float(ref_dist.std)).add_(float(ref_dist.mean))                      # distributions.py:96-97
         xs = t.empty_like(refs); vols = t.empty(n * n_is, device=eng.dev, dtype=t.float32)
         eng.ctx.ode_transform(1, refs, xs, vols, keys=_keys_dev(kh))                        # :287
         lps = _logprob_any(eng, xs, beta=beta)                                             # :288
@@ -327,14 +338,14 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
 
     # ---- final flow samples + importance resampling (:453-459) --------------------------------------------------
     n_final = n_iter * n_chain
-    ref = IndepGaussian(args.dim)
+    ref = ref_dists[args.ref_dist](args.dim)                                                # :388
     u_host = ref.sample_rows(jr.split(key_gen, n_final))                                    # :453 (:389)
     key_hutch, key_choice = jr.split(key_gen)                                               # :454
     lo = eng.rank * (n_final // eng.world)
     u = torch.as_tensor(np.ascontiguousarray(u_host[lo:lo + n_final // eng.world], dtype=np.float32), device=eng.dev)
     flow_samples, vols = transform_and_logdet(key_hutch, u, state.params)                   # :455
     samples_logdensity = _logprob_any(eng, flow_samples)                                    # :456
-    ref_lp = (-0.5 * (u.double() ** 2).sum(1) - 0.5 * args.dim * np.log(2 * np.pi))
+    ref_lp = (-0.5 * (((u.double() - ref.mean) / ref.std) ** 2).sum(1) - args.dim * np.log(ref.std) - 0.5 * args.dim * np.log(2 * np.pi))   # distributions.py:89-90
     log_weights = samples_logdensity - ref_lp - vols.double()                               # :457
     weights = torch.exp(log_weights - log_weights.max())                                    # :458
     p_cuml = torch.cumsum(weights, 0)

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import mala, ode, prng
 from .mala import MALAInfo, MALAState
-from .targets import IndepGaussian, Tempered
+from .targets import REF_VARS, IndepGaussian, Tempered
 
 
 def _accept(keys_acc, a, prev, prop):
@@ -50,7 +50,7 @@ def rwmh_step(keys, prev, value_and_grad, model, params, args, stats=None):
 def imh_step(keys, prev, value_and_grad, model, params, args, stats=None):
     """``exe_flow_matching.py:246-260``."""
     B, d = prev.position.shape
-    ref = IndepGaussian(d)
+    ref = IndepGaussian(d, var=REF_VARS[getattr(args, "ref_dist", "stdgauss")])
     kk = prng.split_rows(keys, 4)                      # :247
     o = dict(hutch=args.hutchs, rtol=args.rtol, atol=args.atol, mxstep=args.mxstep, n_ts=args.n_ts)
     up = ref.sample_model_rows(kk[:, 0])                                                           # :249
@@ -67,7 +67,7 @@ def cis_step(keys, prev, value_and_grad, model, params, args, stats=None):
     flow samples per chain.  Quirk kept: an accepted state carries the STALE ``prev_state.logdensity_grad`` (``:295``)."""
     B, d = prev.position.shape
     n_is = int(args.num_importance_samples)
-    ref = IndepGaussian(d)
+    ref = IndepGaussian(d, var=REF_VARS[getattr(args, "ref_dist", "stdgauss")])
     kk = prng.split_rows(keys, 4)                      # :281 key_sample, key_hutch_prev, key_hutch, key_choice
     o = dict(hutch=args.hutchs, rtol=args.rtol, atol=args.atol, mxstep=args.mxstep, n_ts=args.n_ts)
     u0, vol0 = ode.inverse_and_logdet(model, params, kk[:, 1], prev.position, **o)                 # :282

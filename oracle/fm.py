@@ -15,14 +15,14 @@ import numpy as np
 from . import prng
 
 
-def cond_flow_batch(key, samples, sigma, n_total=None, start=0):
-    """``exe_flow_matching.py:151-169`` with ref_dist = IndepGaussian (stdgauss)."""
+def cond_flow_batch(key, samples, sigma, n_total=None, start=0, ref_std=1.0):
+    """``exe_flow_matching.py:151-169``; ref_dist = IndepGaussian(dim, var = ref_std**2) (``:48-54,149,155``)."""
     B, d = samples.shape
     n_total = B if n_total is None else n_total
     key_time, key_ref, key_gauss, _key_ot = prng.split(key, 4)                       # :153
     t = prng.uniform(key_time, (n_total, 1), start=start, count=B)                   # :154
     ref_keys = prng.split_at(key_ref, n_total, np.arange(start, start + B))          # :155
-    x0 = prng.normal_rows(ref_keys, d)
+    x0 = ref_std * prng.normal_rows(ref_keys, d)                                     # distributions.py:96-97
     eps = prng.normal(key_gauss, (n_total, d), start=start * d, count=B * d).reshape(B, d)   # :166
     tt = t[:, None]
     cond = sigma * eps + tt * samples + (1.0 - tt) * x0                              # :167
@@ -43,10 +43,10 @@ def flow_batch(key, samples, sigma, n_total=None, start=0):
 
 
 def loss_and_grad(model, params, key, samples, sigma, cond_flow=True, n_total=None, start=0,
-                  need_grad=True):
+                  need_grad=True, ref_std=1.0):
     """``exe_flow_matching.py:171-178`` + ``:364-365``."""
     batch = cond_flow_batch if cond_flow else flow_batch
-    t, cond, target = batch(key, samples, sigma, n_total, start)
+    t, cond, target = batch(key, samples, sigma, n_total, start, ref_std) if cond_flow else batch(key, samples, sigma, n_total, start)
     if not need_grad:
         v = model.forward(params, cond, t)
         return ((v - target) ** 2).sum(), None

@@ -10,7 +10,7 @@ from types import SimpleNamespace
 
 import numpy as np
 
-from . import flow, fm, optim, prng
+from . import flow, fm, optim, prng, targets
 from .vfield import VectorFieldNet
 
 
@@ -55,6 +55,7 @@ def run(dist, args, target_gn=None, params_override=None, beta_override=None, ti
     if params_override is not None:
         state.params = [{kk: v.astype(np.float32).copy() for kk, v in p.items()} for p in params_override]
     n_chain = args.num_chain
+    ref_std = float(np.sqrt(targets.REF_VARS[args.ref_dist]))                            # :149 (ref_dists, :48-54)
     iter_per_temp = args.anneal_iter // args.num_anneal_temp                             # :330
     use_real_samples = args.mcmc_per_flow_steps < 0                                       # :328
     if use_real_samples:
@@ -80,7 +81,7 @@ def run(dist, args, target_gn=None, params_override=None, beta_override=None, ti
             states, infos = flow.train_data_generator(key_gn, states, count, model, state.params, dist,
                                                       args, beta, stats=stats)           # :438
         loss, grads = fm.loss_and_grad(model, state.params, key_step, states.position, args.sigma,
-                                       args.cond_flow)                                   # :364-365
+                                       args.cond_flow, ref_std=ref_std)                  # :364-365
         lr = lr_fn(state.step)                                                           # :367
         state.apply_gradients(grads)                                                     # :366
         if not use_real_samples and count % iter_per_temp == 0:                          # :440-441
@@ -93,7 +94,7 @@ def run(dist, args, target_gn=None, params_override=None, beta_override=None, ti
             trace["n_att"].append((stats["n_att_inv"].mean(), stats["n_att_fwd"].mean()))
         if real is not None:                                                             # :444-446
             tl, _ = fm.loss_and_grad(model, state.params, key_loss, real, args.sigma, args.cond_flow,
-                                     need_grad=False)
+                                     need_grad=False, ref_std=ref_std)
             trace["target_loss"].append(tl)
         if timer is not None:
             timer(count, time.perf_counter() - t0)

@@ -130,6 +130,9 @@ class GaussianMixture:
         return self.modes[choice] + self.chol_covs[choice] * prng.normal_rows(kk[:, 1], self.dim)
 
 
+REF_VARS = {"stdgauss": 1.0, "widegauss": 5.0}      # exe_flow_matching.py:48-54 (the entries that can be constructed)
+
+
 class IndepGaussian:
     """``distributions.py:80-97`` (the flow's base distribution, 'stdgauss' by default)."""
 

@@ -53,6 +53,7 @@ def make_ctx(dist, args, n_local=None, n_total=None, offset=0, fourier=None, par
         learning_rate=args.learning_rate, adam_b1=args.adam_beta1, adam_b2=args.adam_beta2, adam_eps=args.adam_epsilon,
         weight_decay=args.weight_decay, update_clip=args.gradient_clip, learning_iter=args.learning_iter,
         warmup_steps=args.warmup_steps, max_eval_samples=max_eval, activation=_lib.ACTIVATIONS[args.non_linearity],
+        ref_std=float(np.sqrt(targets.REF_VARS[getattr(args, "ref_dist", "stdgauss")])),
         **({} if family is None else {"kernel_family": family}))
     kind, blk = target_block(dist)
     ctx.set_target(kind, blk)
