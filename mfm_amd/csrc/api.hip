@@ -800,6 +800,11 @@ extern "C" int mfm_gather_rows(mfm_ctx* x, const float* d_src, const int32_t* d_
   return MFM_OK;
 }
 
+#ifdef MFM_FM_STAMPS
+extern "C" int mfm_debug_fm_buffer(unsigned long long* d_buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fm_dbg), &d_buf, sizeof d_buf) == hipSuccess ? 0 : MFM_EHIP;
+}
+#endif
 #ifdef MFM_STAMPS
 extern "C" int mfm_debug_flow_buffer(unsigned long long* d_buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_flow_dbg), &d_buf, sizeof d_buf) == hipSuccess ? 0 : MFM_EHIP;

@@ -8,6 +8,13 @@
 #include "mlp.cuh"
 #include "prng.cuh"
 
+#ifdef MFM_FM_STAMPS
+__device__ unsigned long long* g_fm_dbg = nullptr;      // [WG][32] section time stamps (development build only)
+#define FM_STAMP(id) do { if (g_fm_dbg && threadIdx.x == 0) g_fm_dbg[blockIdx.x * 32 + (id)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FM_STAMP(id) do {} while (0)
+#endif
+
 struct WsLayout {            // tile-row offsets (units: NBB * 256 floats) into the packed activation workspaces
   int a_ffat, a_t1, a_st, a_cond, a_x1, a_sx, a_j1, a_j2, a_tiles;
   int z_t1, z_t2, z_x1, z_x2, z_gate, z_j1, z_j2, z_out, z_tiles;
@@ -89,6 +96,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   float* bDV = lds + L.dv;  float* bD1 = lds + L.d1; float* bD2 = lds + L.d2; float* bDC = lds + L.dcat;
   float* gcs = lds + L.gcs; double* red = reinterpret_cast<double*>(lds + L.red); float* bGC = lds + L.gc;
 
+  FM_STAMP(0);
   // ---------------- prologue: K3 batch construction (exe_flow_matching.py:151-169 / :139-147) ----------------
   for (int i = threadIdx.x; i < 16 * L.ldx; i += (MLP_WAVES_FM * 64)) bX[i] = 0.f;      // pads (incl. x[-1], x[d..])
   __syncthreads();
@@ -134,6 +142,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     }
     if (TRAIN && nt * 16 < n.dp) store_packed(a.acts, a.ws.a_cond + nt, nbb, bb, lane, cv);
   }
+  FM_STAMP(1);
   // Fourier features of t (:70-71): cos block then sin block
   if (n.F % 16 == 0) {          // tile-aligned halves: one sincos per (row, frequency) feeds both
     const int FT = n.F / 16;
@@ -184,6 +193,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     for (int j = 0; j < d; ++j) gcs[threadIdx.x * 8 + j] = gg[j];
   }
 
+  FM_STAMP(2);
   // ---------------- forward ----------------------------------------------------------------------------------
   auto relu_store = [&](const LayerDesc& ld, float* out, int ldo, int coff, int a_tile) {
     return [&, out, ldo, coff, a_tile](int q, int nt, int m, f32x4 acc, float bias) {
@@ -228,6 +238,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   layer_gemm<1, MLP_WAVES_FM>(bJ1, L.ldj1, n.Wp + n.L[6].w_off, n.bias + n.L[6].b_off, n.L[6].Kp / 16, n.L[6].Np / 16, wave, lane,
                    relu_store(n.L[6], bJ2, L.ldj2, 0, a.ws.a_j2));
   __syncthreads();
+  FM_STAMP(3);
   // output layer + loss (:88-90, :177-178); dv = 2 (v - target), dgate = dv * clip(grad log pi)
   float loss_loc = 0.f;
   layer_gemm<1, MLP_WAVES_FM>(bJ2, L.ldj2, n.Wp + n.L[7].w_off, n.bias + n.L[7].b_off, n.L[7].Kp / 16, n.L[7].Np / 16, wave, lane,
@@ -266,6 +277,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     for (int w = 0; w < MLP_WAVES_FM; ++w) tot += red[w];
     a.loss_part[blockIdx.x] = tot;
   }
+  FM_STAMP(4);
   if (!TRAIN) return;
 
   // ---------------- backward (data gradients only; weight gradients: wgrad_kernel) -----------------------------
@@ -339,6 +351,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                      for (int i = 0; i < 4; ++i) z[i] = mask_out(bT1[(4 * g + i) * L.ldt1 + nt * 16 + c], acc[i], n.act);
                      store_packed(a.dzs, a.ws.z_t1 + nt, nbb, bb, lane, z);
                    });
+  FM_STAMP(5);
 }
 
 // ---- weight gradients: dW[k][n] = sum_b A[b][k] dZ[b][n], db[n] = sum_b dZ[b][n] ------------------------------
