@@ -161,7 +161,8 @@ __device__ static const float C5[5] = {1.f / 5, 3.f / 10, 4.f / 5, 8.f / 9, 1.f}
 
 // Row-state fields beyond ode.hip's RS_* (0..15), used by the flow step's per-row solve phases (solve2): every chain of a
 // tile runs its OWN sequence inverse solve -> proposal -> forward solve; the tile only shares the attempt clock.
-enum { RS_MODE = 16, RS_SOLVE = 17, RS_SIGN = 18, RS_VOL0 = 19, RS_NTOT = 20, RS_LQ = 21, RS_SW = 22, RS_TILE = 23 };
+enum { RS_MODE = 16, RS_SOLVE = 17, RS_SIGN = 18, RS_VOL0 = 19, RS_NTOT = 20, RS_LQ = 21, RS_SW = 22, RS_TILE = 23,
+       RS_RANK = 13 /* = RS_DONE, unused by solve2: rank of the row among the rows still integrating, -1 otherwise */ };
 enum { RM_INIT0 = 0, RM_INIT1 = 1, RM_ATT = 2, RM_DONE = 3 };
 
 template <int D>
@@ -179,6 +180,7 @@ struct FTile {
   // partial-sum writes, bias column, A-fragment reads and owned-element accesses in the X / Z buffers, A-fragment reads
   // and epilogue writes in region R and in R2 = R + 64 LDH
   int o_rs, o_pg, o_pp, o_bias, o_xa, o_xo, o_ha, o_ha2, o_he, o_he2, o_l8, o_l1;    // o_l8 / o_l1: row leaders (row = lane)
+  int o_hc;                     // region R, row 0, this lane's column (compact time batch: the row is data dependent)
   __device__ __forceinline__ float* at(int off_bytes, int cfloats) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + off_bytes) + cfloats; }
 #ifdef MFM_STAMPS
   unsigned long long n_eval = 0, cyc_eval = 0, n_tb = 0, cyc_tb = 0, cyc_sec[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sec_t0 = 0;
@@ -227,16 +229,22 @@ struct FTile {
   // Entry: P = first group of W0 tile `wave`; row state visible.  Exit: P = first group of W2 tile `wave` (x1), and a
   // barrier has passed since every LDS access of this routine (region R is free for the x branch; a stage input written
   // by the caller BEFORE this call is visible).
-  template <bool ROWMODE = false>
+  // MTB = 5: the 80 (stage, row) pairs of the tile, stage-major (M-row 16 s + row).  MTB = 1 (flow step, <= 3 rows still
+  // integrating): the <= 15 pairs of the ACTIVE rows compacted into ONE M tile (M-row 3 s + rank(row)) -- a fifth of the
+  // matrix work of the time branch for the attempts of a tile's tail, which is what the launch waits for.
+  template <bool ROWMODE = false, int MTB = 5>
   __device__ __forceinline__ void tbatch(int phase, f32x4 (&P)[4], f32x4 (&Q)[4]) {
 #ifdef MFM_STAMPS
     sec_t0 = __builtin_amdgcn_s_memtime();
 #endif
+    constexpr bool CMP = MTB == 1;
+    int mrow[5][4];                         // compact mode: LDS row of (stage s, this lane's row i), -1: row not integrating
     {
       float sv[5][4];
       const f32x4 t4 = rs_get(RS_T), h4 = rs_get(phase == 1 ? RS_H0 : RS_DT);
-      f32x4 md4 = {2.f, 2.f, 2.f, 2.f}, sg4 = {(float)sign, (float)sign, (float)sign, (float)sign};
+      f32x4 md4 = {2.f, 2.f, 2.f, 2.f}, sg4 = {(float)sign, (float)sign, (float)sign, (float)sign}, rk4 = {0.f, 0.f, 0.f, 0.f};
       if constexpr (ROWMODE) { md4 = rs_get(RS_MODE); sg4 = rs_get(RS_SIGN); }
+      if constexpr (CMP) rk4 = rs_get(RS_RANK);
       const double f = (double)ffreq;
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
@@ -252,7 +260,12 @@ struct FTile {
           ft -= rint(ft);
           float cv;
           sincospif(2.f * (float)ft, &sv[s][i], &cv);                          // :70-71
-          *at(o_he, (s * 16 + i) * LDH) = cv;
+          if constexpr (CMP) {
+            mrow[s][i] = rk4[i] >= 0.f ? 3 * s + (int)rk4[i] : -1;
+            if (mrow[s][i] >= 0) *at(o_hc, mrow[s][i] * LDH) = cv;
+          } else {
+            *at(o_he, (s * 16 + i) * LDH) = cv;
+          }
         }
         // the sine block waits in this lane's scratch slot of the stage (rewritten by the gate epilogue afterwards)
         bstore(sr, lane * 16, ((s * NW + wave) * 3 + 0) * 1024, f32x4{sv[s][0], sv[s][1], sv[s][2], sv[s][3]});
@@ -261,38 +274,56 @@ struct FTile {
     FSEC(0);
     __syncthreads();
     FSEC(1);
-    f32x4 acc[1][5];
-#pragma unroll
-    for (int m = 0; m < 5; ++m) acc[0][m] = f32x4{0, 0, 0, 0};
     const float* afh = at(o_ha, 0);
-    run_job<5, 1, 8, LDH, 0, 1, 0>(afh, wr, W(S::W0, wave, 16, 0), W(S::W0, wave, 16, 8), lane, P, Q, acc);      // cos half
+    // MTB = 1 runs its single tile with two accumulators (even / odd k-blocks): one dependent MFMA chain per wave would leave
+    // the matrix pipe waiting on its own latency.  That reassociates the k-sum of the time branch (float rounding only): a
+    // row's attempts after its tile compacts can differ in the last bits from the stage-major schedule.  Tiles are fixed
+    // groups of 16 consecutive global chains, so results stay deterministic and independent of the sharding.  (Giving the
+    // MTB = 5 mode the same even / odd order -- 10 accumulators -- cost it 6 %: measured, not kept.)
+    f32x4 acc[1][MTB], ac2[2];
+    auto zero = [&]() {
+#pragma unroll
+      for (int m = 0; m < MTB; ++m) acc[0][m] = f32x4{0, 0, 0, 0};
+      ac2[0] = f32x4{0, 0, 0, 0}; ac2[1] = f32x4{0, 0, 0, 0};
+    };
+    auto job = [&](const float* arow, int w, int wnext) {
+      if constexpr (CMP) run_job<1, 1, 8, LDH, 0, 1, 0, true>(arow, wr, w, wnext, lane, P, Q, ac2);
+      else run_job<5, 1, 8, LDH, 0, 1, 0>(arow, wr, w, wnext, lane, P, Q, acc);
+    };
+    auto fold = [&]() { if constexpr (CMP) acc[0][0] = ac2[0] + ac2[1]; };
+    zero();
+    job(afh, W(S::W0, wave, 16, 0), W(S::W0, wave, 16, 8));      // cos half
     FSEC(2);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       const f32x4 sn = bload(sr, lane * 16, ((s * NW + wave) * 3 + 0) * 1024);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *at(o_he, (s * 16 + i) * LDH) = sn[i];
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (CMP) { if (mrow[s][i] >= 0) *at(o_hc, mrow[s][i] * LDH) = sn[i]; }
+        else *at(o_he, (s * 16 + i) * LDH) = sn[i];
+      }
     }
     __syncthreads();
     FSEC(3);
-    run_job<5, 1, 8, LDH, 0, 1, 0>(afh, wr, W(S::W0, wave, 16, 8), W(S::W1, wave, 8), lane, P, Q, acc);           // sin half
+    job(afh, W(S::W0, wave, 16, 8), W(S::W1, wave, 8));           // sin half (accumulates on the cos half)
+    fold();
     {
       const float b = bias(S::B0);
 #pragma unroll
-      for (int m = 0; m < 5; ++m)
+      for (int m = 0; m < MTB; ++m)
 #pragma unroll
         for (int i = 0; i < 4; ++i) *at(o_he2, (16 + m * 16 + i) * LDH) = fmaxf(acc[0][m][i] + b, 0.f);
     }
     __syncthreads();
     FSEC(4);
-#pragma unroll
-    for (int m = 0; m < 5; ++m) acc[0][m] = f32x4{0, 0, 0, 0};
-    run_job<5, 1, 8, LDH, 0, 1, 0>(at(o_ha2, 16 * LDH), wr, W(S::W1, wave, 8), W(S::W4, wave, 8), lane, P, Q, acc);
+    zero();
+    job(at(o_ha2, 16 * LDH), W(S::W1, wave, 8), W(S::W4, wave, 8));
+    fold();
     {
       const float b = bias(S::B1);
 #pragma unroll
-      for (int m = 0; m < 5; ++m)
+      for (int m = 0; m < MTB; ++m)
 #pragma unroll
         for (int i = 0; i < 4; ++i) *at(o_he, (m * 16 + i) * LDH) = fmaxf(acc[0][m][i] + b, 0.f);   // st
     }
@@ -302,19 +333,19 @@ struct FTile {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {        // gate tiles wave, wave + 8 (D = 256; D = 128: one tile), then the st half of j1
       if (q == 1 && TPW == 1) continue;
-#pragma unroll
-      for (int m = 0; m < 5; ++m) acc[0][m] = f32x4{0, 0, 0, 0};
+      zero();
       float b;
       if (q < 2) {
         const int nxt = (q == 0 && TPW == 2) ? W(S::W4, wave + 8, 8) : W(S::W5, wave, 16, 8);
-        run_job<5, 1, 8, LDH, 0, 1, 0>(ast, wr, W(S::W4, wave + 8 * q, 8), nxt, lane, P, Q, acc);
+        job(ast, W(S::W4, wave + 8 * q, 8), nxt);
         b = bias(S::B4 + 128 * q);
       } else {
-        run_job<5, 1, 8, LDH, 0, 1, 0>(ast, wr, W(S::W5, wave, 16, 8), W(S::W2, wave, D / 16), lane, P, Q, acc);
+        job(ast, W(S::W5, wave, 16, 8), W(S::W2, wave, D / 16));
         b = bias(S::B5);
       }
+      fold();
 #pragma unroll
-      for (int m = 0; m < 5; ++m) bstore(sr, lane * 16, ((m * NW + wave) * 3 + q) * 1024, f32x4{acc[0][m][0] + b, acc[0][m][1] + b, acc[0][m][2] + b, acc[0][m][3] + b});
+      for (int m = 0; m < MTB; ++m) bstore(sr, lane * 16, ((m * NW + wave) * 3 + q) * 1024, f32x4{acc[0][m][0] + b, acc[0][m][1] + b, acc[0][m][2] + b, acc[0][m][3] + b});
     }
     FSEC(6);
     __syncthreads();
@@ -326,16 +357,29 @@ struct FTile {
   // elements (row 4g+i, col 16 (wave + 8 q) + c); this wave's divergence partials in DLP[dst]; P = first group of
   // `wnext` (W2: another evaluation follows, W0: a time batch follows).
   __device__ __forceinline__ void eval(int slot, int cur, int dst, bool next_is_tbatch, f32x4 (&P)[4], f32x4 (&Q)[4], float (&kv)[TPW][4],
-                                       const f32x4 sg) {
+                                       const f32x4 sg, bool compact = false, const f32x4 rk = f32x4{0.f, 0.f, 0.f, 0.f}) {
 #ifdef MFM_STAMPS
     sec_t0 = __builtin_amdgcn_s_memtime();
 #endif
     const int xsel = cur ? S::XB1 * 4 : S::XB0 * 4;
     // stage-time inputs of this lane, written by itself in tbatch
-    f32x4 gt[TPW];
+    f32x4 gt[TPW], j1t;
+    if (!compact) {
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) gt[q] = bload(sr, lane * 16, ((slot * NW + wave) * 3 + q) * 1024);
-    const f32x4 j1t = bload(sr, lane * 16, ((slot * NW + wave) * 3 + 2) * 1024);
+      for (int q = 0; q < TPW; ++q) gt[q] = bload(sr, lane * 16, ((slot * NW + wave) * 3 + q) * 1024);
+      j1t = bload(sr, lane * 16, ((slot * NW + wave) * 3 + 2) * 1024);
+    } else {
+      // compact time batch: (stage, row) sits in M-row 3 slot + rank(row) of the single tile, i.e. in element (mm & 3) of the
+      // float4 that lane 16 (mm >> 2) + c of this wave stored
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mm = 3 * slot + (rk[i] >= 0.f ? (int)rk[i] : 0);
+        const int vo = ((mm >> 2) * 16 + c) * 16 + (mm & 3) * 4;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) gt[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, vo, (wave * 3 + q) * 1024, 0));
+        j1t[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, vo, (wave * 3 + 2) * 1024, 0));
+      }
+    }
     // grad log pi(x) (clipped), the masked Hessian-vector product and z for this lane's out-layer elements.  Pure VALU
     // + LDS work on inputs known when the evaluation starts: waves 0-3 do it before their x1 job, waves 4-7 after theirs,
     // so on every SIMD one wave's VALU phase runs beside its partner's MFMAs instead of both stalling the matrix pipe
@@ -757,10 +801,11 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
         }
       }
     }
-    if (phase == 2) T.template tbatch<true>(2, P, Q); else __syncthreads();
+    const bool compact = *T.at(0, S::RS + RS_TILE * 16 + 1) != 0.f;        // <= 3 rows of the tile still integrate
+    if (phase == 2) { if (compact) T.template tbatch<true, 1>(2, P, Q); else T.template tbatch<true, 5>(2, P, Q); } else __syncthreads();
     float kv[TPW][4];
     const int dst = phase - 1;
-    T.eval(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN));
+    T.eval(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN), compact, T.rs_get(RS_RANK));
     cur ^= 1;
 #pragma unroll
     for (int j = 1; j < 7; ++j)
@@ -878,6 +923,10 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
       }
       R1(RS_FLAG) = flag; R1(RS_SW) = sw;
       any = R1(RS_MODE) != (float)RM_DONE ? 1 : 0;
+      // rank of this row among the rows that take part in the next attempt: with <= 3 of them the time batch is compacted
+      const unsigned long long bal = __ballot(any != 0);
+      R1(RS_RANK) = any ? (float)__popcll(bal & ((1ull << T.lane) - 1ull)) : -1.f;
+      if (T.lane == 0) *T.at(0, S::RS + RS_TILE * 16 + 1) = __popcll(bal) <= 3 ? 1.f : 0.f;
     }
     const int go = __syncthreads_or(any);
     // ---- every lane: apply the decision of its rows (branch-free selects) ----
@@ -947,7 +996,8 @@ __device__ __forceinline__ void tile_init(FTile<D>& T, const NetDev& n, float* l
     asm volatile("" : "+v"(T.o_rs), "+v"(T.o_pg), "+v"(T.o_pp), "+v"(T.o_bias), "+v"(T.o_xa));
     asm volatile("" : "+v"(T.o_xo), "+v"(T.o_ha), "+v"(T.o_ha2), "+v"(T.o_he), "+v"(T.o_he2));
     T.o_l8 = (T.lane & 15) * 32; T.o_l1 = (T.lane & 15) * 4;
-    asm volatile("" : "+v"(T.o_l8), "+v"(T.o_l1));
+    T.o_hc = (S::R + 16 * w + c) * 4;
+    asm volatile("" : "+v"(T.o_l8), "+v"(T.o_l1), "+v"(T.o_hc));
   }
   for (int i = threadIdx.x; i < S::TOTAL; i += NW * 64)
     if (i < S::BIAS || i >= S::BIAS + S::BTOT) lds[i] = 0.f;                   // halo pads, row state, scratch
