@@ -77,3 +77,70 @@ def test_hip_kernels_match_golden_vectors():
     # beta bisection
     assert abs(ctx.beta_update(0.0, dev(G["beta_ll"]), 0.95) - float(G["beta_0"])) < 1e-9
     ctx.close()
+
+
+# ---- second set: SMC pieces, non-default activations, widegauss reference distribution ------------------------------------
+GX = np.load(os.path.join(ROOT, "tests", "golden", "mfm_golden_ext.npz"))
+
+
+def test_oracle_reproduces_extended_golden_vectors():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden
+    now = make_golden.build_ext()
+    assert set(now) == set(GX.files)
+    for k in GX.files:
+        np.testing.assert_allclose(np.asarray(now[k], dtype=np.float64), np.asarray(GX[k], dtype=np.float64), rtol=1e-9, atol=1e-9, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_hip_kernels_match_extended_golden_vectors():
+    import torch
+    from mfm_amd import _lib
+    from tests import gpu_util as gu
+    dev = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()
+    # SMC pieces
+    args, dist, kk, model, state = gu.phi4_setup(d=64, B=256, hidden=32, F=16)
+    ctx = gu.make_ctx(dist, args)
+    ll = dev(GX["smc_ll"])
+    assert abs(ctx.smc_delta(ll, 0.95, 1.0) - float(GX["smc_delta"])) < 1e-9
+    w = torch.empty(256, dtype=torch.float64, device="cuda")
+    lognorm = ctx.smc_weights(ll, float(GX["smc_delta"]), w)
+    np.testing.assert_allclose(w.cpu().numpy(), GX["smc_weights"], rtol=1e-12)
+    assert abs(lognorm - float(GX["smc_lognorm"])) < 1e-10
+    idx = torch.empty(256, dtype=torch.int32, device="cuda"); scr = torch.empty(256, dtype=torch.float64, device="cuda")
+    ctx.smc_resample(GX["smc_key"], dev(GX["smc_weights"]), scr, idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), GX["smc_idx"])
+    ctx.close()
+    # activations (tanh: fused family, gelu: wide family)
+    for act in ("tanh", "gelu"):
+        args, dist, kk, model, state = gu.phi4_setup(d=64, B=32, hidden=32, F=16, non_linearity=act)
+        ctx = gu.make_ctx(dist, args, fourier=GX[f"{act}_fourier"], params=gu.unflat_params(model, GX[f"{act}_params"]))
+        x0 = dev(GX[f"{act}_x0"], torch.float32)
+        v = torch.empty(32, 64, device="cuda"); jv = torch.empty_like(v)
+        ctx.vf_apply(x0, dev(GX[f"{act}_t"]), v, dev(GX[f"{act}_z"]), jv)
+        assert np.abs(v.cpu().numpy() - GX[f"{act}_v"]).max() < 3e-5 * np.abs(GX[f"{act}_v"]).max()
+        assert np.abs(jv.cpu().numpy() - GX[f"{act}_jvp"]).max() < 3e-5 * np.abs(GX[f"{act}_jvp"]).max()
+        loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctx.n_params, device="cuda")
+        ctx.fm_loss_grad(GX[f"{act}_key"], x0, loss, grads)
+        assert abs(loss.item() - float(GX[f"{act}_loss"])) < 2e-5 * float(GX[f"{act}_loss"])
+        assert np.abs(grads.cpu().numpy() - GX[f"{act}_grads"]).max() < 3e-4 * np.abs(GX[f"{act}_grads"]).max()
+        ctx.close()
+    # widegauss reference distribution
+    args, dist, kk, model, state = gu.phi4_setup(d=64, B=32, hidden=32, F=16, ref_dist="widegauss")
+    ctx = gu.make_ctx(dist, args, fourier=GX["wg_fourier"], params=gu.unflat_params(model, GX["wg_params"]))
+    x0 = dev(GX["wg_x0"], torch.float32)
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctx.n_params, device="cuda")
+    ctx.fm_loss_grad(GX["wg_key"], x0, loss, grads)
+    assert abs(loss.item() - float(GX["wg_loss"])) < 2e-5 * float(GX["wg_loss"])
+    pos = x0.clone(); logp = torch.empty(32, dtype=torch.float64, device="cuda"); grad = torch.empty(32, 64, device="cuda")
+    ctx.mala_init(pos, 0.8, logp, grad)
+    acc = torch.empty(32, device="cuda"); isacc = torch.empty(32, dtype=torch.uint8, device="cuda"); prop = torch.empty(32, 64, device="cuda")
+    ctx.flow_step(_lib.FLOW_IMH, GX["wg_imh_key"], 0.8, pos, logp, grad, acc, isacc, prop, None)
+    assert np.abs(prop.cpu().numpy() - GX["wg_imh_prop"]).max() < 5e-3 * max(1.0, np.abs(GX["wg_imh_prop"]).max())
+    with np.errstate(divide="ignore"):
+        la = np.log(acc.cpu().numpy().astype(np.float64))
+    fin = np.isfinite(la) & np.isfinite(GX["wg_imh_logacc"])
+    if fin.any():
+        assert np.abs(la[fin] - GX["wg_imh_logacc"][fin]).max() < 0.5 + 2e-4 * np.abs(GX["wg_imh_logacc"][fin]).max()
+    ctx.close()

@@ -75,8 +75,53 @@ def build():
     return out
 
 
+def build_ext():
+    """Second set (tests/golden/mfm_golden_ext.npz): the rows added after the first set was frozen -- the tempered-SMC pieces
+    (N4), the non-default activations, the 'widegauss' reference distribution."""
+    from oracle import smc
+    out = {}
+    rng = np.random.default_rng(1)
+    # ---- SMC pieces (bblackjax/smc) ----
+    ll = rng.standard_normal(256) * 40 - 300
+    key = prng.PRNGKey(9)
+    delta = float(np.clip(smc.ess_solver(ll, 0.95, 1.0), 0.0, 1.0))
+    lw = delta * ll
+    w = np.exp(lw - smc.logsumexp(lw))
+    out.update(smc_ll=ll, smc_delta=delta, smc_weights=w, smc_lognorm=smc.logsumexp(lw) - np.log(256), smc_key=key,
+               smc_idx=smc.systematic(key, w, 256))
+    # ---- activations: vector field / JVP and loss for tanh and gelu on one small configuration ----
+    for act in ("tanh", "gelu"):
+        args, dist, kk, model, state = gu.phi4_setup(d=64, B=32, hidden=32, F=16, non_linearity=act)
+        params = gu.rand_params(model, seed=12)
+        x0 = dist.init_params.astype(np.float32).astype(np.float64)
+        t = rng.uniform(0, 1, 32).astype(np.float32); z = rng.standard_normal((32, 64)).astype(np.float32)
+        v, jv = model.forward(params, x0, t.astype(np.float64), tangent=z.astype(np.float64))
+        kf = prng.PRNGKey(13)
+        loss, grads = fm.loss_and_grad(model, params, kf, x0, args.sigma)
+        out.update({f"{act}_fourier": model.f, f"{act}_params": gu.flat_params(params), f"{act}_x0": x0, f"{act}_t": t, f"{act}_z": z,
+                    f"{act}_v": v, f"{act}_jvp": jv, f"{act}_key": kf, f"{act}_loss": loss, f"{act}_grads": gu.flat_params(grads)})
+    # ---- widegauss reference distribution: training batch loss, independent-MH step ----
+    args, dist, kk, model, state = gu.phi4_setup(d=64, B=32, hidden=32, F=16, ref_dist="widegauss")
+    params = gu.rand_params(model, seed=14, out_scale=0.05)
+    params[4]["kernel"] *= 1e-3; params[4]["bias"] *= 1e-3
+    x0 = dist.init_params.astype(np.float32).astype(np.float64)
+    kf = prng.PRNGKey(15)
+    loss, grads = fm.loss_and_grad(model, params, kf, x0, args.sigma, ref_std=np.sqrt(5.0))
+    vg = targets.Tempered(dist, 0.8).value_and_grad
+    st = mala.init(x0, vg)
+    ki = prng.PRNGKey(16)
+    new, info = flow.imh_step(prng.split(ki, 32), st, vg, model, params, args)
+    with np.errstate(divide="ignore"):
+        out.update(wg_fourier=model.f, wg_params=gu.flat_params(params), wg_x0=x0, wg_key=kf, wg_loss=loss, wg_grads=gu.flat_params(grads),
+                   wg_imh_key=ki, wg_imh_prop=info.proposed_position, wg_imh_logacc=np.log(info.acceptance_rate), wg_imh_isacc=info.is_accepted)
+    return out
+
+
 if __name__ == "__main__":
-    o = build()
-    path = os.path.join(ROOT, "tests", "golden", "mfm_golden.npz")
-    np.savez_compressed(path, **o)
-    print(path, os.path.getsize(path), "bytes,", len(o), "arrays")
+    for name, fn in (("mfm_golden.npz", build), ("mfm_golden_ext.npz", build_ext)):
+        path = os.path.join(ROOT, "tests", "golden", name)
+        if name == "mfm_golden.npz" and os.path.exists(path) and "--all" not in sys.argv:
+            continue                     # the first set stays frozen unless asked for
+        o = fn()
+        np.savez_compressed(path, **o)
+        print(path, os.path.getsize(path), "bytes,", len(o), "arrays")
