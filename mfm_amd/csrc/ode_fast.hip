@@ -183,6 +183,7 @@ struct FTile {
   int o_hc;                     // region R, row 0, this lane's column (compact time batch: the row is data dependent)
   __device__ __forceinline__ float* at(int off_bytes, int cfloats) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + off_bytes) + cfloats; }
 #ifdef MFM_STAMPS
+  unsigned long long n_tc = 0, cyc_tc = 0;      // compacted time batches
   unsigned long long n_eval = 0, cyc_eval = 0, n_tb = 0, cyc_tb = 0, cyc_sec[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sec_t0 = 0;
 #define FSEC(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cyc_sec[i] += t_ - sec_t0; sec_t0 = t_; } while (0)
 #else
@@ -802,10 +803,20 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
       }
     }
     const bool compact = *T.at(0, S::RS + RS_TILE * 16 + 1) != 0.f;        // <= 3 rows of the tile still integrate
+#ifdef MFM_STAMPS
+    const unsigned long long c0_ = __builtin_amdgcn_s_memtime();
+#endif
     if (phase == 2) { if (compact) T.template tbatch<true, 1>(2, P, Q); else T.template tbatch<true, 5>(2, P, Q); } else __syncthreads();
+#ifdef MFM_STAMPS
+    const unsigned long long c1_ = __builtin_amdgcn_s_memtime();
+    if (phase == 2) { if (compact) { T.cyc_tc += c1_ - c0_; T.n_tc += 1; } else { T.cyc_tb += c1_ - c0_; T.n_tb += 1; } }
+#endif
     float kv[TPW][4];
     const int dst = phase - 1;
     T.eval(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN), compact, T.rs_get(RS_RANK));
+#ifdef MFM_STAMPS
+    T.cyc_eval += __builtin_amdgcn_s_memtime() - c1_; T.n_eval += 1;
+#endif
     cur ^= 1;
 #pragma unroll
     for (int j = 1; j < 7; ++j)
@@ -1159,7 +1170,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
   if (g_flow_dbg && (threadIdx.x == 0 || threadIdx.x == 256)) {
     unsigned long long* o = g_flow_dbg + (blockIdx.x + (threadIdx.x ? gridDim.x : 0)) * 32;
     o[0] = __builtin_amdgcn_s_memtime() - fc0_; o[1] = __builtin_amdgcn_s_memrealtime() - fr0_;
-    o[2] = T.n_eval; o[3] = T.cyc_eval; o[5] = T.n_tb; o[6] = T.cyc_tb;
+    o[2] = T.n_eval; o[3] = T.cyc_eval; o[5] = T.n_tb; o[6] = T.cyc_tb; o[28] = T.n_tc; o[29] = T.cyc_tc;
     for (int i = 0; i < 20; ++i) o[8 + i] = T.cyc_sec[i];
   }
 #endif

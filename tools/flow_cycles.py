@@ -54,6 +54,10 @@ for count in range(1, 304):
         if d4[:, 16:28].max() > 0:
             print("   WAVE 4 eval sections: jobs x1,x2,j1,j2,out:", (np.median(d4[:, 16:21] / d4[:, 2:3], axis=0)).astype(int), " epilogue before barrier 1..4:", (np.median(d4[:, 21:25] / d4[:, 2:3], axis=0)).astype(int), " out epilogue:", int(np.median(d4[:, 25] / d4[:, 2])), " 4 barriers:", int(np.median(d4[:, 26] / d4[:, 2])), "eval total", int(np.median(d4[:, 3] / d4[:, 2])))
             print("   WAVE 4 time-batch sections:", (np.median(d4[:, 8:16] / d4[:, 5:6], axis=0)).astype(int))
+        if d[:, 28].max() > 0:
+            nct, cct = d[:, 28], d[:, 29]
+            f = nct > 0
+            print(f"   compacted time batches (<= 3 rows): per WG mean {nct.mean():.0f}, slowest WG {nct[np.argmax(cyc)]:.0f}; cycles/batch {np.median(cct[f] / nct[f]):.0f}")
         print(f"   WG time: mean/max {cyc.mean()/cyc.max():.3f}; alg evals (4+6 natt) mean {4+6*n.mean():.0f}; executed/alg {nev.mean()/(4+6*n.mean()):.3f}; max-WG/alg {nev.max()/(4+6*n.mean()):.3f}")
     else:
         ctx.mala_step(kg, 1.0, args.step_size, pos, logp, grad, acc)
