@@ -11,7 +11,7 @@ next) trains it so the timed flow steps integrate a non-trivial field.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-K should be a multiple of the 101-iteration cycle (default 202 = two cycles: 2 flow steps + 200 MALA iterations, the mix the
+K should be a multiple of the 101-iteration cycle (default 1010 = ten cycles: 10 flow steps + 1000 MALA iterations, the mix the
 metric is defined on); other values are timed as asked, and "flow_steps_timed" in the output says what the window held.
 
 Prints ONE JSON line (rank 0).  value = (chains over all GPUs) * K / (max-over-ranks wall time of the K steps).
@@ -116,7 +116,9 @@ def pmc_traffic(kernel_class):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=202)       # two full (K+1)-cycles
+    ap.add_argument("--steps", type=int, default=1010)      # ten full (K+1)-cycles: a flow step lasts as long as its SLOWEST chain (an
+                                                             # extreme statistic of 4096 adaptive solves: 510..620 attempted steps from
+                                                             # one flow step to the next), so two cycles are a noisy sample of it
     ap.add_argument("--warmup", type=int, default=201)      # one full cycle (incl. its flow step: first launch, scratch set-up) + the
                                                              # MALA iterations of the next: the timed region then holds two complete
                                                              # cycles, each STARTING with its flow step (whose tail produces the draws
@@ -150,8 +152,8 @@ def main():
     wl_example, wl_dim, wl_h, _, wl_chains, wl_K = WORKLOADS[a.workload]
     if not a.chains_per_gpu:
         a.chains_per_gpu = wl_chains
-    if a.workload == "pines" and a.steps == 202 and a.warmup == 201:      # one cycle is enough at this size
-        a.steps, a.warmup = 101, 100
+    if a.workload == "pines" and a.steps == 1010 and a.warmup == 201:     # three cycles at this size
+        a.steps, a.warmup = 303, 100
     n_total = a.chains_per_gpu * world            # weak scaling: per-GPU work fixed
     args = make_args(n_total, learning_iter=10000, workload=a.workload)
     dist = PhiFour(wl_dim) if a.workload == "phi-four" else LogGaussianCoxPines(wl_dim)
