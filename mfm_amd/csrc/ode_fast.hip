@@ -181,9 +181,11 @@ struct FTile {
   // and epilogue writes in region R and in R2 = R + 64 LDH
   int o_rs, o_pg, o_pp, o_bias, o_xa, o_xo, o_ha, o_ha2, o_he, o_he2, o_l8, o_l1;    // o_l8 / o_l1: row leaders (row = lane)
   int o_hc;                     // region R, row 0, this lane's column (compact time batch: the row is data dependent)
+  int o_xc;                     // X buffers, row 0, this lane's column (compact evaluation: rows are ranks)
   __device__ __forceinline__ float* at(int off_bytes, int cfloats) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + off_bytes) + cfloats; }
 #ifdef MFM_STAMPS
   unsigned long long n_tc = 0, cyc_tc = 0;      // compacted time batches
+  unsigned long long n_ec = 0, cyc_ec = 0;      // compact evaluations
   unsigned long long n_eval = 0, cyc_eval = 0, n_tb = 0, cyc_tb = 0, cyc_sec[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sec_t0 = 0;
 #define FSEC(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cyc_sec[i] += t_ - sec_t0; sec_t0 = t_; } while (0)
 #else
@@ -233,39 +235,51 @@ struct FTile {
   // MTB = 5: the 80 (stage, row) pairs of the tile, stage-major (M-row 16 s + row).  MTB = 1 (flow step, <= 3 rows still
   // integrating): the <= 15 pairs of the ACTIVE rows compacted into ONE M tile (M-row 3 s + rank(row)) -- a fifth of the
   // matrix work of the time branch for the attempts of a tile's tail, which is what the launch waits for.
+  // Fourier features of the stage times (:70-71): ONE copy of the sincos code, shared by every time-batch variant (the
+  // three variants of the matrix part below used to carry it each: 3 x ~10 KB of a 64 KB instruction cache shared by two CUs)
+  template <bool ROWMODE>
+  __device__ __forceinline__ void tb_trig(int phase, float (&cv)[5][4], float (&sv)[5][4]) {
+    const f32x4 t4 = rs_get(RS_T), h4 = rs_get(phase == 1 ? RS_H0 : RS_DT);
+    f32x4 md4 = {2.f, 2.f, 2.f, 2.f}, sg4 = {(float)sign, (float)sign, (float)sign, (float)sign};
+    if constexpr (ROWMODE) { md4 = rs_get(RS_MODE); sg4 = rs_get(RS_SIGN); }
+    const double f = (double)ffreq;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const float cs = phase == 0 ? 0.f : (phase == 1 ? 1.f : C5[s]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // a row in its initial-step phases rides along the attempt: INIT0 has dt = 0 (every slot is t0), INIT1 has
+        // dt = h0 and takes the extra evaluation of the step-size heuristic in slot 0 at t0 + h0
+        const float csr = ROWMODE ? (md4[i] == (float)RM_INIT1 ? (s == 0 ? 1.f : 0.f) : cs) : cs;
+        const float tt = t4[i] + h4[i] * csr;
+        const double te = sg4[i] > 0.f ? (double)tt : 1.0 - (double)tt;          // :229
+        double ft = f * te;
+        ft -= rint(ft);
+        sincospif(2.f * (float)ft, &sv[s][i], &cv[s][i]);                      // :70-71
+      }
+    }
+  }
+
   template <bool ROWMODE = false, int MTB = 5>
-  __device__ __forceinline__ void tbatch(int phase, f32x4 (&P)[4], f32x4 (&Q)[4]) {
+  __device__ __forceinline__ void tbatch(int phase, f32x4 (&P)[4], f32x4 (&Q)[4], const float (&cv)[5][4], const float (&sv)[5][4]) {
+    constexpr int RPS = MTB == 1 ? 3 : 8;   // compact modes: rows per stage (M-row RPS * s + rank)
 #ifdef MFM_STAMPS
     sec_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    constexpr bool CMP = MTB == 1;
+    constexpr bool CMP = MTB != 5;
     int mrow[5][4];                         // compact mode: LDS row of (stage s, this lane's row i), -1: row not integrating
     {
-      float sv[5][4];
-      const f32x4 t4 = rs_get(RS_T), h4 = rs_get(phase == 1 ? RS_H0 : RS_DT);
-      f32x4 md4 = {2.f, 2.f, 2.f, 2.f}, sg4 = {(float)sign, (float)sign, (float)sign, (float)sign}, rk4 = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (ROWMODE) { md4 = rs_get(RS_MODE); sg4 = rs_get(RS_SIGN); }
+      f32x4 rk4 = {0.f, 0.f, 0.f, 0.f};
       if constexpr (CMP) rk4 = rs_get(RS_RANK);
-      const double f = (double)ffreq;
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
-        const float cs = phase == 0 ? 0.f : (phase == 1 ? 1.f : C5[s]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          // a row in its initial-step phases rides along the attempt: INIT0 has dt = 0 (every slot is t0), INIT1 has
-          // dt = h0 and takes the extra evaluation of the step-size heuristic in slot 0 at t0 + h0
-          const float csr = ROWMODE ? (md4[i] == (float)RM_INIT1 ? (s == 0 ? 1.f : 0.f) : cs) : cs;
-          const float tt = t4[i] + h4[i] * csr;
-          const double te = sg4[i] > 0.f ? (double)tt : 1.0 - (double)tt;          // :229
-          double ft = f * te;
-          ft -= rint(ft);
-          float cv;
-          sincospif(2.f * (float)ft, &sv[s][i], &cv);                          // :70-71
           if constexpr (CMP) {
-            mrow[s][i] = rk4[i] >= 0.f ? 3 * s + (int)rk4[i] : -1;
-            if (mrow[s][i] >= 0) *at(o_hc, mrow[s][i] * LDH) = cv;
+            mrow[s][i] = rk4[i] >= 0.f ? RPS * s + (int)rk4[i] : -1;
+            if (mrow[s][i] >= 0) *at(o_hc, mrow[s][i] * LDH) = cv[s][i];
           } else {
-            *at(o_he, (s * 16 + i) * LDH) = cv;
+            *at(o_he, (s * 16 + i) * LDH) = cv[s][i];
           }
         }
         // the sine block waits in this lane's scratch slot of the stage (rewritten by the gate epilogue afterwards)
@@ -288,10 +302,10 @@ struct FTile {
       ac2[0] = f32x4{0, 0, 0, 0}; ac2[1] = f32x4{0, 0, 0, 0};
     };
     auto job = [&](const float* arow, int w, int wnext) {
-      if constexpr (CMP) run_job<1, 1, 8, LDH, 0, 1, 0, true>(arow, wr, w, wnext, lane, P, Q, ac2);
-      else run_job<5, 1, 8, LDH, 0, 1, 0>(arow, wr, w, wnext, lane, P, Q, acc);
+      if constexpr (MTB == 1) run_job<1, 1, 8, LDH, 0, 1, 0, true>(arow, wr, w, wnext, lane, P, Q, ac2);
+      else run_job<MTB, 1, 8, LDH, 0, 1, 0>(arow, wr, w, wnext, lane, P, Q, acc);
     };
-    auto fold = [&]() { if constexpr (CMP) acc[0][0] = ac2[0] + ac2[1]; };
+    auto fold = [&]() { if constexpr (MTB == 1) acc[0][0] = ac2[0] + ac2[1]; };
     zero();
     job(afh, W(S::W0, wave, 16, 0), W(S::W0, wave, 16, 8));      // cos half
     FSEC(2);
@@ -357,8 +371,17 @@ struct FTile {
   // Entry: X[cur] visible to the workgroup, P = first group of W2 tile `wave`.  Exit: kv = dx/dt of this lane's
   // elements (row 4g+i, col 16 (wave + 8 q) + c); this wave's divergence partials in DLP[dst]; P = first group of
   // `wnext` (W2: another evaluation follows, W0: a time batch follows).
+  // gate (q < TPW) / st contribution to j1 (q = 2) of (stage `slot`, rank `rank`) from a compacted time batch: M-row
+  // mm = rps * slot + rank, i.e. element (mm & 3) of the float4 that lane 16 ((mm & 15) >> 2) + c of this wave stored for M tile mm >> 4
+  __device__ __forceinline__ float tgather(int slot, int rank, int rps, int q) const {
+    const int mm = rps * slot + rank;
+    const int vo = (mm >> 4) * (NW * 3 * 1024) + (((mm & 15) >> 2) * 16 + c) * 16 + (mm & 3) * 4;
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, vo, (wave * 3 + q) * 1024, 0));
+  }
+
   __device__ __forceinline__ void eval(int slot, int cur, int dst, bool next_is_tbatch, f32x4 (&P)[4], f32x4 (&Q)[4], float (&kv)[TPW][4],
-                                       const f32x4 sg, bool compact = false, const f32x4 rk = f32x4{0.f, 0.f, 0.f, 0.f}) {
+                                       const f32x4 sg, int rps = 0, const f32x4 rk = f32x4{0.f, 0.f, 0.f, 0.f}) {
+    const bool compact = rps != 0;
 #ifdef MFM_STAMPS
     sec_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -374,11 +397,10 @@ struct FTile {
       // float4 that lane 16 (mm >> 2) + c of this wave stored
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int mm = 3 * slot + (rk[i] >= 0.f ? (int)rk[i] : 0);
-        const int vo = ((mm >> 2) * 16 + c) * 16 + (mm & 3) * 4;
+        const int rank = rk[i] >= 0.f ? (int)rk[i] : 0;
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) gt[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, vo, (wave * 3 + q) * 1024, 0));
-        j1t[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, vo, (wave * 3 + 2) * 1024, 0));
+        for (int q = 0; q < TPW; ++q) gt[q][i] = tgather(slot, rank, rps, q);
+        j1t[i] = tgather(slot, rank, rps, 2);
       }
     }
     // grad log pi(x) (clipped), the masked Hessian-vector product and z for this lane's out-layer elements.  Pure VALU
@@ -490,6 +512,116 @@ struct FTile {
       FSEC(17);
     }
   }
+
+  // lanes 32..63 receive the value of lane - 32 (v_permlane32_swap: lanes [32:63] of vdst <-> lanes [0:31] of src)
+  __device__ __forceinline__ float from_lower_half(float v) const {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, r[0]);
+  }
+
+  // ---- COMPACT field evaluation: at most 8 rows of the tile still integrate ----------------------------------------
+  // The full evaluation pushes 16 value rows and 16 tangent rows (two M tiles) through the x branch whatever the number of
+  // rows still integrating.  Here the value rows of the <= 8 active chains (by rank) and their tangent rows share ONE M
+  // tile: M-rows 0..7 = values of ranks 0..7, M-rows 8..15 = tangents of ranks 0..7 -- half the matrix work per evaluation
+  // for the attempts of a tile's tail, which is what the launch waits for.  In the accumulator, lane (g, c) holds M-rows
+  // 4g..4g+3: lanes 0..31 values, lanes 32..63 the tangents of the same (rank, column), so the activation mask crosses the
+  // wave halves with one v_permlane32_swap per element.  Inputs: X[cur] rows 0..7 = stage inputs by rank, rows 8..15 = the
+  // probes by rank (written by the owners: solve2).  The first x layer recomputes z W_x1 as its rows 8..15.  Results go
+  // back to the lanes that own the chain rows (Runge-Kutta registers) through rows 0..7 of the OTHER X buffer.
+  __device__ __forceinline__ void eval_c(int slot, int cur, int dst, bool next_is_tbatch, f32x4 (&P)[4], f32x4 (&Q)[4], float (&kv)[TPW][4],
+                                         const f32x4 sg, int rps, const f32x4 rk) {
+    const int xsel = cur ? S::XB1 * 4 : S::XB0 * 4, xoth = cur ? S::XB0 * 4 : S::XB1 * 4;
+    const bool is_t = g >= 2;
+    const int jr0 = 4 * (g & 1);                       // this lane's M-rows 4g + i carry rank jr0 + i
+    f32x4 gt[TPW], j1t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) gt[q][i] = tgather(slot, jr0 + i, rps, q);
+      const float jt = tgather(slot, jr0 + i, rps, 2);
+      j1t[i] = is_t ? 0.f : jt;                        // the st half of j1's input has no tangent
+    }
+    float gc[TPW][4], hz[TPW][4], zz[TPW][4];
+    auto target_terms = [&]() {
+      const float icoef = 1.f / coef;
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float* xr = at(o_xc + xsel, (jr0 + i) * LDX + 128 * q);
+          const float* zr = xr + 8 * LDX;
+          const float x = xr[0], z = zr[0];
+          const float graw = -tbeta * (coef * (2.f * x - xr[-1] - xr[1]) - x * (1.f - x * x) * icoef);
+          const float hv = -tbeta * (coef * (2.f * z - zr[-1] - zr[1]) - (1.f - 3.f * x * x) * z * icoef);
+          gc[q][i] = clip > 0.f ? fminf(fmaxf(graw, -clip), clip) : graw;
+          hz[q][i] = (!(clip > 0.f) || fabsf(graw) <= clip) ? hv : 0.f;
+          zz[q][i] = z;
+        }
+      }
+    };
+    // one layer's epilogue: value lanes activate, tangent lanes take the mask from their partner's pre-activation
+    auto act_store = [&](const f32x4& pre, float b, float* dstp) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float pv = pre[i] + b;
+        const float pp = from_lower_half(pv);
+        dstp[i * LDH] = is_t ? (pp > 0.f ? pre[i] : 0.f) : fmaxf(pv, 0.f);
+      }
+    };
+    if (wave < NW / 2) target_terms();
+    {   // x1 on [values ; probes]
+      f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+      run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(at(o_xa + xsel, 0), wr, W(S::W2, wave, D / 16), W(S::W3, wave, 8), lane, P, Q, acc);
+      if (wave >= NW / 2) target_terms();
+      act_store(acc[0] + acc[1], bias(S::B2), at(o_he, 0));
+    }
+    __syncthreads();
+    {   // x2
+      f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+      run_job<1, 1, 8, LDH, 0, 1, 0, true>(at(o_ha, 0), wr, W(S::W3, wave, 8), W(S::W5, wave, 16, 0), lane, P, Q, acc);
+      act_store(acc[0] + acc[1], bias(S::B3), at(o_he, 32 * LDH));
+    }
+    __syncthreads();
+    {   // j1: the st half + bias arrive as the initial accumulator of the value rows
+      f32x4 acc[2] = {j1t, {0, 0, 0, 0}};
+      run_job<1, 1, 8, LDH, 0, 1, 0, true>(at(o_ha, 32 * LDH), wr, W(S::W5, wave, 16, 0), W(S::W6, wave, 8), lane, P, Q, acc);
+      act_store(acc[0] + acc[1], 0.f, at(o_he2, 0));
+    }
+    __syncthreads();
+    {   // j2
+      f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+      run_job<1, 1, 8, LDH, 0, TPW, OUT_T1OFF, true>(at(o_ha2, 0), wr, W(S::W6, wave, 8), W(S::W7, wave, 8), lane, P, Q, acc);
+      act_store(acc[0] + acc[1], bias(S::B6), at(o_he2, 32 * LDH));
+    }
+    __syncthreads();
+    {   // out
+      float bo[TPW];
+      f32x4 acc[TPW][1];
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) { acc[q][0] = f32x4{0, 0, 0, 0}; bo[q] = bias(S::B7 + 128 * q); }
+      const int wnext = next_is_tbatch ? W(S::W0, wave, 16) : W(S::W2, wave, D / 16);
+      run_job<1, TPW, 8, LDH, OUT_T1OFF, 1, 0>(at(o_ha2, 32 * LDH), wr, W(S::W7, wave, 8), wnext, lane, P, Q, acc);
+      float dp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (is_t) dp[i] += zz[q][i] * (acc[q][0][i] + gt[q][i] * hz[q][i]);                   // z . J z of rank jr0 + i
+          else *at(o_xc + xoth, (jr0 + i) * LDX + 128 * q) = acc[q][0][i] + bo[q] + gt[q][i] * gc[q][i];   // v of rank jr0 + i
+        }
+      }
+      part_put(S::DLP + dst * 128, dp);            // M-row 8 + rank; direction sign applied by the row leaders
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = rk[i] >= 0.f ? *at(o_xc + xoth, (int)rk[i] * LDX + 128 * q) : 0.f;
+        kv[q][i] = sg[i] > 0.f ? v : -v;
+      }
+  }
 };
 
 // Integrate the augmented ODE from t = 0 to 1 (see ode_solve in ode.hip: same state machine, same controller).
@@ -547,7 +679,7 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
 #ifdef MFM_STAMPS
     const unsigned long long c0_ = __builtin_amdgcn_s_memtime();
 #endif
-    if (phase <= 2) T.tbatch(phase, P, Q); else __syncthreads();
+    if (phase <= 2) { float cvv[5][4], svv[5][4]; T.template tb_trig<false>(phase, cvv, svv); T.tbatch(phase, P, Q, cvv, svv); } else __syncthreads();
 #ifdef MFM_STAMPS
     const unsigned long long c1_ = __builtin_amdgcn_s_memtime();
     if (phase <= 2) { T.cyc_tb += c1_ - c0_; T.n_tb += 1; }
@@ -780,7 +912,9 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
   for (;;) {
     // ---- stage input -> X[cur] ----
     float hs[4];
-    const f32x4 md4 = T.rs_get(RS_MODE);
+    const f32x4 md4 = T.rs_get(RS_MODE), rk4 = T.rs_get(RS_RANK);
+    const int cmode = (int)*T.at(0, S::RS + RS_TILE * 16 + 1);             // 0: > 8 rows of the tile still integrate, 1: <= 8, 2: <= 3
+    const int rps = cmode == 2 ? 3 : (cmode == 1 ? 8 : 0);
     {
       float cf[6];
 #pragma unroll
@@ -798,24 +932,43 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
           float acc = c0 * k[0][q][i];
 #pragma unroll
           for (int j = 1; j < 6; ++j) acc += cf[j] * k[j][q][i];
-          *T.at(T.o_xo + xsel, i * LDX + 128 * q) = y[q][i] + he * acc;
+          const float xin = y[q][i] + he * acc;
+          if (cmode == 0) *T.at(T.o_xo + xsel, i * LDX + 128 * q) = xin;
+          else if (rk4[i] >= 0.f) {                              // compact evaluation: value rows by rank, probes by rank below them
+            *T.at(T.o_xc + xsel, (int)rk4[i] * LDX + 128 * q) = xin;
+            if (phase == 2) {
+              const float z = *T.at(T.o_xo, S::ZB + i * LDX + 128 * q);
+              *T.at(T.o_xc + S::XB0 * 4, (8 + (int)rk4[i]) * LDX + 128 * q) = z;
+              *T.at(T.o_xc + S::XB1 * 4, (8 + (int)rk4[i]) * LDX + 128 * q) = z;
+            }
+          }
         }
       }
     }
-    const bool compact = *T.at(0, S::RS + RS_TILE * 16 + 1) != 0.f;        // <= 3 rows of the tile still integrate
 #ifdef MFM_STAMPS
-    const unsigned long long c0_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long tb0_ = __builtin_amdgcn_s_memtime();
 #endif
-    if (phase == 2) { if (compact) T.template tbatch<true, 1>(2, P, Q); else T.template tbatch<true, 5>(2, P, Q); } else __syncthreads();
+    if (phase == 2) {
+      float cvv[5][4], svv[5][4];
+      T.template tb_trig<true>(2, cvv, svv);
+      if (cmode == 2) T.template tbatch<true, 1>(2, P, Q, cvv, svv);
+      else if (cmode == 1) T.template tbatch<true, 3>(2, P, Q, cvv, svv);
+      else T.template tbatch<true, 5>(2, P, Q, cvv, svv);
+    } else __syncthreads();
 #ifdef MFM_STAMPS
-    const unsigned long long c1_ = __builtin_amdgcn_s_memtime();
-    if (phase == 2) { if (compact) { T.cyc_tc += c1_ - c0_; T.n_tc += 1; } else { T.cyc_tb += c1_ - c0_; T.n_tb += 1; } }
+    if (phase == 2) { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - tb0_;
+      if (cmode == 0) { T.cyc_tb += d_; T.n_tb += 1; } else { T.cyc_tc += d_; T.n_tc += 1; } }
 #endif
     float kv[TPW][4];
     const int dst = phase - 1;
-    T.eval(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN), compact, T.rs_get(RS_RANK));
 #ifdef MFM_STAMPS
-    T.cyc_eval += __builtin_amdgcn_s_memtime() - c1_; T.n_eval += 1;
+    const unsigned long long ce0_ = __builtin_amdgcn_s_memtime();
+#endif
+    if (cmode == 0) T.eval(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN), 0, rk4);
+    else T.eval_c(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN), rps, rk4);
+#ifdef MFM_STAMPS
+    { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - ce0_;
+      if (cmode == 0) { T.cyc_eval += d_; T.n_eval += 1; } else { T.cyc_ec += d_; T.n_ec += 1; } }
 #endif
     cur ^= 1;
 #pragma unroll
@@ -862,11 +1015,19 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
       auto R1 = [&](int field) -> float& { return *T.at(T.o_l1, S::RS + field * 16); };
       const float mode = R1(RS_MODE);
       float flag = 0.f, sw = 0.f;
+      // divergence partials of this row: full evaluation: M-row = row, direction already applied; compact evaluation: M-row
+      // 8 + rank(row), raw
+      const int dl_off = cmode == 0 ? T.o_l8 : (8 + (int)R1(RS_RANK)) * 32;
+      const float dl_sg = cmode == 0 ? 1.f : (R1(RS_SIGN) > 0.f ? -1.f : 1.f);
+      auto dlsum = [&](int base) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(T.at(dl_off, base)), v = *reinterpret_cast<const f32x4*>(T.at(dl_off, base + 4));
+        return dl_sg * (((u[0] + u[1]) + (u[2] + u[3])) + ((v[0] + v[1]) + (v[2] + v[3])));
+      };
       if (mode == (float)RM_INIT0) {
         // f0 sits in k[1] (slot 0 of the attempt): initial step size, part 1
         if (R1(RS_SOLVE) != 0.f && f.mode == MFM_FLOW_IMH)                 // ref.logprob(u0) - ref.logprob(up)  (:254-255)
           R1(RS_LQ) = -0.5f * (sum8(S::RED + 4 * 128) - sum8(S::RED + 5 * 128)) / (f.ref_std * f.ref_std);
-        const float dl0 = sum8(S::DLP + 1 * 128);
+        const float dl0 = dlsum(S::DLP + 1 * 128);
         const float a1 = dl0 / atol;
         const float d0 = sqrtf(sum8(S::RED + 0 * 128)), d1 = sqrtf(sum8(S::RED + 1 * 128) + a1 * a1);
         const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
@@ -875,7 +1036,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
         flag = 3.f;
       } else if (mode == (float)RM_INIT1) {
         const float h0 = R1(RS_H0), d1 = R1(RS_D1);
-        const float a2 = (sum8(S::DLP + 1 * 128) - R1(RS_KL + 0)) / atol;
+        const float a2 = (dlsum(S::DLP + 1 * 128) - R1(RS_KL + 0)) / atol;
         const float d2 = sqrtf(sum8(S::RED + 2 * 128) + a2 * a2) / h0;
         const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
         const float dt = fminf(100.f * h0, h1);
@@ -885,7 +1046,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
         float kl[7];
         kl[0] = R1(RS_KL + 0);
 #pragma unroll
-        for (int j = 1; j < 7; ++j) kl[j] = sum8(S::DLP + j * 128);
+        for (int j = 1; j < 7; ++j) kl[j] = dlsum(S::DLP + j * 128);
         const float e2 = sum8(S::RED + 3 * 128);
         const float t0 = R1(RS_T), dti = R1(RS_DT), ell0 = R1(RS_ELL), na = R1(RS_NATT);
         const bool active = na < (float)max_attempts && dti > 0.f;
@@ -937,7 +1098,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
       // rank of this row among the rows that take part in the next attempt: with <= 3 of them the time batch is compacted
       const unsigned long long bal = __ballot(any != 0);
       R1(RS_RANK) = any ? (float)__popcll(bal & ((1ull << T.lane) - 1ull)) : -1.f;
-      if (T.lane == 0) *T.at(0, S::RS + RS_TILE * 16 + 1) = __popcll(bal) <= 3 ? 1.f : 0.f;
+      if (T.lane == 0) { const int na = __popcll(bal); *T.at(0, S::RS + RS_TILE * 16 + 1) = na <= 3 ? 2.f : (na <= 8 ? 1.f : 0.f); }
     }
     const int go = __syncthreads_or(any);
     // ---- every lane: apply the decision of its rows (branch-free selects) ----
@@ -1007,8 +1168,8 @@ __device__ __forceinline__ void tile_init(FTile<D>& T, const NetDev& n, float* l
     asm volatile("" : "+v"(T.o_rs), "+v"(T.o_pg), "+v"(T.o_pp), "+v"(T.o_bias), "+v"(T.o_xa));
     asm volatile("" : "+v"(T.o_xo), "+v"(T.o_ha), "+v"(T.o_ha2), "+v"(T.o_he), "+v"(T.o_he2));
     T.o_l8 = (T.lane & 15) * 32; T.o_l1 = (T.lane & 15) * 4;
-    T.o_hc = (S::R + 16 * w + c) * 4;
-    asm volatile("" : "+v"(T.o_l8), "+v"(T.o_l1), "+v"(T.o_hc));
+    T.o_hc = (S::R + 16 * w + c) * 4; T.o_xc = (4 + 16 * w + c) * 4;
+    asm volatile("" : "+v"(T.o_l8), "+v"(T.o_l1), "+v"(T.o_hc), "+v"(T.o_xc));
   }
   for (int i = threadIdx.x; i < S::TOTAL; i += NW * 64)
     if (i < S::BIAS || i >= S::BIAS + S::BTOT) lds[i] = 0.f;                   // halo pads, row state, scratch
@@ -1170,8 +1331,9 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
   if (g_flow_dbg && (threadIdx.x == 0 || threadIdx.x == 256)) {
     unsigned long long* o = g_flow_dbg + (blockIdx.x + (threadIdx.x ? gridDim.x : 0)) * 32;
     o[0] = __builtin_amdgcn_s_memtime() - fc0_; o[1] = __builtin_amdgcn_s_memrealtime() - fr0_;
-    o[2] = T.n_eval; o[3] = T.cyc_eval; o[5] = T.n_tb; o[6] = T.cyc_tb; o[28] = T.n_tc; o[29] = T.cyc_tc;
+    o[2] = T.n_eval; o[3] = T.cyc_eval; o[5] = T.n_tb; o[6] = T.cyc_tb;
     for (int i = 0; i < 20; ++i) o[8 + i] = T.cyc_sec[i];
+    o[28] = T.n_tc; o[29] = T.cyc_tc; o[30] = T.n_ec; o[31] = T.cyc_ec;
   }
 #endif
 }

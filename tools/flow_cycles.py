@@ -57,7 +57,11 @@ for count in range(1, 304):
         if d[:, 28].max() > 0:
             nct, cct = d[:, 28], d[:, 29]
             f = nct > 0
-            print(f"   compacted time batches (<= 3 rows): per WG mean {nct.mean():.0f}, slowest WG {nct[np.argmax(cyc)]:.0f}; cycles/batch {np.median(cct[f] / nct[f]):.0f}")
+            print(f"   compacted time batches (<= 8 rows): per WG mean {nct.mean():.0f}, slowest WG {nct[np.argmax(cyc)]:.0f}; cycles/batch {np.median(cct[f] / nct[f]):.0f}")
+            nec, cec = d[:, 30], d[:, 31]
+            f = nec > 0
+            if f.any():
+                print(f"   compact evaluations (<= 8 rows): per WG mean {nec.mean():.0f}, slowest WG {nec[np.argmax(cyc)]:.0f}; cycles/evaluation {np.median(cec[f] / nec[f]):.0f}")
         print(f"   WG time: mean/max {cyc.mean()/cyc.max():.3f}; alg evals (4+6 natt) mean {4+6*n.mean():.0f}; executed/alg {nev.mean()/(4+6*n.mean()):.3f}; max-WG/alg {nev.max()/(4+6*n.mean()):.3f}")
     else:
         ctx.mala_step(kg, 1.0, args.step_size, pos, logp, grad, acc)
