@@ -202,7 +202,8 @@ def main():
     # contain a flow step.  Nothing of the benchmark state changes: parameters, optimizer and chains are untouched.
     _p, _l, _g = pos.clone(), logp.clone(), grad.clone()
     ctx.mala_step(keys[0, 0], beta, args.step_size, _p, _l, _g, acc)
-    ctx.flow_step(FLOW_RWMH, keys[0, 0], beta, _p, _l, _g, acc, None, None, nst)
+    if a.warmup < wl_K + 1:          # (a warm-up of a full cycle launches the flow-step kernel itself)
+        ctx.flow_step(FLOW_RWMH, keys[0, 0], beta, _p, _l, _g, acc, None, None, nst)
     ctx.fm_loss(keys[0, 1], _p, torch.zeros(1, device=eng.dev, dtype=torch.float64))
     natt_sum.add_(nst.double().sum()); natt_sum.zero_()      # torch loads its reduction kernels lazily, too
     fence()
