@@ -185,6 +185,9 @@ int mfm_smc_weights(mfm_ctx* ctx, const double* d_loglik, int n, double delta, d
 int mfm_smc_resample(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const double* d_weights, int n, double* d_scratch,
                      int32_t* d_idx);
 int mfm_gather_rows(mfm_ctx* ctx, const float* d_src, const int32_t* d_idx, int n, int dim, float* d_dst);
+/* d_out[0..1] = sum and sum of squares (float64) of d_x[0..n): the per-iteration acceptance statistics
+ * (exe_flow_matching.py:442-443: infos.acceptance_rate.mean() / .std()) without a host round trip */
+int mfm_acc_stats(mfm_ctx* ctx, const float* d_x, int n, double* d_out);
 
 /* class_mask: 0 = off; otherwise bit c enables class c (-1: all) and the record is reset.  Two event records per launch
  * cost ~6 us of stream time each side on this runtime, so a caller that is itself being timed enables only the class it

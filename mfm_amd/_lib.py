@@ -58,6 +58,7 @@ _SIGS = {
     "mfm_smc_weights": (C.c_int, [_P, _P, C.c_int, C.c_double, _P, C.POINTER(C.c_double)]),
     "mfm_smc_resample": (C.c_int, [_P, _U32, _U32, _P, C.c_int, _P, _P]),
     "mfm_gather_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "mfm_acc_stats": (C.c_int, [_P, _P, C.c_int, _P]),
     "mfm_fm_loss_grad": (C.c_int, [_P, _U32, _U32, _P, _P, _P]),
     "mfm_fm_loss": (C.c_int, [_P, _U32, _U32, _P, C.c_int, C.c_int, C.c_int, _P]),
     "mfm_adamw_step": (C.c_int, [_P, _P]),
@@ -234,6 +235,10 @@ class Context:
 
     def smc_resample(self, key, weights, scratch, idx):
         _chk(self.lib.mfm_smc_resample(self.h, int(key[0]), int(key[1]), _ptr(weights, F64), weights.shape[0], _ptr(scratch, F64), _ptr(idx, I32)))
+
+    def acc_stats(self, x, out):
+        """out[0:2] (float64) = sum, sum of squares of the float32 vector x."""
+        _chk(self.lib.mfm_acc_stats(self.h, _ptr(x, F32), x.shape[0], _ptr(out, F64)))
 
     def gather_rows(self, src, idx, dst):
         _chk(self.lib.mfm_gather_rows(self.h, _ptr(src, F32), _ptr(idx, I32), src.shape[0], src.shape[1], _ptr(dst, F32)))

@@ -790,6 +790,13 @@ extern "C" int mfm_smc_resample(mfm_ctx* x, uint32_t k0, uint32_t k1, const doub
   LAUNCHCHK();
   return MFM_OK;
 }
+extern "C" int mfm_acc_stats(mfm_ctx* x, const float* d_x, int n, double* d_out) {
+  if (!x || !d_x || !d_out) return fail(MFM_EINVAL, "null argument");
+  if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
+  hipLaunchKernelGGL(acc_stats_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, d_x, n, d_out);
+  LAUNCHCHK();
+  return MFM_OK;
+}
 extern "C" int mfm_gather_rows(mfm_ctx* x, const float* d_src, const int32_t* d_idx, int n, int dim, float* d_dst) {
   if (!x || !d_src || !d_idx || !d_dst) return fail(MFM_EINVAL, "null argument");
   if (n <= 0 || dim <= 0) return fail(MFM_EINVAL, "n and dim must be positive");

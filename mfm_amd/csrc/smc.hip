@@ -88,6 +88,17 @@ __global__ __launch_bounds__(SMC_THREADS) void smc_resample_kernel(Key2 key, con
   }
 }
 
+// sum and sum of squares (float64) of a per-chain float32 quantity: the acceptance statistics logged every iteration
+// (exe_flow_matching.py:442-443) without a handful of framework launches per iteration
+__global__ __launch_bounds__(SMC_THREADS) void acc_stats_kernel(const float* x, int n, double* out) {
+  __shared__ double sm[SMC_THREADS / 64];
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < n; i += SMC_THREADS) { const double v = x[i]; s1 += v; s2 += v * v; }
+  s1 = smc_block_reduce(s1, sm, false);
+  s2 = smc_block_reduce(s2, sm, false);
+  if (threadIdx.x == 0) { out[0] = s1; out[1] = s2; }
+}
+
 __global__ void gather_rows_kernel(const float* src, const int* idx, int n, int d, float* dst) {
   const size_t tot = (size_t)n * d;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {

@@ -316,16 +316,15 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
             if kg:
                 prefetch = eng.ctx.noise_prefetch(np.stack(kg), np.stack(kt))               # False: not served for this configuration
         train_states, infos = train_data_generator(key_train_gn, train_states, count, state.params, beta)    # :438
-        loss = eng.train_step(key_train_step, train_states.position)                        # :439 (:362-368)
+        row = metrics[count - 1]                                                            # loss | sum acc | sum acc^2 | target loss
+        eng.train_step(key_train_step, train_states.position, loss_out=row[0:1])            # :439 (:362-368)
         lrs.append(learning_rate_fn(count - 1))                                             # :367 (pre-increment step)
         if not use_real_samples and count % iter_per_temp == 0 and beta < 1.0:              # :440-441, :417
             beta = eng.ctx.beta_update(beta, eng.all_logliks(train_states.position), args.alpha)              # :413
             train_states = init_fn(train_states.position, beta)                             # :415
-        acc = infos.acceptance_rate.double()
-        metrics[count - 1, 0] = loss[0]; metrics[count - 1, 1] = acc.sum(); metrics[count - 1, 2] = (acc * acc).sum()
+        eng.ctx.acc_stats(infos.acceptance_rate, row[1:3])                                  # :442-443, per-rank partial sums
         if real_samples is not None:                                                        # :444-446
-            eng.eval_loss(key_loss, real_samples, eval_loss, n_total=n_eval, offset=eng.rank * (n_eval // eng.world))
-            metrics[count - 1, 3] = eval_loss[0]
+            eng.eval_loss(key_loss, real_samples, row[3:4], n_total=n_eval, offset=eng.rank * (n_eval // eng.world))
         betas.append(beta)
         if count % log_every == 0 or count == learning_iter:
             _finish_metric_rows(eng, metrics, n_reduced, count); n_reduced = count          # ONE collective per log interval

@@ -157,3 +157,20 @@ def test_noise_prefetch_is_bit_identical_to_inline_draws():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     for (l0, g0, a0), (l1, g1, a1) in zip(res[0][2], res[1][2]):
         assert l0 == l1 and torch.equal(g0, g1) and torch.equal(a0, a1)
+
+
+def test_acc_stats_kernel():
+    import torch
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.phi4_setup(d=64, B=32, hidden=32, F=16)
+    ctx = gu.make_ctx(dist, args)
+    x = torch.rand(4096, device="cuda") * 3
+    out = torch.zeros(2, dtype=torch.float64, device="cuda")
+    ctx.acc_stats(x, out)
+    xd = x.double()
+    assert abs(out[0].item() - xd.sum().item()) < 1e-9 * xd.sum().item()
+    assert abs(out[1].item() - (xd * xd).sum().item()) < 1e-9 * (xd * xd).sum().item()
+    x[7] = float("nan")
+    ctx.acc_stats(x, out)
+    assert torch.isnan(out).all()                       # exact-sample training logs NaN acceptance (exe_flow_matching.py:385)
+    ctx.close()
