@@ -613,7 +613,10 @@ struct FTile {
       }
       part_put(S::DLP + dst * 128, dp);            // M-row 8 + rank; direction sign applied by the row leaders
     }
-    __syncthreads();
+    // no workgroup barrier: an owner lane reads what a lane of its OWN wave (same column tile, another row group) stored just
+    // above, and a wave's LDS instructions complete in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int q = 0; q < TPW; ++q)
 #pragma unroll
