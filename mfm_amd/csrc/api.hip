@@ -65,6 +65,7 @@ struct mfm_ctx {
   double* loss_part; int loss_cap;
   WgradJob* jobs; int n_jobs, split;
   OptState* opt; int* flag;
+  const float* checked_grads = nullptr;   // gradient whose finite check already sits in flag[0] (single-rank mfm_fm_loss_grad)
   float *gmm_mode, *gmm_std, *gmm_logw, *counts, *Kinv, *kbias;
   OdeWs ode;
   double* beta_out;
@@ -518,16 +519,22 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
 extern "C" int mfm_fm_loss_grad(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_pos, double* d_loss, float* d_grads) {
   NEED_TARGET();
   if (!d_pos || !d_loss || !d_grads) return fail(MFM_EINVAL, "null device pointer");
+  x->checked_grads = nullptr;
   int rc = fm_common(x, k0, k1, d_pos, x->cfg.n_chain_local, x->cfg.n_chain_total, x->cfg.chain_offset, true, d_loss, d_grads);
   if (rc || x->wide) return rc;
   WgradArgs w; memset(&w, 0, sizeof w);
   w.net = x->net; w.ws = x->ws; w.acts = x->acts; w.dzs = x->dzs; w.jobs = x->jobs; w.n_jobs = x->n_jobs;
   w.nbb = x->cfg.n_chain_local / 16; w.split = x->split; w.slabs = x->slabs;
+  // One rank: this sum is the gradient the optimizer will see, so its finite check rides in the reduction and
+  // mfm_adamw_step(d_grads) skips its check kernel.  With more ranks the check has to follow the all-reduce.
+  const bool single = x->cfg.n_chain_total == x->cfg.n_chain_local;
+  w.flag_reset = single ? x->flag : nullptr;
   { ProfScope ps_(x, PROF_WGRAD); launch_wgrad(w, x->stream); }
   LAUNCHCHK();
   ProfScope ps2_(x, PROF_REDUCE);
-  launch_reduce_slabs(x->slabs, x->split, x->net.n_params, d_grads, x->loss_part, x->cfg.n_chain_local / 16, d_loss, x->stream);
+  launch_reduce_slabs(x->slabs, x->split, x->net.n_params, d_grads, x->loss_part, x->cfg.n_chain_local / 16, d_loss, single ? x->flag : nullptr, x->stream);
   LAUNCHCHK();
+  x->checked_grads = single ? d_grads : nullptr;
   return MFM_OK;
 }
 
@@ -547,6 +554,8 @@ extern "C" int mfm_adamw_step(mfm_ctx* x, const float* d_grads) {
   a.lr0 = c.learning_rate; a.learning_iter = c.learning_iter; a.warmup = c.warmup_steps;
   a.b1 = c.adam_b1; a.b2 = c.adam_b2; a.eps = (float)c.adam_eps; a.wd = (float)c.weight_decay; a.clip = (float)c.update_clip;
   a.max_err = 10;
+  a.inline_decide = (x->checked_grads == d_grads) ? 1 : 0;
+  x->checked_grads = nullptr;
   ProfScope ps_(x, PROF_ADAM);
   launch_adamw(a, x->stream);
   LAUNCHCHK();

@@ -367,6 +367,7 @@ struct WgradArgs {
   const WgradJob* jobs; int n_jobs;
   int nbb, split;
   float* slabs;            // [split][n_params]
+  int* flag_reset;         // non-null: the non-finite flag reduce_slabs_kernel will raise for THIS gradient (cleared here)
 };
 
 __device__ __forceinline__ int wgrad_a_tile(const NetDev& n, const WsLayout& w, int layer, int kt) {
@@ -397,6 +398,7 @@ __device__ __forceinline__ int wgrad_z_tile(const WsLayout& w, int layer, int nt
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const int job = blockIdx.x * 4 + wave;
+  if (a.flag_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.flag_reset = 0;
   if (job >= a.n_jobs) return;
   const WgradJob J = a.jobs[job];
   const NetDev& n = a.net;
@@ -453,12 +455,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 
 // grads[p] = sum_s slabs[s][p]; the last workgroup of the grid also totals the per-tile loss partials of the forward
 // kernel (same fixed order as reduce_loss_kernel), which saves a launch per training step.
-__global__ void reduce_slabs_kernel(const float* slabs, int split, int n, float* out, const double* loss_part, int n_part, double* loss_out) {
+// With `bad` (single-rank training: the summed gradient IS the one the optimizer will see) it also raises the non-finite
+// flag the AdamW kernel decides on, which saves the check kernel of the optimizer step.
+__global__ void reduce_slabs_kernel(const float* slabs, int split, int n, float* out, const double* loss_part, int n_part, double* loss_out, int* bad) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
+  bool nf = false;
   if (p < n) {
     float s = 0.f;
     for (int k = 0; k < split; ++k) s += slabs[(size_t)k * n + p];
     out[p] = s;
+    nf = !isfinite(s);
+  }
+  if (bad) {                                   // uniform over the grid
+    const int any = __syncthreads_or(nf ? 1 : 0);
+    if (any && threadIdx.x == 0) atomicOr(bad, 1);
   }
   if (loss_part && blockIdx.x == gridDim.x - 1) {
     __shared__ double sm[256];
@@ -514,8 +524,8 @@ int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
   return 0;
 }
 
-void launch_reduce_slabs(const float* slabs, int split, int n, float* out, const double* loss_part, int n_part, double* loss_out, hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, slabs, split, n, out, loss_part, n_part, loss_out);
+void launch_reduce_slabs(const float* slabs, int split, int n, float* out, const double* loss_part, int n_part, double* loss_out, int* bad, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, slabs, split, n, out, loss_part, n_part, loss_out, bad);
 }
 void launch_reduce_loss(const double* part, int n, double* out, int accumulate, hipStream_t stream) {
   hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, stream, part, n, out, accumulate);

@@ -27,7 +27,25 @@ struct AdamArgs {
   double lr0; int learning_iter, warmup;
   double b1, b2; float eps, wd, clip;
   int max_err;
+  int inline_decide;                   // the non-finite flag was raised by the kernel that produced `grads`: decide here
 };
+
+// apply_if_finite decision + step scalars, identical in every thread.  With inline_decide every thread derives the decision
+// from the flag and the (not yet advanced) state; the last workgroup commits the state once all have read it.
+struct AdamDecision { bool apply; int count; int nf_new; };
+__device__ __forceinline__ AdamDecision adam_decide(const AdamArgs& a) {
+  AdamDecision d;
+  d.count = a.st->count;
+  if (a.inline_decide) {
+    const bool finite = a.flag[0] == 0;
+    d.nf_new = finite ? 0 : a.st->notfinite_count + 1;
+    d.apply = finite || d.nf_new > a.max_err;
+  } else {
+    d.nf_new = a.st->notfinite_count;
+    d.apply = a.st->last_applied != 0;
+  }
+  return d;
+}
 
 __device__ __forceinline__ float lr_schedule(double lr0, int learning_iter, int warmup, int count) {
   // join_schedules([linear(0 -> lr, warmup), linear(lr -> 0, learning_iter - warmup)], [warmup]) (:189-198)
@@ -67,20 +85,33 @@ __global__ void finite_decide_kernel(const float* grads, int n_slabs, int n, Opt
 
 __device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool apply, float bc1, float bc2, float lr);
 
+// Last workgroup of an update kernel: advance the inner count, and with inline_decide the bookkeeping finite_decide_kernel
+// would have done (every workgroup has read the old state by the time the last ticket is drawn).
+__device__ __forceinline__ void adam_commit(const AdamArgs& a, const AdamDecision& d) {
+  if (atomicInc(reinterpret_cast<unsigned int*>(a.flag + 2), gridDim.x - 1) != gridDim.x - 1) return;
+  if (a.inline_decide) {
+    a.st->notfinite_count = d.nf_new;
+    a.st->last_lr = lr_schedule(a.lr0, a.learning_iter, a.warmup, a.st->step);
+    a.st->step += 1;
+    a.st->last_applied = d.apply ? 1 : 0;
+    atomicExch(a.flag, 0);
+  }
+  if (d.apply) a.st->count = d.count + 1;
+}
+
 // The update + repack; the LAST workgroup to finish advances the inner optimizer count (every workgroup has read it by
 // then), which used to be a kernel of its own.
 __global__ void adamw_kernel(AdamArgs a) {
-  const bool apply = a.st->last_applied != 0;
-  const int count = a.st->count;
+  const AdamDecision dec = adam_decide(a);
+  const bool apply = dec.apply;
+  const int count = dec.count;
   // per-step scalars once per thread (two float64 pow calls used to be evaluated per parameter)
   const int c1 = count + 1;
   const float bc1 = (float)(1.0 - pow(a.b1, (double)c1)), bc2 = (float)(1.0 - pow(a.b2, (double)c1));
   const float lr = lr_schedule(a.lr0, a.learning_iter, a.warmup, count);
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < a.net.n_params; p += gridDim.x * blockDim.x) adamw_element(a, p, apply, bc1, bc2, lr);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    if (atomicInc(reinterpret_cast<unsigned int*>(a.flag + 2), gridDim.x - 1) == gridDim.x - 1 && apply) a.st->count = count + 1;
-  }
+  if (threadIdx.x == 0) adam_commit(a, dec);
 }
 
 __device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool apply, float bc1, float bc2, float lr) {
@@ -125,8 +156,9 @@ __device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool app
 struct AdamBlocks { int first[MLP_NLAYER + 1]; int n_blocks; int n_bias_items; };
 __global__ void adamw_vec_kernel(AdamArgs a, AdamBlocks bl) {
   const NetDev& n = a.net;
-  const bool apply = a.st->last_applied != 0;
-  const int count = a.st->count;
+  const AdamDecision dec = adam_decide(a);
+  const bool apply = dec.apply;
+  const int count = dec.count;
   const int c1 = count + 1;
   const float bc1 = (float)(1.0 - pow(a.b1, (double)c1)), bc2 = (float)(1.0 - pow(a.b2, (double)c1));
   const float lr = lr_schedule(a.lr0, a.learning_iter, a.warmup, count);
@@ -172,9 +204,7 @@ __global__ void adamw_vec_kernel(AdamArgs a, AdamBlocks bl) {
       *reinterpret_cast<f32x4*>(a.Wp + ld.w_off + pack_index(k0, n0 + j, ld.Kp / 16)) = f32x4{w[0][j], w[1][j], w[2][j], w[3][j]};
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    if (atomicInc(reinterpret_cast<unsigned int*>(a.flag + 2), gridDim.x - 1) == gridDim.x - 1 && apply) a.st->count = count + 1;
-  }
+  if (threadIdx.x == 0) adam_commit(a, dec);
 }
 
 void launch_adamw(const AdamArgs& a, hipStream_t stream) {
@@ -184,7 +214,8 @@ void launch_adamw(const AdamArgs& a, hipStream_t stream) {
   // widths: 8.65 M parameters) for the elementwise pass itself to need the whole chip
   const int cap = n > (1 << 21) ? 2048 : 256;
   dim3 grid(nb < cap ? nb : cap), block(256);
-  hipLaunchKernelGGL(finite_decide_kernel, grid, block, 0, stream, a.grads, a.n_slabs, n, a.st, a.flag, a.lr0, a.learning_iter, a.warmup, a.max_err);
+  if (!a.inline_decide)
+    hipLaunchKernelGGL(finite_decide_kernel, grid, block, 0, stream, a.grads, a.n_slabs, n, a.st, a.flag, a.lr0, a.learning_iter, a.warmup, a.max_err);
   bool vec = true;
   AdamBlocks bl; memset(&bl, 0, sizeof bl);
   for (int l = 0; l < MLP_NLAYER; ++l) {

@@ -133,3 +133,34 @@ def test_vector_field_and_jvp_match_oracle(setup, d, hidden, F):
     ctx.vf_apply(_dev(x), _dev(t), v2)
     assert _relerr(v2.cpu().numpy(), v_o) < 2e-5
     ctx.close()
+
+
+def test_finite_check_in_the_reduction_matches_separate_check():
+    """Single rank: mfm_adamw_step(grads) right after mfm_fm_loss_grad(..., grads) takes the apply_if_finite decision
+    (exe_flow_matching.py:135-137) from the flag raised in the gradient reduction; a gradient handed over in another
+    buffer goes through the separate check kernel.  Same parameters and counters either way, including a rejected
+    non-finite step and the recovery after it."""
+    import torch
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.phi4_setup(d=64, B=64, hidden=32, F=16, learning_iter=12)
+    params = gu.rand_params(model, seed=6)
+    x32 = dist.init_params.astype(np.float32)
+    bad = x32.copy(); bad[3, 5] = np.inf
+    ctxs = [gu.make_ctx(dist, args, fourier=model.f, params=params) for _ in range(2)]
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctxs[0].n_params, device="cuda")
+    for it in range(6):
+        pos = _dev(bad if it in (2, 3) else x32)
+        key = prng.PRNGKey(20 + it)
+        ctxs[0].fm_loss_grad(key, pos, loss, grads); ctxs[0].adamw_step(grads)                 # decision in the update kernel
+        ctxs[1].fm_loss_grad(key, pos, loss, grads); ctxs[1].adamw_step(grads.clone())         # separate check kernel
+        s0, s1 = ctxs[0].opt_state(), ctxs[1].opt_state()
+        assert s0 == s1, (it, s0, s1)
+        assert s0["step"] == it + 1 and s0["notfinite_count"] == (it - 1 if it in (2, 3) else 0)
+        np.testing.assert_array_equal(ctxs[0].get_params(), ctxs[1].get_params())
+    assert s0["count"] == 4
+    # two gradient evaluations before one update: the flag belongs to the LAST one (a stale non-finite flag must not survive)
+    ctxs[0].fm_loss_grad(prng.PRNGKey(40), _dev(bad), loss, grads)
+    ctxs[0].fm_loss_grad(prng.PRNGKey(41), _dev(x32), loss, grads); ctxs[0].adamw_step(grads)
+    assert ctxs[0].opt_state()["count"] == 5 and ctxs[0].opt_state()["notfinite_count"] == 0
+    for c in ctxs:
+        c.close()
