@@ -111,6 +111,38 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     kref[i] = split_at(a.key_ref, a.n_total, bglob[i]);                         // :155
   }
   float tgt[TPW][4];
+  if (a.cond_flow && a.pre_x0) {
+    // draws produced ahead of time: issue every load of the tile before the first use (behind the per-element
+    // `drawn ? load : threefry + erfinv` selection below each load waited for the previous one: 24 HBM round trips)
+    float x1f[TPW][4]; double x0d[TPW][4], ned[TPW][4];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int nt = wave + MLP_WAVES_FM * q, col = nt * 16 + c;
+      const bool live = nt * 16 < n.dp && col < d;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t po = (size_t)(b0 + 4 * g + i) * d + (live ? col : 0);
+        x1f[q][i] = a.pos[po]; x0d[q][i] = a.pre_x0[po]; ned[q][i] = a.pre_eps[po];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int nt = wave + MLP_WAVES_FM * q, col = nt * 16 + c;
+      const bool live = nt * 16 < n.dp && col < d;
+      f32x4 cv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tgt[q][i] = 0.f;
+        if (live) {
+          const double x1v = x1f[q][i], t = tt[i], x0 = a.ref_std * x0d[q][i];
+          cv[i] = (float)((double)a.sigma * ned[q][i] + t * x1v + (1.0 - t) * x0);      // :167
+          tgt[q][i] = (float)(x1v - x0);                                              // :168
+          bX[(4 * g + i) * L.ldx + 4 + col] = cv[i];
+        }
+      }
+      if (TRAIN && nt * 16 < n.dp) store_packed(a.acts, a.ws.a_cond + nt, nbb, bb, lane, cv);
+    }
+  } else
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     const int nt = wave + MLP_WAVES_FM * q, col = nt * 16 + c;

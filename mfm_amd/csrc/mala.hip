@@ -139,13 +139,18 @@ __global__ __launch_bounds__(MALA_WAVES * 64) void mala_step_kernel(MalaArgs a) 
       k_rmh = split_at(kb, 2, 1);
     }
     const double s2e = sqrt(2.0 * a.eps);
+    double nz[MAXIT];                      // prefetched draws: all loads in flight before the first use
+    if (a.pre_n) {
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) { const int j = lane + 64 * it; nz[it] = j < d ? a.pre_n[row + j] : 0.0; }
+    }
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
       int j = lane + 64 * it;
       if (j < d) {
         x[it] = a.pos[row + j];
         g[it] = a.grad[row + j];
-        double n = a.pre_n ? a.pre_n[row + j] : normal64(k_int, (uint32_t)j, (uint32_t)d);   // util.py:80-82
+        double n = a.pre_n ? nz[it] : normal64(k_int, (uint32_t)j, (uint32_t)d);   // util.py:80-82
         double th = s2e * n;
         th1 += th * th;
         xn[it] = (float)((double)x[it] + a.eps * (double)g[it] + th);              // diffusions.py:25-30
