@@ -213,8 +213,8 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
   // wgrad job table
   std::vector<WgradJob> jobs;
   for (int l = 0; l < 8; ++l)
-    for (int nt = 0; nt < n.L[l].Np / 16; nt += 2)
-      for (int kt = 0; kt < n.L[l].Kp / 16; kt += 2) jobs.push_back(WgradJob{l, kt, nt});
+    for (int nt = 0; nt < n.L[l].Np / 16; nt += 4)
+      for (int kt = 0; kt < n.L[l].Kp / 16; kt += 4) jobs.push_back(WgradJob{l, kt, nt});
   x->n_jobs = (int)jobs.size();
 #define ALLOC(p, cnt) HIPCHK(hipMalloc((void**)&(p), (size_t)(cnt) * sizeof(*(p))))
   ALLOC(x->master, n.n_params); ALLOC(x->mu, n.n_params); ALLOC(x->nu, n.n_params);
