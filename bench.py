@@ -183,14 +183,13 @@ def main():
     n_flow = [0]
 
     def step(i, count):
-        if count % 101 == 0:                                                     # :311
-            if not os.environ.get("MFM_NO_PREFETCH"):        # draws of the next K iterations, in the flow step's tail (noise.hip)
-                ctx.noise_prefetch(keys[i + 1:i + 1 + wl_K, 0], keys[i + 1:i + 1 + wl_K, 1])
-            ctx.flow_step(FLOW_RWMH, keys[i, 0], beta, pos, logp, grad, acc, None, None, nst)
+        flow = count % (wl_K + 1) == 0                                           # :311
+        if flow and not os.environ.get("MFM_NO_PREFETCH"):   # draws of the next K iterations, in the flow step's tail (noise.hip)
+            ctx.noise_prefetch(keys[i + 1:i + 1 + wl_K, 0], keys[i + 1:i + 1 + wl_K, 1])
+        # generator (:300-314) + loss/grad + [all-reduce] + AdamW (:362-368): mfm_train_iter on one rank
+        eng.train_iter(count, wl_K, FLOW_RWMH, keys[i, 0], keys[i, 1], beta, args.step_size, pos, logp, grad, acc=acc, nsteps=nst)
+        if flow:
             natt_sum.add_(nst.double().sum()); n_flow[0] += 1
-        else:
-            ctx.mala_step(keys[i, 0], beta, args.step_size, pos, logp, grad, acc)
-        eng.train_step(keys[i, 1], pos)                                          # loss+grad, all-reduce, AdamW
 
     def fence():
         if td is not None:

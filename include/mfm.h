@@ -136,6 +136,18 @@ int mfm_flow_step(mfm_ctx* ctx, int mode, uint32_t key0, uint32_t key1, double b
                   float* d_pos, double* d_logp, float* d_grad,
                   float* d_acceptance_rate, uint8_t* d_is_accepted, float* d_proposed_position, int32_t* d_nsteps);
 
+/* ---- L1: one loop iteration in one call (exe_flow_matching.py:432-439) ------------------------------------------ */
+/* train_data_generator(key_gen, states, count, params, beta) (:300-314) followed by train_step(key_train, positions,
+ * state) (:362-368): the flow-MH step of `flow_mode` when count % (mcmc_per_flow_steps + 1) == 0, the MALA step otherwise
+ * (mcmc_per_flow_steps >= 1; the fractional / negative schedules of :304-310 are composed by the host from the separate
+ * entry points), then loss and gradient on the NEW positions and, with apply_update != 0, the optimizer step.  A
+ * multi-GPU host passes apply_update = 0, all-reduces d_grads (SUM) and calls mfm_adamw_step itself.  d_acceptance_rate
+ * and d_nsteps may be NULL; d_nsteps is written by flow iterations only.  Returns MFM_OK or the first failing step's status. */
+int mfm_train_iter(mfm_ctx* ctx, int64_t count, int mcmc_per_flow_steps, int flow_mode,
+                   uint32_t gen_key0, uint32_t gen_key1, uint32_t train_key0, uint32_t train_key1,
+                   double beta, double step_size, float* d_pos, double* d_logp, float* d_grad,
+                   float* d_acceptance_rate, int32_t* d_nsteps, double* d_loss, float* d_grads, int apply_update);
+
 /* ---- K8: annealing (exe_flow_matching.py:391-417) ------------------------------------------------------------- */
 /* Bisection for the next beta on n (global) log-likelihoods; h_beta_out gets the new beta (synchronises). */
 int mfm_beta_update(mfm_ctx* ctx, double prev_beta, const double* d_logliks, int n, double alpha, double* h_beta_out);

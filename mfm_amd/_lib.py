@@ -66,6 +66,8 @@ _SIGS = {
     "mfm_vf_apply": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
     "mfm_ode_transform": (C.c_int, [_P, C.c_int, C.c_int, _P, _U32, _U32, _P, C.c_int, _P, _P, _P]),
     "mfm_flow_step": (C.c_int, [_P, C.c_int, _U32, _U32, C.c_double, _P, _P, _P, _P, _P, _P, _P]),
+    "mfm_train_iter": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _U32, _U32, _U32, _U32, C.c_double, C.c_double,
+                                 _P, _P, _P, _P, _P, _P, _P, C.c_int]),
     "mfm_beta_update": (C.c_int, [_P, C.c_double, _P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     "mfm_normal_rows": (C.c_int, [_P, _P, C.c_int, _P]),
     "mfm_cis_select": (C.c_int, [_P, _U32, _U32, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -277,6 +279,16 @@ class Context:
         self._p()
         _chk(self.lib.mfm_flow_step(self.h, mode, int(key[0]), int(key[1]), float(beta), _ptr(pos, F32), _ptr(logp, F64), _ptr(grad, F32),
                                     _ptr(acc, F32), _ptr(is_acc, U8), _ptr(proposed, F32), _ptr(nsteps, I32)))
+
+    def train_iter(self, count, mcmc_per_flow_steps, flow_mode, key_gen, key_train, beta, step_size, pos, logp, grad, loss, grads,
+                   acc=None, nsteps=None, apply_update=True):
+        """One loop iteration (exe_flow_matching.py:432-439): generator (flow-MH step when ``count % (K+1) == 0``, MALA step
+        otherwise) + train_step on the new positions, in one library call."""
+        self._p()
+        _chk(self.lib.mfm_train_iter(self.h, int(count), int(mcmc_per_flow_steps), int(flow_mode), int(key_gen[0]), int(key_gen[1]),
+                                     int(key_train[0]), int(key_train[1]), float(beta), float(step_size), _ptr(pos, F32), _ptr(logp, F64),
+                                     _ptr(grad, F32), _ptr(acc, F32), _ptr(nsteps, I32), _ptr(loss, F64), _ptr(grads, F32),
+                                     1 if apply_update else 0))
 
     def noise_prefetch(self, keys_gn, keys_step):
         """Produce the draws of the iterations keyed ``keys_gn[j]`` (MALA step) / ``keys_step[j]`` (training batch) on the side

@@ -562,6 +562,25 @@ extern "C" int mfm_adamw_step(mfm_ctx* x, const float* d_grads) {
   return MFM_OK;
 }
 
+extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, double beta, float* d_pos, double* d_logp, float* d_grad,
+                             float* d_acc, uint8_t* d_is_acc, float* d_prop, int32_t* d_nsteps);
+
+// exe_flow_matching.py:432-439 as one call: generator (:300-314) + train_step (:362-368); see include/mfm.h
+extern "C" int mfm_train_iter(mfm_ctx* x, int64_t count, int K, int flow_mode, uint32_t gk0, uint32_t gk1, uint32_t tk0, uint32_t tk1,
+                              double beta, double step_size, float* d_pos, double* d_logp, float* d_grad, float* d_acc,
+                              int32_t* d_nsteps, double* d_loss, float* d_grads, int apply_update) {
+  if (!x) return fail(MFM_EINVAL, "null context");
+  if (K < 1) return fail(MFM_EINVAL, "mfm_train_iter serves mcmc_per_flow_steps >= 1; compose the other schedules from the separate calls");
+  if (count < 0) return fail(MFM_EINVAL, "count must be non-negative");
+  int rc;
+  if (count % ((int64_t)K + 1) == 0) rc = mfm_flow_step(x, flow_mode, gk0, gk1, beta, d_pos, d_logp, d_grad, d_acc, nullptr, nullptr, d_nsteps);
+  else rc = mfm_mala_step(x, gk0, gk1, beta, step_size, 0, d_pos, d_logp, d_grad, d_acc, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  rc = mfm_fm_loss_grad(x, tk0, tk1, d_pos, d_loss, d_grads);
+  if (rc || !apply_update) return rc;
+  return mfm_adamw_step(x, d_grads);
+}
+
 extern "C" int mfm_opt_state(mfm_ctx* x, int32_t out[4], float* lr) {
   if (!x || !out) return fail(MFM_EINVAL, "null argument");
   OptState s;

@@ -173,6 +173,22 @@ class Engine:
         self._deferred.submit(self.grads)
         return loss
 
+    def train_iter(self, count, K, flow_mode, key_gen, key_train, beta, step_size, pos, logp, grad, acc=None, nsteps=None,
+                   loss_out=None):
+        """One loop iteration (exe_flow_matching.py:432-439): generator + train_step.  One rank: a single library call
+        (``mfm_train_iter``).  More ranks: the separate calls, so that the MALA step — which needs neither the parameters
+        nor the gradient buffer — runs while the previous iteration's gradient all-reduce is still in flight."""
+        loss = self.loss if loss_out is None else loss_out
+        if self.world == 1:
+            self.ctx.train_iter(count, K, flow_mode, key_gen, key_train, beta, step_size, pos, logp, grad, loss, self.grads,
+                                acc=acc, nsteps=nsteps)
+            return loss
+        if count % (int(K) + 1) == 0:
+            self.ctx.flow_step(flow_mode, key_gen, beta, pos, logp, grad, acc, None, None, nsteps)
+        else:
+            self.ctx.mala_step(key_gen, beta, step_size, pos, logp, grad, acc)
+        return self.train_step(key_train, pos, loss_out)
+
     def flush(self):
         """Apply a deferred optimizer step now (before reading parameters / optimizer state from outside the ctx)."""
         self._deferred.flush()

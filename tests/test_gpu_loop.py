@@ -139,3 +139,47 @@ def test_run_with_noise_prefetch_is_bit_identical(monkeypatch):
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
     np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
+def test_train_iter_equals_the_separate_calls():
+    """mfm_train_iter (generator :300-314 + train_step :362-368 in one call) against the same iterations composed from
+    mfm_mala_step / mfm_flow_step / mfm_fm_loss_grad / mfm_adamw_step: bit-identical chains, losses and parameters over a
+    schedule with a flow iteration in it (K = 3: counts 4 and 8 are flow steps)."""
+    import torch
+    from oracle import prng
+    from tests import gpu_util as gu
+    from mfm_amd._lib import FLOW_RWMH, MfmError
+    args, dist, k, model, state = gu.phi4_setup(d=64, B=64, hidden=32, F=16, learning_iter=20)
+    params = gu.rand_params(model, seed=3, out_scale=0.05)
+    x0 = dist.init_params.astype(np.float32)
+    K = 3
+    out = []
+    for fused in (False, True):
+        ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+        pos = torch.from_numpy(x0).cuda(); logp = torch.empty(64, device="cuda", dtype=torch.float64); grad = torch.empty_like(pos)
+        acc = torch.empty(64, device="cuda", dtype=torch.float32); nst = torch.zeros(64, device="cuda", dtype=torch.int32)
+        loss = torch.zeros(1, device="cuda", dtype=torch.float64); grads = torch.zeros(ctx.n_params, device="cuda")
+        ctx.mala_init(pos, 1.0, logp, grad)
+        losses, ks = [], prng.PRNGKey(5)
+        for count in range(1, 10):
+            ks, kg, kt = prng.split(ks, 3)
+            if fused:
+                ctx.train_iter(count, K, FLOW_RWMH, kg, kt, 1.0, args.step_size, pos, logp, grad, loss, grads, acc=acc, nsteps=nst)
+            else:
+                if count % (K + 1) == 0:
+                    ctx.flow_step(FLOW_RWMH, kg, 1.0, pos, logp, grad, acc, None, None, nst)
+                else:
+                    ctx.mala_step(kg, 1.0, args.step_size, pos, logp, grad, acc)
+                ctx.fm_loss_grad(kt, pos, loss, grads)
+                ctx.adamw_step(grads)
+            losses.append(loss.item())
+        out.append((pos.cpu().numpy(), logp.cpu().numpy(), np.array(losses), ctx.get_params(), ctx.opt_state(), nst.cpu().numpy()))
+        if fused:
+            with pytest.raises(MfmError, match="mcmc_per_flow_steps >= 1"):
+                ctx.train_iter(1, 0, FLOW_RWMH, kg, kt, 1.0, args.step_size, pos, logp, grad, loss, grads)
+        ctx.close()
+    a, b = out
+    assert a[4] == b[4] and a[4]["step"] == 9
+    assert b[5].min() > 0                                     # the flow iterations ran
+    for u, v in zip(a[:4] + a[5:], b[:4] + b[5:]):
+        np.testing.assert_array_equal(u, v)
