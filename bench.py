@@ -173,7 +173,16 @@ def main():
     ctx.mala_init(pos, beta, logp, grad)
 
     EXTRA = 40                                               # untimed, fully instrumented iterations after the timed region
-    total = a.warmup + a.steps
+    # The metric is a steady-state rate: the timed flow steps must integrate a TRAINED field (at the flax zero-init the flow is
+    # the identity and a flow step costs a tenth of its steady-state time), and one iteration in K+1 is a flow step.  So,
+    # whatever --warmup / --steps are: (1) at least one full cycle (a flow step + K training iterations) runs untimed --
+    # `prep` state-preparation iterations are added in front of a shorter --warmup -- and (2) the loop counter is aligned so
+    # that the timed region STARTS with a flow step: it then holds ceil(steps / (K+1)) of them, never fewer than the
+    # schedule's share (a short --steps understates the rate, it cannot overstate it).  Defaults: prep = 0, alignment = 0.
+    prep = max(0, wl_K + 1 - a.warmup)
+    untimed = prep + a.warmup
+    count0 = (-(untimed + 1)) % (wl_K + 1)
+    total = untimed + a.steps
     keys = np.empty((total + EXTRA, 2, 2), dtype=np.uint32)  # key plumbing of :433, precomputed off the clock
     ks = key_sample
     for i in range(total + EXTRA):
@@ -201,14 +210,13 @@ def main():
     # contain a flow step.  Nothing of the benchmark state changes: parameters, optimizer and chains are untouched.
     _p, _l, _g = pos.clone(), logp.clone(), grad.clone()
     ctx.mala_step(keys[0, 0], beta, args.step_size, _p, _l, _g, acc)
-    if a.warmup < wl_K + 1:          # (a warm-up of a full cycle launches the flow-step kernel itself)
-        ctx.flow_step(FLOW_RWMH, keys[0, 0], beta, _p, _l, _g, acc, None, None, nst)
+    # (the untimed iterations hold a full cycle: they launch the flow-step kernel themselves)
     ctx.fm_loss(keys[0, 1], _p, torch.zeros(1, device=eng.dev, dtype=torch.float64))
     natt_sum.add_(nst.double().sum()); natt_sum.zero_()      # torch loads its reduction kernels lazily, too
     fence()
     del _p, _l, _g
-    count = 0
-    for i in range(a.warmup):
+    count = count0
+    for i in range(untimed):
         count += 1
         step(i, count)
     fence()
@@ -223,7 +231,7 @@ def main():
     dom_cls = "flow_step" if a.workload == "phi-four" else "fm_fwd_bwd"
     ctx.profile(True, classes=[dom_cls])
     t0 = time.perf_counter()
-    for i in range(a.warmup, total):
+    for i in range(untimed, total):
         count += 1
         step(i, count)
     fence()
@@ -274,7 +282,7 @@ def main():
             "config": {"workload": ("phi-four d=256, 4096 chains/GPU, mcmc_per_flow_steps=100, --hutch, beta=1 (BASELINE configs[2])" if a.workload == "phi-four" else
                                     f"pines LGCP d={wl_dim} (32x32), hidden {wl_h}, {a.chains_per_gpu} chains/GPU, mcmc_per_flow_steps=100, --hutch, beta=1 (BASELINE configs[4] per-GPU shape; wide kernel family)"),
                        "chains_total": n_total, "chains_per_gpu": B, "parallelism": f"chains sharded x{world}, RCCL grad all-reduce" if world > 1 else "single GPU",
-                       "flow_steps_timed": n_flow[0], "dopri_attempts_per_chain_per_flow_step": round(natt_mean, 2),
+                       "state_prep_iterations": prep, "flow_steps_timed": n_flow[0], "dopri_attempts_per_chain_per_flow_step": round(natt_mean, 2),
                        "chain_dim_updates_per_s": round(value * wl_dim, 1)},
             "roofline": roof,
             "kernels_ms_total": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in prof.items() if v["launches"]},
