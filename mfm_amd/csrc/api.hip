@@ -487,6 +487,9 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
       wide::FmCall c;
       c.key_time = a.key_time; c.key_ref = a.key_ref; c.key_gauss = a.key_gauss; c.n_total = (uint32_t)n_total; c.chain_offset = (uint32_t)(offset + r0);
       c.sigma = a.sigma; c.cond_flow = a.cond_flow; c.ref_std = a.ref_std; c.pos = d_samples + (size_t)r0 * x->cfg.dim; c.rows = n - r0 < w->R ? n - r0 : w->R;
+      // one rank, one pass: this IS the gradient the optimizer will see, so its finite check rides in the weight-gradient kernel
+      const bool inline_check = train && n <= w->R && x->cfg.n_chain_total == x->cfg.n_chain_local;
+      c.bad = inline_check ? x->flag : nullptr;
       int rcw;
       { ProfScope ps_(x, train ? PROF_FM : PROF_EVAL); rcw = wide::fm(w, x->net, c, train, train ? d_grads : nullptr, x->stream); }
       if (rcw) return fail(rcw, "wide fm kernels cannot be launched for this configuration");
@@ -494,6 +497,7 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
       ProfScope ps2_(x, PROF_REDUCE);
       launch_reduce_loss(w->loss_part, (c.rows + 3) / 4, d_loss, r0 > 0, x->stream);
       LAUNCHCHK();
+      if (inline_check) x->checked_grads = d_grads;
     }
     return MFM_OK;
   }

@@ -173,7 +173,8 @@ static void launch_gemm(const Gemm& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------------
 struct WgLayer { const float* A; int lda; const float* Z; int ldz; int K, N, Kp, Np, m_w, m_b; };
 struct WgJob { int layer, kt, nt; };
-struct WgArgs { WgLayer L[MLP_NLAYER]; const WgJob* jobs; int n_jobs; int rows; float* grads; };
+struct WgArgs { WgLayer L[MLP_NLAYER]; const WgJob* jobs; int n_jobs; int rows; float* grads;
+                int* bad; };   // non-null: raise *bad when a gradient element is not finite (the optimizer's apply_if_finite check)
 
 __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
@@ -214,12 +215,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
   // acc[s][u][i] = dW[64 kt + 4 (4 g + i) + s][64 nt + 4 c + u]
   float* gw = a.grads + L.m_w;
   const bool vec = (L.N & 3) == 0;
+  float chk = 0.f;                             // sum of 0 * element: NaN iff some element of this wave's block is not finite
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = 64 * J.kt + 4 * (4 * g + i) + s;
       if (k >= L.K) continue;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (zc + u < L.N) chk += 0.f * acc[s][u][i];
       if (vec) {
         if (zc < L.N) *reinterpret_cast<f32x4*>(gw + (size_t)k * L.N + zc) = f32x4{acc[s][0][i], acc[s][1][i], acc[s][2][i], acc[s][3][i]};
       } else {
@@ -234,9 +238,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
     if (g == 0) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (zc + u < L.N) a.grads[L.m_b + zc + u] = bs[u];
+        if (zc + u < L.N) { a.grads[L.m_b + zc + u] = bs[u]; chk += 0.f * bs[u]; }
     }
   }
+  if (a.bad && __any(chk != chk) && lane == 0) atomicOr(a.bad, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -258,10 +263,12 @@ struct FmPro {
   int rows, d, dp, F, F2p; float sigma; int cond_flow; double ref_std;
   const float* pos; const float* fourier;
   float* cond; float* tgt; float* ffat;
+  int* flag_reset;       // non-null: the non-finite flag wgrad_kernel raises for this gradient, cleared here
 };
 // K3 batch construction (exe_flow_matching.py:151-169 / :139-147), same draws as fm.hip's prologue
 __global__ __launch_bounds__(256) void fm_prologue_kernel(FmPro a) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (a.flag_reset && blockIdx.x == 0 && threadIdx.x == 0) *a.flag_reset = 0;
   if (b >= a.rows) return;
   const uint32_t bg = a.chain_offset + (uint32_t)b, d = (uint32_t)a.d;
   const float tf = (float)uniform01(a.key_time, bg, a.n_total);                 // :154 / :142
@@ -907,6 +914,7 @@ static void probe_setup(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
 struct FmCall {
   Key2 key_time, key_ref, key_gauss; uint32_t n_total, chain_offset; float sigma; int cond_flow; double ref_std;
   const float* pos; int rows;
+  int* bad;              // non-null (training, one rank): finite check of the gradient rides in the weight-gradient kernel
 };
 // loss (+ gradient into d_grads, canonical layout) on `rows` samples; the per-workgroup loss partials land in w->loss_part
 static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_grads, hipStream_t s) {
@@ -915,7 +923,7 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
   FmPro p; memset(&p, 0, sizeof p);
   p.key_time = c.key_time; p.key_ref = c.key_ref; p.key_gauss = c.key_gauss; p.n_total = c.n_total; p.chain_offset = c.chain_offset;
   p.rows = rows; p.d = n.d; p.dp = n.dp; p.F = n.F; p.F2p = n.F2p; p.sigma = c.sigma; p.cond_flow = c.cond_flow; p.ref_std = c.ref_std;
-  p.pos = c.pos; p.fourier = n.fourier; p.cond = w->cond; p.tgt = w->tgt; p.ffat = w->ffat;
+  p.pos = c.pos; p.fourier = n.fourier; p.cond = w->cond; p.tgt = w->tgt; p.ffat = w->ffat; p.flag_reset = train ? c.bad : nullptr;
   hipLaunchKernelGGL(fm_prologue_kernel, dim3(grid4(rows)), dim3(256), 0, s, p);
   time_branch(w, n, rows, s);
   target_eval(w, n, w->cond, nullptr, rows, s);
@@ -960,7 +968,7 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
     const LayerDesc& L = n.L[l];
     a.L[l] = WgLayer{A[l], lda[l], Z[l], ldz[l], L.K, L.N, L.Kp, L.Np, L.m_w, L.m_b};
   }
-  a.jobs = w->jobs; a.n_jobs = w->n_jobs; a.rows = rows; a.grads = d_grads;
+  a.jobs = w->jobs; a.n_jobs = w->n_jobs; a.rows = rows; a.grads = d_grads; a.bad = c.bad;
   hipLaunchKernelGGL(wgrad_kernel, dim3((w->n_jobs + 3) / 4), dim3(256), 0, s, a);
   return 0;
 }

@@ -135,7 +135,8 @@ def test_vector_field_and_jvp_match_oracle(setup, d, hidden, F):
     ctx.close()
 
 
-def test_finite_check_in_the_reduction_matches_separate_check():
+@pytest.mark.parametrize("family", ["tile", "wide"])
+def test_finite_check_in_the_reduction_matches_separate_check(family):
     """Single rank: mfm_adamw_step(grads) right after mfm_fm_loss_grad(..., grads) takes the apply_if_finite decision
     (exe_flow_matching.py:135-137) from the flag raised in the gradient reduction; a gradient handed over in another
     buffer goes through the separate check kernel.  Same parameters and counters either way, including a rejected
@@ -146,7 +147,9 @@ def test_finite_check_in_the_reduction_matches_separate_check():
     params = gu.rand_params(model, seed=6)
     x32 = dist.init_params.astype(np.float32)
     bad = x32.copy(); bad[3, 5] = np.inf
-    ctxs = [gu.make_ctx(dist, args, fourier=model.f, params=params) for _ in range(2)]
+    from mfm_amd import _lib
+    fam = _lib.FAMILY_WIDE if family == "wide" else _lib.FAMILY_TILE       # wide: the check rides in its weight-gradient kernel
+    ctxs = [gu.make_ctx(dist, args, fourier=model.f, params=params, family=fam) for _ in range(2)]
     loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctxs[0].n_params, device="cuda")
     for it in range(6):
         pos = _dev(bad if it in (2, 3) else x32)
