@@ -14,7 +14,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE FETCH_SIZE" \
            "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 101 --warmup 101 --no-cpu-baseline > $OUT/p$i.json 2> $OUT/p$i.err
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 101 --warmup 201 --no-cpu-baseline > $OUT/p$i.json 2> $OUT/p$i.err
   echo "pmc pass $i done"
 done
 python3 - $OUT <<'PY'
