@@ -82,10 +82,21 @@ __device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf
   return clipf(gv, n.grad_clip);
 }
 
-template <int TPW, bool TRAIN>
+// STATIC: the headline network shape (F = 128, every hidden width 128, d = 256: multi_modal.py:156,178-180 at phi-four
+// d = 256) with its dimensions as compile-time constants -- loop bounds, tile counts and the LDS layout fold, the K loops
+// unroll; offsets into the parameter buffers stay the host's.  Same arithmetic in the same order as the generic instance.
+template <int TPW, bool TRAIN, bool STATIC = false>
 __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const NetDev& n = a.net;
+  NetDev nloc = a.net;
+  if constexpr (STATIC) {
+    nloc.d = 256; nloc.dp = 256; nloc.F = 128; nloc.F2p = 256;
+    nloc.ht1 = nloc.ht2 = nloc.hx1 = nloc.hx2 = nloc.hj1 = nloc.hj2 = 128;
+    constexpr int K_[MLP_NLAYER] = {256, 128, 256, 128, 128, 256, 128, 128}, N_[MLP_NLAYER] = {128, 128, 128, 128, 256, 128, 128, 256};
+#pragma unroll
+    for (int l = 0; l < MLP_NLAYER; ++l) { nloc.L[l].K = nloc.L[l].Kp = K_[l]; nloc.L[l].N = nloc.L[l].Np = N_[l]; }
+  }
+  const NetDev& n = nloc;
   const FmLds L = fm_lds_layout(n, TRAIN);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const int bb = blockIdx.x, b0 = bb * 16, nbb = a.B / 16;
@@ -570,11 +581,24 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)fm_fwd_bwd_kernel<T, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
     hipLaunchKernelGGL((fm_fwd_bwd_kernel<T, TR>), grid, block, sm, stream, a);                           \
   } while (0)
-  if (train) {
+  const NetDev& n = a.net;
+  bool headline = n.d == 256 && n.dp == 256 && n.F == 128 && n.F2p == 256 && n.ht1 == 128 && n.ht2 == 128 && n.hx1 == 128 &&
+                  n.hx2 == 128 && n.hj1 == 128 && n.hj2 == 128 && n.T.kind != MFM_TARGET_LGCP && !getenv("MFM_GENERIC_FM");
+  static const int Kh[MLP_NLAYER] = {256, 128, 256, 128, 128, 256, 128, 128}, Nh[MLP_NLAYER] = {128, 128, 128, 128, 256, 128, 128, 256};
+  for (int l = 0; l < MLP_NLAYER; ++l) headline &= n.L[l].K == Kh[l] && n.L[l].Kp == Kh[l] && n.L[l].N == Nh[l] && n.L[l].Np == Nh[l];
+#define FM_LAUNCH_S(TR)                                                                                    \
+  do {                                                                                                     \
+    (void)hipFuncSetAttribute((const void*)fm_fwd_bwd_kernel<2, TR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+    hipLaunchKernelGGL((fm_fwd_bwd_kernel<2, TR, true>), grid, block, sm, stream, a);                     \
+  } while (0)
+  if (headline) {
+    if (train) FM_LAUNCH_S(true); else FM_LAUNCH_S(false);
+  } else if (train) {
     if (tpw <= 1) FM_LAUNCH(1, true); else if (tpw <= 2) FM_LAUNCH(2, true); else return -3;
   } else {
     if (tpw <= 1) FM_LAUNCH(1, false); else if (tpw <= 2) FM_LAUNCH(2, false); else return -3;
   }
+#undef FM_LAUNCH_S
 #undef FM_LAUNCH
   return 0;
 }
