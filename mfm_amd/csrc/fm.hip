@@ -82,8 +82,8 @@ __device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf
   return clipf(gv, n.grad_clip);
 }
 
-// STATIC: the headline network shape (F = 128, every hidden width 128, d = 256: multi_modal.py:156,178-180 at phi-four
-// d = 256) with its dimensions as compile-time constants -- loop bounds, tile counts and the LDS layout fold, the K loops
+// STATIC: the headline configuration (F = 128, every hidden width 128, relu, phi-four d = 256: multi_modal.py:156,177-180)
+// with its dimensions, activation and target kind as compile-time constants -- loop bounds, tile counts and the LDS layout fold, the K loops
 // unroll; offsets into the parameter buffers stay the host's.  Same arithmetic in the same order as the generic instance.
 template <int TPW, bool TRAIN, bool STATIC = false>
 __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs a) {
@@ -95,6 +95,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     constexpr int K_[MLP_NLAYER] = {256, 128, 256, 128, 128, 256, 128, 128}, N_[MLP_NLAYER] = {128, 128, 128, 128, 256, 128, 128, 256};
 #pragma unroll
     for (int l = 0; l < MLP_NLAYER; ++l) { nloc.L[l].K = nloc.L[l].Kp = K_[l]; nloc.L[l].N = nloc.L[l].Np = N_[l]; }
+    nloc.act = MFM_ACT_RELU; nloc.T.kind = MFM_TARGET_PHI4;      // the epilogues' activation / target selections fold too
   }
   const NetDev& n = nloc;
   const FmLds L = fm_lds_layout(n, TRAIN);
@@ -583,7 +584,7 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
   } while (0)
   const NetDev& n = a.net;
   bool headline = n.d == 256 && n.dp == 256 && n.F == 128 && n.F2p == 256 && n.ht1 == 128 && n.ht2 == 128 && n.hx1 == 128 &&
-                  n.hx2 == 128 && n.hj1 == 128 && n.hj2 == 128 && n.T.kind != MFM_TARGET_LGCP && !getenv("MFM_GENERIC_FM");
+                  n.hx2 == 128 && n.hj1 == 128 && n.hj2 == 128 && n.T.kind == MFM_TARGET_PHI4 && n.act == MFM_ACT_RELU && !getenv("MFM_GENERIC_FM");
   static const int Kh[MLP_NLAYER] = {256, 128, 256, 128, 128, 256, 128, 128}, Nh[MLP_NLAYER] = {128, 128, 128, 128, 256, 128, 128, 256};
   for (int l = 0; l < MLP_NLAYER; ++l) headline &= n.L[l].K == Kh[l] && n.L[l].Kp == Kh[l] && n.L[l].N == Nh[l] && n.L[l].Np == Nh[l];
 #define FM_LAUNCH_S(TR)                                                                                    \
