@@ -33,19 +33,27 @@ struct AdamArgs {
 // apply_if_finite decision + step scalars, identical in every thread.  With inline_decide every thread derives the decision
 // from the flag and the (not yet advanced) state; the last workgroup commits the state once all have read it.
 struct AdamDecision { bool apply; int count; int nf_new; };
-__device__ __forceinline__ AdamDecision adam_decide(const AdamArgs& a) {
+struct AdamRaw { int flag0, nf, last_applied, count; };          // the state words as loaded: no use, hence no wait, yet
+__device__ __forceinline__ AdamRaw adam_load(const AdamArgs& a) {
+  AdamRaw r;
+  r.count = a.st->count; r.nf = a.st->notfinite_count; r.last_applied = a.st->last_applied;
+  r.flag0 = a.inline_decide ? a.flag[0] : 0;
+  return r;
+}
+__device__ __forceinline__ AdamDecision adam_resolve(const AdamArgs& a, const AdamRaw& r) {
   AdamDecision d;
-  d.count = a.st->count;
+  d.count = r.count;
   if (a.inline_decide) {
-    const bool finite = a.flag[0] == 0;
-    d.nf_new = finite ? 0 : a.st->notfinite_count + 1;
+    const bool finite = r.flag0 == 0;
+    d.nf_new = finite ? 0 : r.nf + 1;
     d.apply = finite || d.nf_new > a.max_err;
   } else {
-    d.nf_new = a.st->notfinite_count;
-    d.apply = a.st->last_applied != 0;
+    d.nf_new = r.nf;
+    d.apply = r.last_applied != 0;
   }
   return d;
 }
+__device__ __forceinline__ AdamDecision adam_decide(const AdamArgs& a) { return adam_resolve(a, adam_load(a)); }
 
 __device__ __forceinline__ float lr_schedule(double lr0, int learning_iter, int warmup, int count) {
   // join_schedules([linear(0 -> lr, warmup), linear(lr -> 0, learning_iter - warmup)], [warmup]) (:189-198)
@@ -156,16 +164,16 @@ __device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool app
 struct AdamBlocks { int first[MLP_NLAYER + 1]; int n_blocks; int n_bias_items; };
 __global__ void adamw_vec_kernel(AdamArgs a, AdamBlocks bl) {
   const NetDev& n = a.net;
-  const AdamDecision dec = adam_decide(a);
-  const bool apply = dec.apply;
-  const int count = dec.count;
-  const int c1 = count + 1;
-  const float bc1 = (float)(1.0 - pow(a.b1, (double)c1)), bc2 = (float)(1.0 - pow(a.b2, (double)c1));
-  const float lr = lr_schedule(a.lr0, a.learning_iter, a.warmup, count);
+  const AdamRaw raw = adam_load(a);                 // state reads issued here, first used after the operand loads below
   const float b1 = (float)a.b1, b2 = (float)a.b2;
   const int total = bl.n_blocks + bl.n_bias_items;
   for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
     if (it >= bl.n_blocks) {                       // a bias element: scalar path
+      const AdamDecision dec = adam_resolve(a, raw);
+      const bool apply = dec.apply;
+      const int count = dec.count, c1 = count + 1;
+      const float bc1 = (float)(1.0 - pow(a.b1, (double)c1)), bc2 = (float)(1.0 - pow(a.b2, (double)c1));
+      const float lr = lr_schedule(a.lr0, a.learning_iter, a.warmup, count);
       int p = it - bl.n_blocks, layer = 0;
       for (int l = 0; l < MLP_NLAYER; ++l) { if (p < n.L[l].N) { layer = l; break; } p -= n.L[l].N; }
       adamw_element(a, n.L[layer].m_b + p, apply, bc1, bc2, lr);
@@ -176,15 +184,29 @@ __global__ void adamw_vec_kernel(AdamArgs a, AdamBlocks bl) {
     for (int l = 1; l < MLP_NLAYER; ++l) if (it >= bl.first[l]) layer = l;
     const LayerDesc& ld = n.L[layer];
     const int e = it - bl.first[layer], nb4 = ld.N >> 2, kb4 = e / nb4, k0 = 4 * kb4, n0 = 4 * (e - kb4 * nb4);
-    f32x4 w[4];
+    // every operand is loaded unconditionally and up front: the loads then fly together with the optimizer-state reads the
+    // decision above waits for (a rejected update -- rare -- reads moments it does not use)
+    f32x4 w[4], g4[4], m4[4], v4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const size_t p = (size_t)ld.m_w + (size_t)(k0 + r) * ld.N + n0;
       w[r] = *reinterpret_cast<const f32x4*>(a.master + p);
+      g4[r] = *reinterpret_cast<const f32x4*>(a.grads + p);
+      m4[r] = *reinterpret_cast<const f32x4*>(a.mu + p); v4[r] = *reinterpret_cast<const f32x4*>(a.nu + p);
+    }
+    __builtin_amdgcn_sched_barrier(0);             // keep the loads above the first use of the decision
+    const AdamDecision dec = adam_resolve(a, raw);
+    const bool apply = dec.apply;
+    const int count = dec.count, c1 = count + 1;
+    const float bc1 = (float)(1.0 - pow(a.b1, (double)c1)), bc2 = (float)(1.0 - pow(a.b2, (double)c1));
+    const float lr = lr_schedule(a.lr0, a.learning_iter, a.warmup, count);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t p = (size_t)ld.m_w + (size_t)(k0 + r) * ld.N + n0;
       if (apply) {
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        for (int sl = 0; sl < a.n_slabs; ++sl) g += *reinterpret_cast<const f32x4*>(a.grads + (size_t)sl * n.n_params + p);
-        f32x4 m = *reinterpret_cast<const f32x4*>(a.mu + p), v = *reinterpret_cast<const f32x4*>(a.nu + p);
+        f32x4 g = g4[r];
+        for (int sl = 1; sl < a.n_slabs; ++sl) g += *reinterpret_cast<const f32x4*>(a.grads + (size_t)sl * n.n_params + p);
+        f32x4 m = m4[r], v = v4[r];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           m[j] = b1 * m[j] + (1.f - b1) * g[j];
@@ -204,7 +226,7 @@ __global__ void adamw_vec_kernel(AdamArgs a, AdamBlocks bl) {
       *reinterpret_cast<f32x4*>(a.Wp + ld.w_off + pack_index(k0, n0 + j, ld.Kp / 16)) = f32x4{w[0][j], w[1][j], w[2][j], w[3][j]};
   }
   __syncthreads();
-  if (threadIdx.x == 0) adam_commit(a, dec);
+  if (threadIdx.x == 0) adam_commit(a, adam_resolve(a, raw));
 }
 
 void launch_adamw(const AdamArgs& a, hipStream_t stream) {
