@@ -84,7 +84,8 @@ __device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf
 
 // STATIC: the headline configuration (F = 128, every hidden width 128, relu, phi-four d = 256: multi_modal.py:156,177-180)
 // with its dimensions, activation and target kind as compile-time constants -- loop bounds, tile counts and the LDS layout fold, the K loops
-// unroll; offsets into the parameter buffers stay the host's.  Same arithmetic in the same order as the generic instance.
+// unroll; offsets into the parameter buffers stay the host's.  Same arithmetic as the generic instance (the compiler's multiply-add
+// contraction may differ in the last bits).
 template <int TPW, bool TRAIN, bool STATIC = false>
 __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
