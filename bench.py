@@ -98,6 +98,30 @@ def cpu_baseline(params_flat, fourier, steps_mala, chains, seed=1):
                 n_att=float(stats["n_att_inv"].mean() + stats["n_att_fwd"].mean()))
 
 
+def usable_cores():
+    """Host threads this process may actually use: CPU affinity capped by the cgroup CPU quota (a GPU box hands a job a share
+    of its cores), not the machine's core count."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def pmc_traffic(kernel_class):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc passes of this
     same command, tools/prof_round.sh): 2 * FETCH_SIZE + WRITE_SIZE, both reported in KB; the factor 2 is the gfx950
@@ -291,7 +315,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and a.workload == "phi-four":
             try:
                 from threadpoolctl import threadpool_limits
-                cores = os.cpu_count() or 1
+                cores = usable_cores()
                 params_flat = ctx.get_params()
                 with threadpool_limits(limits=cores):
                     cb = cpu_baseline(params_flat, fourier, steps_mala=4, chains=512)
