@@ -63,8 +63,13 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int s
 // buffer_store_dwordx4 with an SGPR soffset followed at once by a VALU write of one of its data registers stored the
 // NEW value of that register on gfx950 (one element of the float4 wrong, which element depending on register
 // allocation).  hipcc only pads that write-after-read hazard when soffset is not a register, so that is the form used.
+// The per-lane offset is formed IN PLACE by a volatile add: as a plain `voff + soff` every store's offset is a loop invariant
+// the compiler hoists out of the solver loop, and with 256 VGPRs in use it spilled them all (a scratch reload and a
+// vmcnt(0) in front of each store of the time batch).
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + soff, 0, 0);
+  int off;
+  asm volatile("v_add_u32 %0, %1, %2" : "=v"(off) : "s"(soff), "v"(voff));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
 }
 template <int NTL, int T1OFF>
 __device__ __forceinline__ void load_group(f32x4 (&bf)[4], __amdgpu_buffer_rsrc_t r, int soff, int lane) {
