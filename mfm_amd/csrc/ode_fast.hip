@@ -315,13 +315,20 @@ struct FTile {
     job(afh, W(S::W0, wave, 16, 0), W(S::W0, wave, 16, 8));      // cos half
     FSEC(2);
     __syncthreads();
+    {
+      // all five read-backs in flight before the first is used (left to itself the compiler reuses ONE destination and
+      // serialises five L2 round trips here)
+      f32x4 sn[5];
 #pragma unroll
-    for (int s = 0; s < 5; ++s) {
-      const f32x4 sn = bload(sr, lane * 16, ((s * NW + wave) * 3 + 0) * 1024);
+      for (int s = 0; s < 5; ++s) sn[s] = bload(sr, lane * 16, ((s * NW + wave) * 3 + 0) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (CMP) { if (mrow[s][i] >= 0) *at(o_hc, mrow[s][i] * LDH) = sn[i]; }
-        else *at(o_he, (s * 16 + i) * LDH) = sn[i];
+      for (int s = 0; s < 5; ++s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (CMP) { if (mrow[s][i] >= 0) *at(o_hc, mrow[s][i] * LDH) = sn[s][i]; }
+          else *at(o_he, (s * 16 + i) * LDH) = sn[s][i];
+        }
       }
     }
     __syncthreads();
