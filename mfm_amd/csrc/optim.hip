@@ -162,7 +162,7 @@ __device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool app
 // are then all 128-bit accesses, where adamw_kernel scatters three 4-byte stores per parameter -- that matters for the
 // pines widths (8.65 M parameters, 34.6 MB per copy).  Biases are handled one element per thread after the blocks.
 struct AdamBlocks { int first[MLP_NLAYER + 1]; int n_blocks; int n_bias_items; };
-__global__ void adamw_vec_kernel(AdamArgs a, AdamBlocks bl) {
+__global__ __launch_bounds__(256) void adamw_vec_kernel(AdamArgs a, AdamBlocks bl) {
   const NetDev& n = a.net;
   const AdamRaw raw = adam_load(a);                 // state reads issued here, first used after the operand loads below
   const float b1 = (float)a.b1, b2 = (float)a.b2;
