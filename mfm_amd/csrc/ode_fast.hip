@@ -79,7 +79,7 @@ __device__ __forceinline__ void load_group(f32x4 (&bf)[4], __amdgpu_buffer_rsrc_
 }
 
 #ifndef FAST_DBUF_MAX_MT
-#define FAST_DBUF_MAX_MT 2
+#define FAST_DBUF_MAX_MT 1
 #endif
 template <int MT, int NTL, int LDA>
 __device__ __forceinline__ void exec_group(const float* arow, const f32x4 (&bf)[4], f32x4 (&acc)[NTL][MT]) {
