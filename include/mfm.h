@@ -117,7 +117,11 @@ int mfm_fm_loss_grad(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const float* d_
 int mfm_fm_loss(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const float* d_samples, int n, int n_total, int offset,
                 double* d_loss);
 
-/* ---- K7: optimizer step (exe_flow_matching.py:129-137,184,366) ------------------------------------------------ */
+/* ---- K7: optimizer step (exe_flow_matching.py:129-137,184,366) ------------------------------------------------
+ * apply_if_finite: on a single-rank context the finite check of the gradient that mfm_fm_loss_grad just wrote to d_grads
+ * rides in its reduction, and mfm_adamw_step(d_grads) with the SAME pointer reuses that verdict.  A caller that changes the
+ * buffer's contents in between (its own all-reduce, accumulation, clipping) must pass the result through a DIFFERENT buffer
+ * (or call on a multi-rank context): any other pointer is checked afresh by the optimizer's own check kernel. */
 int mfm_adamw_step(mfm_ctx* ctx, const float* d_grads);
 /* host copies of {step, count, notfinite_count, last_applied} and the learning rate logged at :367 */
 int mfm_opt_state(mfm_ctx* ctx, int32_t h_out[4], float* h_last_lr);
@@ -197,9 +201,35 @@ int mfm_smc_weights(mfm_ctx* ctx, const double* d_loglik, int n, double delta, d
 int mfm_smc_resample(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const double* d_weights, int n, double* d_scratch,
                      int32_t* d_idx);
 int mfm_gather_rows(mfm_ctx* ctx, const float* d_src, const int32_t* d_idx, int n, int dim, float* d_dst);
+/* ---- N1: self-normalised importance resampling of the final flow samples (exe_flow_matching.py:458-459):
+ *      d_idx[j] = jax.random.choice(key, n, (m,), p = exp(d_logw - max d_logw))[j]; d_scratch: n doubles (the cumulative sum,
+ *      taken in index order).  Combine with mfm_gather_rows. ---- */
+int mfm_choice_logw(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const double* d_logw, int n, int m, double* d_scratch,
+                    int32_t* d_idx);
 /* d_out[0..1] = sum and sum of squares (float64) of d_x[0..n): the per-iteration acceptance statistics
  * (exe_flow_matching.py:442-443: infos.acceptance_rate.mean() / .std()) without a host round trip */
 int mfm_acc_stats(mfm_ctx* ctx, const float* d_x, int n, double* d_out);
+
+/* ---- algorithmic counters (the figures roofline numbers are computed from) ----------------------
+ * h_out[0] MALA chain-steps, [1] flow-matching training samples, [2] flow-matching evaluation samples (mfm_fm_loss),
+ * [3] Dopri5 solves (a flow step is two per chain), [4] attempted Dopri5 steps over all solves (summed on the device),
+ * [5] vector-field evaluations = 2 * [3] + 6 * [4] (odeint: f(y0), the initial-step probe, six stages per attempt),
+ * [6] optimizer steps, [7] algorithmic HBM bytes of the MALA steps (4 (5 dim + 5) per chain-step).  Synchronises. */
+int mfm_get_counters(mfm_ctx* ctx, int64_t h_out[8]);
+int mfm_reset_counters(mfm_ctx* ctx);
+
+/* ---- parity instrumentation: Dormand-Prince on a PRESCRIBED step sequence -------------------------------------------------
+ * Arms the NEXT mfm_ode_transform (one solve per sample) or mfm_flow_step (two: 0 inverse, 1 forward) on this context: the
+ * solver takes d_dt[j] as the step size of attempt j (j = 0: the initial step) and d_acc[j] as its accept decision instead
+ * of its controller's, and records what the controller computed: d_ratio[j] = error ratio of attempt j, d_dt_own[0] = its
+ * initial step, d_dt_own[j + 1] = the step it proposed after attempt j.  Element (solve s, sample r, attempt j) of each
+ * array is at ((s * n + r) * cap + j), n = samples of the armed call; a zero d_dt entry ends the solve.  Lets two
+ * implementations be compared stage for stage on the same step sequence (tests/test_gpu_replay.py); no counterpart in the
+ * reference.  d_diag (may be NULL; flow step only): float64 [n][4] = {inverse log-det, forward log-det, tempered log-density
+ * at the proposal, log acceptance ratio}, the terms of exe_flow_matching.py:271-274.  d_dt == NULL disarms.  Fused kernel
+ * family only (EUNSUPPORTED on the wide family). */
+int mfm_debug_replay(mfm_ctx* ctx, int cap, const float* d_dt, const uint8_t* d_acc, float* d_ratio, float* d_dt_own,
+                     double* d_diag);
 
 /* class_mask: 0 = off; otherwise bit c enables class c (-1: all) and the record is reset.  Two event records per launch
  * cost ~6 us of stream time each side on this runtime, so a caller that is itself being timed enables only the class it

@@ -59,6 +59,7 @@ _SIGS = {
     "mfm_smc_resample": (C.c_int, [_P, _U32, _U32, _P, C.c_int, _P, _P]),
     "mfm_gather_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "mfm_acc_stats": (C.c_int, [_P, _P, C.c_int, _P]),
+    "mfm_choice_logw": (C.c_int, [_P, _U32, _U32, _P, C.c_int, C.c_int, _P, _P]),
     "mfm_fm_loss_grad": (C.c_int, [_P, _U32, _U32, _P, _P, _P]),
     "mfm_fm_loss": (C.c_int, [_P, _U32, _U32, _P, C.c_int, C.c_int, C.c_int, _P]),
     "mfm_adamw_step": (C.c_int, [_P, _P]),
@@ -75,6 +76,9 @@ _SIGS = {
     "mfm_max_mean_disc": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_double)]),
     "mfm_noise_prefetch": (C.c_int, [_P, C.c_int, C.POINTER(_U32), C.POINTER(_U32)]),
     "mfm_noise_drop": (C.c_int, [_P]),
+    "mfm_get_counters": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "mfm_reset_counters": (C.c_int, [_P]),
+    "mfm_debug_replay": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "mfm_profile": (C.c_int, [_P, C.c_int]),
     "mfm_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mfm_pack_index": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -238,6 +242,10 @@ class Context:
     def smc_resample(self, key, weights, scratch, idx):
         _chk(self.lib.mfm_smc_resample(self.h, int(key[0]), int(key[1]), _ptr(weights, F64), weights.shape[0], _ptr(scratch, F64), _ptr(idx, I32)))
 
+    def choice_logw(self, key, logw, m, scratch, idx):
+        """idx[j] = jax.random.choice(key, n, (m,), p=exp(logw - max logw))[j] (``exe_flow_matching.py:458-459``)."""
+        _chk(self.lib.mfm_choice_logw(self.h, int(key[0]), int(key[1]), _ptr(logw, F64), logw.shape[0], int(m), _ptr(scratch, F64), _ptr(idx, I32)))
+
     def acc_stats(self, x, out):
         """out[0:2] (float64) = sum, sum of squares of the float32 vector x."""
         _chk(self.lib.mfm_acc_stats(self.h, _ptr(x, F32), x.shape[0], _ptr(out, F64)))
@@ -306,6 +314,28 @@ class Context:
 
     def noise_drop(self):
         _chk(self.lib.mfm_noise_drop(self.h))
+
+    COUNTERS = ("mala_chain_steps", "fm_train_samples", "fm_eval_samples", "ode_solves", "dopri_attempts", "field_evals",
+                "optimizer_steps", "mala_hbm_bytes")
+
+    def counters(self):
+        """Algorithmic work done through this context since creation / ``reset_counters`` (``mfm_get_counters``)."""
+        out = (C.c_int64 * 8)()
+        _chk(self.lib.mfm_get_counters(self.h, out))
+        return dict(zip(self.COUNTERS, [int(v) for v in out]))
+
+    def reset_counters(self):
+        _chk(self.lib.mfm_reset_counters(self.h))
+
+    def debug_replay(self, dt, acc, ratio, dt_own, diag=None):
+        """Arm the next ``ode_transform`` / ``flow_step`` with a prescribed step sequence (parity instrumentation,
+        ``mfm_debug_replay``): float32 ``dt``, uint8 ``acc``, float32 outputs ``ratio`` / ``dt_own``, all CUDA tensors of shape
+        [n, cap] (transform) or [2, n, cap] (flow step)."""
+        cap = dt.shape[-1]
+        for t_ in (acc, ratio, dt_own):
+            assert t_.shape == dt.shape
+        self._replay_keep = (dt, acc, ratio, dt_own, diag)      # the library holds raw pointers until the armed call has run
+        _chk(self.lib.mfm_debug_replay(self.h, cap, _ptr(dt, F32), _ptr(acc, U8), _ptr(ratio, F32), _ptr(dt_own, F32), _ptr(diag, F64)))
 
     PROF_CLASSES = ("mala_step", "fm_fwd_bwd", "wgrad", "adamw", "flow_step", "fm_eval", "reduce", "_")
 

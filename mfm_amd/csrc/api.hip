@@ -52,6 +52,9 @@ struct NoiseWs {
   int n_valid = 0, cur_gn = 0, cur_st = 0;      // slots filled by the last flow step, consumption cursors
 };
 
+// slots of mfm_get_counters
+enum { CTR_MALA = 0, CTR_FM_TRAIN = 1, CTR_FM_EVAL = 2, CTR_SOLVES = 3, CTR_ATTEMPTS = 4, CTR_FIELD_EVALS = 5, CTR_OPT_STEPS = 6, CTR_MALA_BYTES = 7 };
+
 struct mfm_ctx {
   Prof* prof;
   NoiseWs* noise;
@@ -68,6 +71,10 @@ struct mfm_ctx {
   const float* checked_grads = nullptr;   // gradient whose finite check already sits in flag[0] (single-rank mfm_fm_loss_grad)
   float *gmm_mode, *gmm_std, *gmm_logw, *counts, *Kinv, *kbias;
   OdeWs ode;
+  Replay replay;               // armed by mfm_debug_replay for the NEXT mfm_ode_transform / mfm_flow_step (dt == nullptr: off)
+  int64_t ctr[8];              // mfm_get_counters: host-side tallies (slot 4, the attempted Dopri5 steps, is summed on the device)
+  unsigned long long* d_att;   // device tally of attempted steps
+  int* att_buf; size_t att_cap;   // per-sample attempt counts of the last solve when the caller passed no d_nsteps
   double* beta_out;
   wide::Ctx* wide;             // non-null: the wide kernel family serves the network kernels (wide.hip)
 };
@@ -225,6 +232,7 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
   }
   ALLOC(x->loss_part, x->loss_cap);
   ALLOC(x->jobs, x->n_jobs); ALLOC(x->opt, 1); ALLOC(x->flag, 4); ALLOC(x->beta_out, 4);
+  ALLOC(x->d_att, 1); HIPCHK(hipMemset(x->d_att, 0, sizeof(unsigned long long)));
   HIPCHK(hipMemcpy(x->jobs, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(x->master, 0, n.n_params * 4)); HIPCHK(hipMemset(x->mu, 0, n.n_params * 4));
   HIPCHK(hipMemset(x->nu, 0, n.n_params * 4)); HIPCHK(hipMemset(x->Wp, 0, n.n_packed * 4));
@@ -245,7 +253,8 @@ extern "C" int mfm_destroy(mfm_ctx* x) {
   if (!x) return MFM_OK;
   hipDeviceSynchronize();
   void* ps[] = {x->master, x->mu, x->nu, x->Wp, x->WpT, x->bias, x->fourier, x->acts, x->dzs, x->slabs, x->loss_part,
-                x->jobs, x->opt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->beta_out};
+                x->jobs, x->opt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->beta_out,
+                x->d_att, x->att_buf};
   for (void* p : ps) if (p) hipFree(p);
   ode_ws_free(x->ode);
   wide::destroy(x->wide);
@@ -414,6 +423,7 @@ static int mala_step_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const uint32_t
     ProfScope ps_(x, PROF_MALA);
     if (lgcp_mala_dispatch(x, l)) return fail(MFM_ETOOLARGE, "dim %d too large for the LGCP MALA kernel", x->cfg.dim);
     LAUNCHCHK();
+    x->ctr[CTR_MALA] += x->cfg.n_chain_local; x->ctr[CTR_MALA_BYTES] += (int64_t)x->cfg.n_chain_local * 4 * (5 * x->cfg.dim + 5);
     return MFM_OK;
   }
   MalaArgs a = mala_args(x, beta);
@@ -430,6 +440,7 @@ static int mala_step_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const uint32_t
   ProfScope ps_(x, PROF_MALA);
   if (launch_mala_step(a, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large for the MALA kernel", x->cfg.dim);
   LAUNCHCHK();
+  x->ctr[CTR_MALA] += x->cfg.n_chain_local; x->ctr[CTR_MALA_BYTES] += (int64_t)x->cfg.n_chain_local * 4 * (5 * x->cfg.dim + 5);
   return MFM_OK;
 }
 
@@ -470,6 +481,7 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
   if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
   if (n <= 0 || n % 16) return fail(MFM_EUNSUPPORTED, "sample count must be a positive multiple of 16 (got %d)", n);
   if (!x->wide && n / 16 > x->loss_cap) return fail(MFM_ETOOLARGE, "n=%d exceeds max_eval_samples given at mfm_create", n);
+  x->ctr[train ? CTR_FM_TRAIN : CTR_FM_EVAL] += n;
   FmArgs a; memset(&a, 0, sizeof a);
   a.net = x->net; a.ws = x->ws;
   const Key2 key{k0, k1};
@@ -563,6 +575,7 @@ extern "C" int mfm_adamw_step(mfm_ctx* x, const float* d_grads) {
   ProfScope ps_(x, PROF_ADAM);
   launch_adamw(a, x->stream);
   LAUNCHCHK();
+  x->ctr[CTR_OPT_STEPS] += 1;
   return MFM_OK;
 }
 
@@ -595,6 +608,57 @@ extern "C" int mfm_opt_state(mfm_ctx* x, int32_t out[4], float* lr) {
   return MFM_OK;
 }
 
+// ---- algorithmic counters (mfm_get_counters) ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tally_attempts_kernel(const int* nsteps, int n, unsigned long long* out) {
+  __shared__ unsigned long long part[4];
+  unsigned long long s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (unsigned long long)nsteps[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+// the solver kernels report attempted steps per sample; where the caller did not ask for them the context lends a buffer
+static int* att_buffer(mfm_ctx* x, int32_t* d_nsteps, int n) {
+  if (d_nsteps) return d_nsteps;
+  if ((size_t)n > x->att_cap) {
+    if (x->att_buf) { (void)hipStreamSynchronize(x->stream); (void)hipFree(x->att_buf); x->att_buf = nullptr; x->att_cap = 0; }
+    if (hipMalloc((void**)&x->att_buf, (size_t)n * sizeof(int)) != hipSuccess) return nullptr;
+    x->att_cap = (size_t)n;
+  }
+  return x->att_buf;
+}
+static void tally_solves(mfm_ctx* x, const int* nsteps, int n, int solves_per_sample) {
+  x->ctr[CTR_SOLVES] += (int64_t)n * solves_per_sample;
+  if (nsteps) hipLaunchKernelGGL(tally_attempts_kernel, dim3(1), dim3(256), 0, x->stream, nsteps, n, x->d_att);
+}
+
+extern "C" int mfm_get_counters(mfm_ctx* x, int64_t h_out[8]) {
+  if (!x || !h_out) return fail(MFM_EINVAL, "null argument");
+  unsigned long long att = 0;
+  HIPCHK(hipStreamSynchronize(x->stream));
+  HIPCHK(hipMemcpy(&att, x->d_att, sizeof att, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 8; ++i) h_out[i] = x->ctr[i];
+  h_out[CTR_ATTEMPTS] = (int64_t)att;
+  h_out[CTR_FIELD_EVALS] = 2 * x->ctr[CTR_SOLVES] + 6 * (int64_t)att;      // odeint: f(y0), the initial-step probe, six stages per attempt
+  return MFM_OK;
+}
+extern "C" int mfm_reset_counters(mfm_ctx* x) {
+  if (!x) return fail(MFM_EINVAL, "null ctx");
+  for (int i = 0; i < 8; ++i) x->ctr[i] = 0;
+  HIPCHK(hipMemsetAsync(x->d_att, 0, sizeof(unsigned long long), x->stream));
+  return MFM_OK;
+}
+
+extern "C" int mfm_debug_replay(mfm_ctx* x, int cap, const float* d_dt, const uint8_t* d_acc, float* d_ratio, float* d_dt_own, double* d_diag) {
+  if (!x) return fail(MFM_EINVAL, "null ctx");
+  if (!d_dt) { memset(&x->replay, 0, sizeof x->replay); return MFM_OK; }          // disarm
+  if (!d_acc || !d_ratio || !d_dt_own || cap < 2) return fail(MFM_EINVAL, "mfm_debug_replay needs all four arrays and cap >= 2");
+  if (x->wide) return fail(MFM_EUNSUPPORTED, "the wide kernel family (host-driven Dopri5) has no replay instrumentation");
+  x->replay.dt = d_dt; x->replay.acc = d_acc; x->replay.ratio = d_ratio; x->replay.dt_own = d_dt_own; x->replay.cap = cap; x->replay.n = 0; x->replay.diag = d_diag;
+  return MFM_OK;
+}
+
 extern "C" int mfm_vf_apply(mfm_ctx* x, const float* d_x, const float* d_t, const float* d_tan, int n, float* d_v, float* d_jvp) {
   NEED_TARGET();
   if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
@@ -621,17 +685,21 @@ extern "C" int mfm_ode_transform(mfm_ctx* x, int direction, int per_chain, const
   if ((size_t)n > x->ode.rows) return fail(MFM_ETOOLARGE, "n=%d exceeds max_eval_samples given at mfm_create", n);
   OdeArgs a = ode_args(x->net, x->cfg, x->ode);
   a.direction = direction; a.per_chain_keys = per_chain; a.keys = d_keys; a.key = Key2{k0, k1};
-  a.in = d_in; a.out = d_out; a.ldj = d_ldj; a.nsteps = d_nsteps; a.n = n;
+  a.in = d_in; a.out = d_out; a.ldj = d_ldj; a.n = n;
+  a.nsteps = d_nsteps = att_buffer(x, d_nsteps, n);
+  a.rp = x->replay; a.rp.n = n; memset(&x->replay, 0, sizeof x->replay);      // one-shot
   if (x->wide) {
     launch_probe(per_chain ? 0 : 1, d_keys, a.key, 0, 0, 0, n, x->net.d, const_cast<float*>(a.z1), x->stream);
     const int rcw = wide::transform(x->wide, x->net, direction, a.rtol, a.atol, a.max_attempts, a.z1, d_in, n, d_out, d_ldj, d_nsteps, x->stream);
     if (rcw) return fail(rcw, "wide ODE transform failed: %s", hipGetErrorString(hipGetLastError()));
     LAUNCHCHK();
+    tally_solves(x, d_nsteps, n, 1);
     return MFM_OK;
   }
   int rc = launch_ode_transform(a, x->stream);
   if (rc) return fail(rc, "ODE kernel cannot be launched for this configuration");
   LAUNCHCHK();
+  tally_solves(x, d_nsteps, n, 1);
   return MFM_OK;
 }
 
@@ -646,7 +714,8 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
   FlowArgs f; memset(&f, 0, sizeof f);
   f.mode = mode; f.key = Key2{k0, k1}; f.n_total = x->cfg.n_chain_total; f.chain_offset = x->cfg.chain_offset;
   f.beta = beta; f.ref_std = (float)x->cfg.ref_std; f.pos = d_pos; f.logp = d_logp; f.grad = d_grad; f.acc_prob = d_acc; f.accepted = d_isacc;
-  f.proposed = d_prop; f.nsteps = d_nsteps;
+  f.proposed = d_prop; f.nsteps = d_nsteps = att_buffer(x, d_nsteps, a.n);
+  a.rp = x->replay; a.rp.n = a.n; memset(&x->replay, 0, sizeof x->replay);    // one-shot
   // draws of the following iterations, produced by the workgroups of this launch whose tile is done (noise.hip); only the
   // shape-specialised kernel carries that tail: elsewhere the request is dropped and the consumers draw in line
   NoiseArgs nz; memset(&nz, 0, sizeof nz);
@@ -665,23 +734,26 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
     }
     w->n_armed = 0;
   }
-  ProfScope ps_(x, PROF_FLOW);
-  if (x->wide) {
-    launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 0, a.n, x->net.d, const_cast<float*>(a.zgen), x->stream);     // key_gen
-    launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 3, a.n, x->net.d, const_cast<float*>(a.z1), x->stream);       // key_hutch2
-    launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 2, a.n, x->net.d, const_cast<float*>(a.z2), x->stream);       // key_hutch1
-    wide::FlowCall c; memset(&c, 0, sizeof c);
-    c.mode = mode; c.key = f.key; c.n_total = f.n_total; c.chain_offset = f.chain_offset; c.beta = beta; c.rows = a.n; c.ref_std = f.ref_std;
-    c.rtol = a.rtol; c.atol = a.atol; c.max_attempts = a.max_attempts; c.z_inv = a.z1; c.z_fwd = a.z2; c.zgen = a.zgen;
-    c.pos = d_pos; c.logp = d_logp; c.grad = d_grad; c.acc_prob = d_acc; c.accepted = d_isacc; c.proposed = d_prop; c.nsteps = d_nsteps;
-    const int rcw = wide::flow_step(x->wide, x->net, c, x->stream);
-    if (rcw) return fail(rcw, "wide flow step failed: %s", hipGetErrorString(hipGetLastError()));
+  int rc = 0;
+  {
+    ProfScope ps_(x, PROF_FLOW);
+    if (x->wide) {
+      launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 0, a.n, x->net.d, const_cast<float*>(a.zgen), x->stream);     // key_gen
+      launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 3, a.n, x->net.d, const_cast<float*>(a.z1), x->stream);       // key_hutch2
+      launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 2, a.n, x->net.d, const_cast<float*>(a.z2), x->stream);       // key_hutch1
+      wide::FlowCall c; memset(&c, 0, sizeof c);
+      c.mode = mode; c.key = f.key; c.n_total = f.n_total; c.chain_offset = f.chain_offset; c.beta = beta; c.rows = a.n; c.ref_std = f.ref_std;
+      c.rtol = a.rtol; c.atol = a.atol; c.max_attempts = a.max_attempts; c.z_inv = a.z1; c.z_fwd = a.z2; c.zgen = a.zgen;
+      c.pos = d_pos; c.logp = d_logp; c.grad = d_grad; c.acc_prob = d_acc; c.accepted = d_isacc; c.proposed = d_prop; c.nsteps = d_nsteps;
+      const int rcw = wide::flow_step(x->wide, x->net, c, x->stream);
+      if (rcw) return fail(rcw, "wide flow step failed: %s", hipGetErrorString(hipGetLastError()));
+    } else {
+      rc = launch_flow_step(a, f, nz, x->stream);
+      if (rc) return fail(rc, "flow step cannot be launched for this configuration");
+    }
     LAUNCHCHK();
-    return MFM_OK;
   }
-  int rc = launch_flow_step(a, f, nz, x->stream);
-  if (rc) return fail(rc, "flow step cannot be launched for this configuration");
-  LAUNCHCHK();
+  tally_solves(x, d_nsteps, a.n, 2);
   return MFM_OK;
 }
 
@@ -819,6 +891,13 @@ extern "C" int mfm_smc_resample(mfm_ctx* x, uint32_t k0, uint32_t k1, const doub
   if (!x || !d_weights || !d_scratch || !d_idx) return fail(MFM_EINVAL, "null argument");
   if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
   hipLaunchKernelGGL(smc_resample_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, Key2{k0, k1}, d_weights, n, d_scratch, d_idx);
+  LAUNCHCHK();
+  return MFM_OK;
+}
+extern "C" int mfm_choice_logw(mfm_ctx* x, uint32_t k0, uint32_t k1, const double* d_logw, int n, int m, double* d_scratch, int32_t* d_idx) {
+  if (!x || !d_logw || !d_scratch || !d_idx) return fail(MFM_EINVAL, "null argument");
+  if (n <= 0 || m <= 0) return fail(MFM_EINVAL, "n and m must be positive");
+  hipLaunchKernelGGL(choice_logw_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, Key2{k0, k1}, d_logw, n, m, d_scratch, d_idx);
   LAUNCHCHK();
   return MFM_OK;
 }

@@ -40,6 +40,18 @@ static void ode_ws_free(OdeWs& w) {
   w.noise = nullptr; w.fast_scr = nullptr;
 }
 
+// PARITY INSTRUMENTATION (mfm_debug_replay): a prescribed Dormand-Prince step sequence per sample.  With dt != nullptr the
+// solver takes dt[j] as the step size of attempt j (j = 0: the initial step) and acc[j] as its accept decision instead of
+// its controller's; the controller is still evaluated and what it computed is recorded (ratio[j]: error ratio of attempt j,
+// dt_own[0]: its initial step, dt_own[j + 1]: the step it proposed after attempt j).  Element (solve s, sample r, attempt j)
+// of every array sits at ((s * n + r) * cap + j); a flow step has two solves (0: inverse, 1: forward), a transform one.
+struct Replay {
+  const float* dt; const uint8_t* acc; float* ratio; float* dt_own; int cap, n;
+  double* diag;             // flow step only, may be null: [n][4] = {vol0 (inverse log-det), log-det of the forward solve,
+                            // tempered log-density at the proposal, log acceptance ratio} -- the terms of :271-274 / :253-256
+  __device__ __forceinline__ size_t at(int solve, int row, int j) const { return ((size_t)solve * n + row) * cap + j; }
+};
+
 struct OdeArgs {
   NetDev net;
   int hutch;
@@ -53,6 +65,7 @@ struct OdeArgs {
   const float* z2;          // probe of the second solve (flow step)
   const float* zgen;        // latent proposal noise (flow step)
   f32x4* fast_scr;          // time-branch scratch of the shape-specialised kernels (ode_fast.hip)
+  Replay rp;                // rp.dt == nullptr: off (production)
 };
 
 struct FlowArgs {
@@ -418,7 +431,7 @@ enum { RS_T = 0, RS_DT = 1, RS_H0 = 2, RS_D1 = 3, RS_ELL = 4, RS_KL = 5 /* ..11 
 
 template <int TPW, int NW>
 __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float atol, int max_attempts,
-                                          float (&y)[TPW][4], float (&ell)[4], int (&natt)[4]) {
+                                          float (&y)[TPW][4], float (&ell)[4], int (&natt)[4], const Replay& rp, int rp_solve, int rp_row0) {
   const NetDev& N = *T.n;
   const int d = N.d, g = T.g, c = T.c, wave = T.wave;
   const float inv_n = 1.f / (float)(d + 1);
@@ -560,6 +573,11 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
         const float h1 = (d14[i] <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h04[i] * 1e-3f)
                                                             : powf(0.01f / fmaxf(d14[i], d2), 0.2f);
         dt[i] = fminf(100.f * h04[i], h1);
+        if (rp.dt) {
+          const size_t o = rp.at(rp_solve, rp_row0 + 4 * g + i, 0);
+          if (wave == 0 && c == 0) rp.dt_own[o] = dt[i];
+          dt[i] = rp.dt[o];
+        }
         any |= (dt[i] > 0.f);
       }
       T.rs_put(RS_DT, dt);
@@ -608,10 +626,18 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
         const float tol = atol + rtol * fmaxf(fabsf(ell4[i]), fabsf(l1));
         const float rr = el / tol;
         const float ratio = sqrtf((e2[i] + rr * rr) * inv_n);
-        const bool acc = active && ratio <= 1.f;
+        bool acc = active && ratio <= 1.f;
         const float dfac = ratio < 1.f ? 1.f : 0.2f;
         const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
-        const float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+        float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+        if (rp.dt && active) {
+          const int j = (int)na4[i];
+          const bool in = j < rp.cap, nx = j + 1 < rp.cap;
+          const size_t o = rp.at(rp_solve, rp_row0 + 4 * g + i, in ? j : 0);
+          if (wave == 0 && c == 0 && in) { rp.ratio[o] = ratio; if (nx) rp.dt_own[o + 1] = ndt; }
+          acc = in && rp.acc[o] != 0;
+          ndt = nx ? rp.dt[o + 1] : 0.f;
+        }
         t_n[i] = t4[i]; ell_n[i] = ell4[i]; kl0_n[i] = kl[0][i]; dn_n[i] = dn4[i];
         if (acc) {
           const float tn = t4[i] + dti;
@@ -726,7 +752,7 @@ __global__ __launch_bounds__(NW * 64) void ode_transform_kernel(OdeArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[q][i] = col < d ? a.in[(size_t)(b0 + 4 * T.g + i) * d + col] : 0.f;
   }
-  ode_solve<TPW, NW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
+  ode_solve<TPW, NW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt, a.rp, 0, b0);
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     const int col = (T.wave + NW * q) * 16 + T.c;
@@ -883,7 +909,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
     }
     fill_probe(T, ph == 0 ? a.z1 : a.z2, b0, !T.exact);       // key_hutch2 for the inverse, key_hutch1 for the forward solve
     T.sign = ph == 0 ? -1 : 1;
-    ode_solve<TPW, NW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
+    ode_solve<TPW, NW>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt, a.rp, ph, b0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (ph == 0) vol0[i] = ell[i];
@@ -1000,6 +1026,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
     const double u = uniform01(split_at(kb[i], 4, 1), 0, 1);
     acc[i] = u <= ap;                     // NaN compares false -> reject
     aprob[i] = (float)ap;
+    if (a.rp.diag && wave == 0 && c == 0) { double* o = a.rp.diag + 4 * (size_t)b; o[0] = vol0[i]; o[1] = ell[i]; o[2] = lpn[i]; o[3] = la; }
   }
   __syncthreads();      // every wave has read the OLD log-densities before wave 0 publishes the accepted ones
 #pragma unroll

@@ -641,9 +641,10 @@ struct FTile {
 
 // Integrate the augmented ODE from t = 0 to 1 (see ode_solve in ode.hip: same state machine, same controller).
 // Requires: Z filled (probe), halo pads of X0 / X1 / Z zero, biases in LDS.
-template <int D>
+// RP: the parity-instrumentation instance (Replay, ode.hip); the production instance (RP = false) carries none of it.
+template <int D, bool RP>
 __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int max_attempts, float (&y)[FTile<D>::TPW][4],
-                                      float (&ell)[4], int (&natt)[4]) {
+                                      float (&ell)[4], int (&natt)[4], const Replay& rp, int rp_row0) {
   using S = FS<D>;
   constexpr int TPW = FTile<D>::TPW, LDX = S::LDX;
   const int g = T.g, c = T.c, wave = T.wave;
@@ -767,7 +768,8 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
         const float a2 = (sum8(S::DLP + 1 * 128) - R1(RS_KL + 0)) / atol;
         const float d2 = sqrtf(sum8(S::RED + 2 * 128) + a2 * a2) / h0;
         const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
-        const float dt = fminf(100.f * h0, h1);
+        float dt = fminf(100.f * h0, h1);
+        if constexpr (RP) { const size_t o = rp.at(0, rp_row0 + T.lane, 0); rp.dt_own[o] = dt; dt = rp.dt[o]; }
         R1(RS_DT) = dt;
         any = dt > 0.f ? 1 : 0;
       }
@@ -826,10 +828,20 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
         const float tol = atol + rtol * fmaxf(fabsf(ell0), fabsf(l1));
         const float rr = el / tol;
         const float ratio = sqrtf((e2 + rr * rr) * inv_n);
-        const bool acc = active && ratio <= 1.f;
+        bool acc = active && ratio <= 1.f;
         const float dfac = ratio < 1.f ? 1.f : 0.2f;
         const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
-        const float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+        float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+        if constexpr (RP) {
+          if (active) {
+            const int j = (int)na;
+            const bool in = j < rp.cap, nx = j + 1 < rp.cap;
+            const size_t o = rp.at(0, rp_row0 + T.lane, in ? j : 0);
+            if (in) { rp.ratio[o] = ratio; if (nx) rp.dt_own[o + 1] = ndt; }
+            acc = in && rp.acc[o] != 0;
+            ndt = nx ? rp.dt[o + 1] : 0.f;
+          }
+        }
         const float tn = t0 + dti;
         const bool fin = acc && tn >= 1.f, adv = acc && !(tn >= 1.f);
         const float sfrac = (1.f - t0) / (tn - t0);
@@ -894,7 +906,7 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
 // INIT1 with dt = h0 and unit stage coefficients in slot 0 (the extra evaluation at t0 + h0); their remaining slots are
 // ignored.  Per-row arithmetic (controller, interpolation, step sizes) is that of solve() bit for bit.
 // On return: y = proposal x' at t = 1 of the forward solve, row state holds ell (forward), vol0 (inverse), lq, counts.
-template <int D>
+template <int D, bool RP>
 __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const FlowArgs& f, int b0, float (&y)[FTile<D>::TPW][4]) {
   using S = FS<D>;
   constexpr int TPW = FTile<D>::TPW, LDX = S::LDX;
@@ -1054,7 +1066,8 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
         const float a2 = (dlsum(S::DLP + 1 * 128) - R1(RS_KL + 0)) / atol;
         const float d2 = sqrtf(sum8(S::RED + 2 * 128) + a2 * a2) / h0;
         const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
-        const float dt = fminf(100.f * h0, h1);
+        float dt = fminf(100.f * h0, h1);
+        if constexpr (RP) { const size_t o = a.rp.at((int)R1(RS_SOLVE), b0 + T.lane, 0); a.rp.dt_own[o] = dt; dt = a.rp.dt[o]; }
         R1(RS_DT) = dt; R1(RS_MODE) = (float)RM_ATT;
         flag = 0.f;
       } else if (mode == (float)RM_ATT) {
@@ -1077,10 +1090,20 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
         const float tol = atol + rtol * fmaxf(fabsf(ell0), fabsf(l1));
         const float rr = el / tol;
         const float ratio = sqrtf((e2 + rr * rr) * inv_n);
-        const bool acc = active && ratio <= 1.f;
+        bool acc = active && ratio <= 1.f;
         const float dfac = ratio < 1.f ? 1.f : 0.2f;
         const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
-        const float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+        float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+        if constexpr (RP) {
+          if (active) {
+            const int j = (int)na;
+            const bool in = j < a.rp.cap, nx = j + 1 < a.rp.cap;
+            const size_t o = a.rp.at((int)R1(RS_SOLVE), b0 + T.lane, in ? j : 0);
+            if (in) { a.rp.ratio[o] = ratio; if (nx) a.rp.dt_own[o + 1] = ndt; }
+            acc = in && a.rp.acc[o] != 0;
+            ndt = nx ? a.rp.dt[o + 1] : 0.f;
+          }
+        }
         const float tn = t0 + dti;
         const bool fin = acc && tn >= 1.f, adv = acc && !(tn >= 1.f);
         const float sfrac = (1.f - t0) / (tn - t0);
@@ -1205,7 +1228,7 @@ __device__ __forceinline__ void fill_probe(FTile<D>& T, const float* z, int b0) 
   }
 }
 
-template <int D>
+template <int D, bool RP>
 __global__ __launch_bounds__(NW * 64) void ode_transform_fast_kernel(OdeArgs a, f32x4* scratch) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TPW = FTile<D>::TPW;
@@ -1224,7 +1247,7 @@ __global__ __launch_bounds__(NW * 64) void ode_transform_fast_kernel(OdeArgs a, 
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[q][i] = a.in[(size_t)(b0 + 4 * T.g + i) * D + col];
     }
-    solve<D>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt);
+    solve<D, RP>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt, a.rp, b0);
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
       const int col = 16 * (T.wave + NW * q) + T.c;
@@ -1242,7 +1265,7 @@ __global__ __launch_bounds__(NW * 64) void ode_transform_fast_kernel(OdeArgs a, 
 }
 
 // One flow-based MH step per chain (random-walk in latent space :264-278, or independent :246-260), PhiFour target.
-template <int D>
+template <int D, bool RP>
 __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, FlowArgs f, NoiseArgs nz, f32x4* scratch) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using S = FS<D>;
@@ -1262,7 +1285,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
     for (int i = 0; i < 4; ++i) y[q][i] = f.pos[(size_t)(b0 + 4 * g + i) * D + col];                 // :267 / :251
   }
   fill_probe(T, a.z1, b0);               // key_hutch2: probe of the inverse solve (the forward probe is loaded per row)
-  solve2<D>(T, a, f, b0, y);             // inverse solve -> proposal -> forward solve, per row
+  solve2<D, RP>(T, a, f, b0, y);         // inverse solve -> proposal -> forward solve, per row
   {
     const f32x4 e4 = T.rs_get(RS_ELL), v4 = T.rs_get(RS_VOL0), l4 = T.rs_get(RS_LQ), n0 = T.rs_get(RS_NTOT), n1 = T.rs_get(RS_NATT);
 #pragma unroll
@@ -1318,6 +1341,9 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
     const double u = uniform01(split_at(kb, 4, 1), 0, 1);
     acc[i] = u <= ap;                     // NaN compares false -> reject
     aprob[i] = (float)ap;
+    if constexpr (RP) {
+      if (a.rp.diag && wave == 0 && c == 0) { double* o = a.rp.diag + 4 * (size_t)b; o[0] = vol0[i]; o[1] = ell[i]; o[2] = lpn[i]; o[3] = la; }
+    }
   }
   __syncthreads();      // every wave has read the OLD log-densities before wave 0 publishes the accepted ones
 #pragma unroll
@@ -1361,20 +1387,28 @@ static bool shape_ok(const NetDev& n, int hutch) {
 }
 static int max_wgs() { return ODE_FAST_MAX_WGS; }
 
+template <int D, bool RP>
+static int launch_flow_tr(const OdeArgs& a, const FlowArgs& f, const NoiseArgs& nz, f32x4* scratch, hipStream_t stream) {
+  const size_t sm = (size_t)FS<D>::TOTAL * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)flow_step_fast_kernel<D, RP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL((flow_step_fast_kernel<D, RP>), dim3(a.n / 16), dim3(NW * 64), sm, stream, a, f, nz, scratch);
+  return 0;
+}
 template <int D>
 static int launch_flow_t(const OdeArgs& a, const FlowArgs& f, const NoiseArgs& nz, f32x4* scratch, hipStream_t stream) {
+  return a.rp.dt ? launch_flow_tr<D, true>(a, f, nz, scratch, stream) : launch_flow_tr<D, false>(a, f, nz, scratch, stream);
+}
+template <int D, bool RP>
+static int launch_transform_tr(const OdeArgs& a, f32x4* scratch, hipStream_t stream) {
   const size_t sm = (size_t)FS<D>::TOTAL * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)flow_step_fast_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL((flow_step_fast_kernel<D>), dim3(a.n / 16), dim3(NW * 64), sm, stream, a, f, nz, scratch);
+  (void)hipFuncSetAttribute((const void*)ode_transform_fast_kernel<D, RP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  const int tiles = a.n / 16, grid = tiles < max_wgs() ? tiles : max_wgs();
+  hipLaunchKernelGGL((ode_transform_fast_kernel<D, RP>), dim3(grid), dim3(NW * 64), sm, stream, a, scratch);
   return 0;
 }
 template <int D>
 static int launch_transform_t(const OdeArgs& a, f32x4* scratch, hipStream_t stream) {
-  const size_t sm = (size_t)FS<D>::TOTAL * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)ode_transform_fast_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  const int tiles = a.n / 16, grid = tiles < max_wgs() ? tiles : max_wgs();
-  hipLaunchKernelGGL((ode_transform_fast_kernel<D>), dim3(grid), dim3(NW * 64), sm, stream, a, scratch);
-  return 0;
+  return a.rp.dt ? launch_transform_tr<D, true>(a, scratch, stream) : launch_transform_tr<D, false>(a, scratch, stream);
 }
 
 }  // namespace fast

@@ -236,6 +236,11 @@ void launch_adamw(const AdamArgs& a, hipStream_t stream) {
   // widths: 8.65 M parameters) for the elementwise pass itself to need the whole chip
   const int cap = n > (1 << 21) ? 2048 : 256;
   dim3 grid(nb < cap ? nb : cap), block(256);
+  if (!a.inline_decide) {
+    // flag[0] may still hold the verdict of an earlier mfm_fm_loss_grad whose gradient was never applied (another buffer was
+    // passed here): the check below must start from a clean flag
+    (void)hipMemsetAsync(a.flag, 0, sizeof(int), stream);
+  }
   if (!a.inline_decide)
     hipLaunchKernelGGL(finite_decide_kernel, grid, block, 0, stream, a.grads, a.n_slabs, n, a.st, a.flag, a.lr0, a.learning_iter, a.warmup, a.max_err);
   bool vec = true;

@@ -88,6 +88,33 @@ __global__ __launch_bounds__(SMC_THREADS) void smc_resample_kernel(Key2 key, con
   }
 }
 
+// jax.random.choice(key, n, (m,), replace=True, p = exp(logw - max logw)) -- the self-normalised importance resampling of the
+// final flow samples (exe_flow_matching.py:458-459).  jax: p_cuml = cumsum(p); r = p_cuml[-1] * (1 - uniform(key, (m,)));
+// searchsorted(p_cuml, r) (side = 'left').  Sequential cumulative sum for the same reason as above.
+__global__ __launch_bounds__(SMC_THREADS) void choice_logw_kernel(Key2 key, const double* logw, int n, int m, double* cum, int* idx) {
+  __shared__ double sm[SMC_THREADS / 64];
+  double mx = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += SMC_THREADS) mx = fmax(mx, logw[i]);          // jnp.max: a NaN weight poisons the draw there too
+  mx = smc_block_reduce(mx, sm, true);
+  for (int i = threadIdx.x; i < n; i += SMC_THREADS) cum[i] = exp(logw[i] - mx);      // :458
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double c = 0.0;
+    for (int i = 0; i < n; ++i) { c += cum[i]; cum[i] = c; }
+  }
+  __syncthreads();
+  const double tot = cum[n - 1];
+  for (int j = threadIdx.x; j < m; j += SMC_THREADS) {
+    const double r = tot * (1.0 - uniform01(key, (uint32_t)j, (uint32_t)m));
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cum[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    idx[j] = lo < n - 1 ? lo : n - 1;
+  }
+}
+
 // sum and sum of squares (float64) of a per-chain float32 quantity: the acceptance statistics logged every iteration
 // (exe_flow_matching.py:442-443) without a handful of framework launches per iteration
 __global__ __launch_bounds__(SMC_THREADS) void acc_stats_kernel(const float* x, int n, double* out) {

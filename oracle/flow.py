@@ -28,22 +28,25 @@ def _accept(keys_acc, a, prev, prop):
     return state, info
 
 
-def rwmh_step(keys, prev, value_and_grad, model, params, args, stats=None):
-    """``exe_flow_matching.py:264-278``."""
+def rwmh_step(keys, prev, value_and_grad, model, params, args, stats=None, replay=None):
+    """``exe_flow_matching.py:264-278``.  ``replay = dict(inv=..., fwd=...)``: prescribed step sequences of the two
+    solves (parity instrumentation, see ``ode.odeint``)."""
     B, d = prev.position.shape
     kk = prng.split_rows(keys, 4)                      # :265 key_gen, key_acc, key_hutch1, key_hutch2
     o = dict(hutch=args.hutchs, rtol=args.rtol, atol=args.atol, mxstep=args.mxstep, n_ts=args.n_ts)
     st_inv = {} if stats is not None else None
     st_fwd = {} if stats is not None else None
-    u0, vol0 = ode.inverse_and_logdet(model, params, kk[:, 3], prev.position, stats=st_inv, **o)   # :267
+    rp = replay or {}
+    u0, vol0 = ode.inverse_and_logdet(model, params, kk[:, 3], prev.position, stats=st_inv, replay=rp.get("inv"), **o)   # :267
     up = u0 + (2.38 / np.sqrt(d)) * prng.normal_rows(kk[:, 0], d)                                  # :262,268
-    xp, volp = ode.transform_and_logdet(model, params, kk[:, 2], up, stats=st_fwd, **o)            # :269
+    xp, volp = ode.transform_and_logdet(model, params, kk[:, 2], up, stats=st_fwd, replay=rp.get("fwd"), **o)            # :269
     lpn, gn = value_and_grad(xp)                                                                    # :270
     with np.errstate(over="ignore", invalid="ignore"):
         a = np.exp(lpn - volp - prev.logdensity - vol0)                                            # :271-274
     if stats is not None:
         stats["n_att_inv"], stats["n_att_fwd"] = st_inv["n_attempted"], st_fwd["n_attempted"]
         stats["u0"], stats["vol0"], stats["up"], stats["volp"] = u0, vol0, up, volp
+        stats["inv"], stats["fwd"], stats["log_alpha"] = st_inv, st_fwd, lpn - volp - prev.logdensity - vol0
     return _accept(kk[:, 1], a, prev, (xp, lpn, gn))                                               # :275-278
 
 

@@ -91,17 +91,37 @@ def optimal_step_size(last_step, ratio, safety=0.9, ifactor=10.0, dfactor=0.2, o
     return np.where(ratio == 0, last_step * ifactor, last_step * factor)
 
 
-def odeint(fun, y0, ts, rtol, atol, mxstep, stats=None):
-    """Batched: y0 [B, n]; ``fun(y [B, n], t [B]) -> [B, n]``.  Returns ``[len(ts), B, n]``."""
+def odeint(fun, y0, ts, rtol, atol, mxstep, stats=None, replay=None):
+    """Batched: y0 [B, n]; ``fun(y [B, n], t [B]) -> [B, n]``.  Returns ``[len(ts), B, n]``.
+
+    ``stats`` (optional dict) receives the attempted-step counts and, per chain, the whole step sequence:
+    ``dt_seq [B, A + 1]`` (``[:, j]`` = step size of attempt j, ``[:, 0]`` the initial step; zero past a chain's
+    last attempt), ``acc_seq [B, A]`` (accepted?), ``ratio_seq [B, A]`` (error ratio of attempt j) and
+    ``dt_own [B, A + 1]`` (the step sizes the controller itself chose: equal to ``dt_seq`` without ``replay``).
+
+    ``replay = dict(dt=[B, >= A + 1], acc=[B, >= A])`` is PARITY INSTRUMENTATION (no counterpart in the reference):
+    the solve takes the prescribed step sizes and accept decisions instead of its controller's (which is still
+    evaluated and recorded), so two implementations can be compared stage for stage on the SAME step sequence
+    instead of through the chaotic float32-vs-float64 controller decisions (tests/test_gpu_replay.py)."""
     B = y0.shape[0]
     t = np.full(B, float(ts[0]))
     f = fun(y0, t)
     dt = np.clip(initial_step_size(fun, t, y0, 4, rtol, atol, f), 0.0, np.inf)
+    rec = stats is not None
+    dt_seq, acc_seq, ratio_seq, dt_own, act_seq = [], [], [], [], []
+    if rec:
+        dt_own.append(dt.copy())
+    if replay is not None:
+        rp_dt, rp_acc = np.asarray(replay["dt"], dtype=np.float64), np.asarray(replay["acc"]).astype(bool)
+        dt = rp_dt[:, 0].copy()
+    if rec:
+        dt_seq.append(dt.copy())
     y, last_t = y0.copy(), t.copy()
     coeff = [y0.copy() for _ in range(5)]
     outs = [y0]
     n_att = np.zeros(B, dtype=np.int64)
     n_evals = 2
+    rows = np.arange(B)
     for target in ts[1:]:
         i = np.zeros(B, dtype=np.int64)
         while True:
@@ -116,6 +136,14 @@ def odeint(fun, y0, ts, rtol, atol, mxstep, stats=None):
             ncoeff = interp_fit_dopri(y, ny, k, dt)
             ndt = np.clip(optimal_step_size(dt, ratio), 0.0, np.inf)
             acc = active & (ratio <= 1.0)
+            if rec:
+                act_seq.append(active.copy()); ratio_seq.append(ratio.copy()); dt_own.append(ndt.copy())
+            if replay is not None:
+                j = np.minimum(n_att, rp_acc.shape[1] - 1)
+                acc = active & rp_acc[rows, j]
+                ndt = rp_dt[rows, np.minimum(n_att + 1, rp_dt.shape[1] - 1)]
+            if rec:
+                acc_seq.append(acc.copy())
             m = acc[:, None]
             coeff = [np.where(m, nc, c) for nc, c in zip(ncoeff, coeff)]
             last_t = np.where(acc, t, last_t)
@@ -125,6 +153,8 @@ def odeint(fun, y0, ts, rtol, atol, mxstep, stats=None):
             dt = np.where(active, ndt, dt)
             i = i + active
             n_att += active
+            if rec:
+                dt_seq.append(np.where(active & (t < ts[-1]), dt, 0.0))        # zero once the chain has reached the end
         with np.errstate(divide="ignore", invalid="ignore"):
             s = ((target - last_t) / (t - last_t))[:, None]
         a, b, c, d_, e = coeff
@@ -132,7 +162,32 @@ def odeint(fun, y0, ts, rtol, atol, mxstep, stats=None):
     if stats is not None:
         stats["n_attempted"] = n_att
         stats["n_evals"] = n_evals
+        # the lock-step loop records one column per ROUND; a chain's attempt j is its j-th ACTIVE round: compress
+        e = np.zeros((B, 0))
+        stats.update(_compress_rounds(np.stack(dt_seq, 1), np.stack(acc_seq, 1) if acc_seq else e.astype(bool),
+                                      np.stack(ratio_seq, 1) if ratio_seq else e, np.stack(dt_own, 1),
+                                      np.stack(act_seq, 1) if act_seq else e.astype(bool), n_att))
     return np.stack(outs)
+
+
+def _compress_rounds(dt_seq, acc_seq, ratio_seq, dt_own, act_seq, n_att):
+    """Per chain, keep only the rounds of the lock-step loop in which it was active (a chain idles while slower ones
+    still integrate, and with several output times between reaching one target and the round the slowest reaches
+    it): a chain's attempt j is its j-th ACTIVE round."""
+    B = dt_seq.shape[0]
+    amax = int(n_att.max()) if B else 0
+    out = dict(dt_seq=np.zeros((B, amax + 1)), acc_seq=np.zeros((B, amax), bool), ratio_seq=np.zeros((B, amax)),
+               dt_own=np.zeros((B, amax + 1)))
+    out["dt_seq"][:, 0], out["dt_own"][:, 0] = dt_seq[:, 0], dt_own[:, 0]
+    for b in range(B):
+        idx = np.flatnonzero(act_seq[b])
+        n = len(idx)
+        assert n == n_att[b]
+        out["acc_seq"][b, :n] = acc_seq[b, idx]
+        out["ratio_seq"][b, :n] = ratio_seq[b, idx]
+        out["dt_own"][b, 1:n + 1] = dt_own[b, 1 + idx]
+        out["dt_seq"][b, 1:n + 1] = dt_seq[b, 1 + idx]
+    return out
 
 
 def _augmented(model, params, z, hutch, sign):
@@ -155,24 +210,24 @@ def _augmented(model, params, z, hutch, sign):
 
 
 def transform_and_logdet(model, params, keys, ref_sample, hutch, rtol, atol, mxstep, n_ts=2,
-                         stats=None, z=None):
+                         stats=None, z=None, replay=None):
     """``exe_flow_matching.py:206-221``; ``keys`` [B, 2] (one Hutchinson key per chain) or one key."""
     B, d = ref_sample.shape
     if hutch and z is None:
         keys = np.asarray(keys)
         z = prng.normal_rows(keys, d) if keys.ndim == 2 else np.broadcast_to(prng.normal(keys, (d,)), (B, d))
     y0 = np.concatenate([ref_sample, np.zeros((B, 1))], axis=1)             # :220
-    ys = odeint(_augmented(model, params, z, hutch, +1), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats)
+    ys = odeint(_augmented(model, params, z, hutch, +1), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats, replay)
     return ys[-1][:, :d], ys[-1][:, d]                                      # :221
 
 
 def inverse_and_logdet(model, params, keys, target_sample, hutch, rtol, atol, mxstep, n_ts=2,
-                       stats=None, z=None):
+                       stats=None, z=None, replay=None):
     """``exe_flow_matching.py:223-242``."""
     B, d = target_sample.shape
     if hutch and z is None:
         keys = np.asarray(keys)
         z = prng.normal_rows(keys, d) if keys.ndim == 2 else np.broadcast_to(prng.normal(keys, (d,)), (B, d))
     y0 = np.concatenate([target_sample, np.zeros((B, 1))], axis=1)          # :241
-    ys = odeint(_augmented(model, params, z, hutch, -1), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats)
+    ys = odeint(_augmented(model, params, z, hutch, -1), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats, replay)
     return ys[-1][:, :d], ys[-1][:, d]                                      # :242

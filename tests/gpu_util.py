@@ -90,3 +90,44 @@ def lgcp_setup(n=8, B=32, seed=1, hidden=32, F=16, hutch=True, **kw):
     dist = targets.LogGaussianCoxPines(d, counts)
     k, model, state, lr_fn, _, _ = loop.setup(dist, args)
     return args, dist, k, model, state
+
+
+def train_phi4_like_bench(n_iter=101, chains=4096, d=256, seed=1):
+    """The state bench.py's timed region starts from: phi-four d = 256, `chains` chains, K = 100, --hutch, beta = 1, the
+    flax-style initial network trained for `n_iter` iterations of the product's loop (101 = one full cycle incl. its flow step).
+    Returns the oracle-side objects for the same configuration plus the trained parameters and the chain positions."""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mfm_amd import exe_flow_matching as E, random as jr
+    from mfm_amd._lib import FLOW_RWMH
+    from mfm_amd.distributions import PhiFour
+    from mfm_amd.engine import Engine
+    args = bench.make_args(chains, learning_iter=10000)
+    args.dim = d
+    dist = PhiFour(d)
+    key_target, key_sample, key_init, key_dist, key_fourier, key_gen = jr.split(jr.PRNGKey(seed), 6)
+    dist.initialize_model(key_dist, chains)
+    fourier = args.fourier_std * jr.normal(key_fourier, (args.fourier_dim,))
+    eng = Engine(dist, args, fourier)
+    model = E.VectorFieldNet(fourier, dist.grad_logprob, args.hidden_x, args.hidden_t, args.hidden_xt).attach(eng)
+    eng.ctx.set_params(E.flatten_params(model.init(key_init)))
+    pos = eng.local(dist.init_params)
+    logp = torch.empty(chains, device=eng.dev, dtype=torch.float64); grad = torch.empty_like(pos)
+    acc = torch.empty(chains, device=eng.dev, dtype=torch.float32); nst = torch.zeros(chains, device=eng.dev, dtype=torch.int32)
+    eng.ctx.mala_init(pos, 1.0, logp, grad)
+    ks = key_sample
+    for count in range(1, n_iter + 1):
+        ks, k_gn, k_step = jr.split(ks, 3)
+        eng.train_iter(count, 100, FLOW_RWMH, k_gn, k_step, 1.0, args.step_size, pos, logp, grad, acc=acc, nsteps=nst)
+    eng.ctx.sync()
+    out = dict(params_flat=eng.ctx.get_params(), pos=pos.cpu().numpy(), fourier=np.asarray(fourier, dtype=np.float64),
+               n_att_last_flow=nst.cpu().numpy().copy(), counters=eng.ctx.counters())
+    eng.close()
+    o_dist = targets.PhiFour(d)
+    oargs = loop.default_args(example="phi-four", dim=d, num_chain=32, hutchs=True, step_size=1e-4, seed=seed, mcmc_per_flow_steps=100.0)
+    out["dist"] = o_dist
+    out["args32"] = oargs
+    out["model"] = VectorFieldNet(out["fourier"], o_dist, oargs.hidden_x, oargs.hidden_t, oargs.hidden_xt, "relu", oargs.gradient_clip)
+    return out
