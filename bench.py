@@ -14,7 +14,12 @@ next) trains it so the timed flow steps integrate a non-trivial field.
 K should be a multiple of the 101-iteration cycle (default 1010 = ten cycles: 10 flow steps + 1000 MALA iterations, the mix the
 metric is defined on); other values are timed as asked, and "flow_steps_timed" in the output says what the window held.
 
-Prints ONE JSON line (rank 0).  value = (chains over all GPUs) * K / (max-over-ranks wall time of the K steps).
+`python bench.py --gpus N` launched bare starts the N ranks itself (a child `torch.distributed.run`, before this process touches
+the GPU) and relays rank 0's line.  `--workload` selects another BASELINE config (default: the metric's own, phi-four).
+
+Prints ONE JSON line (rank 0).  value = (chains over all GPUs) * K / (max-over-ranks wall time of the K steps);
+config.cycle_weighted_value = the same run's per-iteration and per-flow-step times composed into one full (K + 1)-iteration cycle
+(what `value` converges to when --steps is a multiple of the cycle).
 "roofline": the kernel with the largest share of GPU time in the timed region (HIP events recorded by the library on
 its stream, mfm_profile); "cpu_baseline": the float64 numpy oracle (a port of the reference semantics, NOT JAX/XLA)
 timed on this host on a bounded sample of the same workload.
@@ -35,16 +40,19 @@ PEAK_HBM_GBS = 8000.0
 WORKLOADS = {   # name: (example, dim, hidden width, MALA step size, chains per GPU, K)
     "phi-four": ("phi-four", 256, 128, 1e-4, 4096, 100),       # BASELINE configs[2] (the headline; configs[3] = 8 x this)
     "pines": ("pines", 1024, 1024, 1e-2, 1024, 100),            # BASELINE configs[4]: 8192 chains over 8 GPUs
+    "gaussian-mixture": ("gaussian-mixture", 2, 128, 0.2, 4096, 100),   # BASELINE configs[1]: 16 modes, exact trace, eval_step on 409,600 samples
+    "4-mode": ("4-mode", 2, 128, 0.2, 512, 10),                 # BASELINE configs[0]: the reference's own CPU-runnable case (51,200 eval samples)
 }
+D2 = ("gaussian-mixture", "4-mode")      # the d = 2 mixtures: no --hutch (exact trace), eval_step every iteration (exe_flow_matching.py:444-446)
 
 
 def make_args(n_total, learning_iter, workload="phi-four"):
     from types import SimpleNamespace
     ex, dim, h, eps, _, K = WORKLOADS[workload]
     return SimpleNamespace(
-        example=ex, dim=dim, num_chain=n_total, seed=1, sigma=1e-4, fourier_dim=128, fourier_std=1.0, hutchs=True,
+        example=ex, dim=dim, num_chain=n_total, seed=1, sigma=1e-4, fourier_dim=128, fourier_std=1.0, hutchs=workload not in D2,
         ref_dist="stdgauss", cond_flow=True, ot_cond_flow=False, num_importance_samples=0, mcmc_per_flow_steps=float(K),
-        learning_iter=learning_iter, eval_iter=1, alpha=0.95, anneal_iter=200, num_anneal_temp=200, non_linearity="relu",
+        learning_iter=learning_iter, eval_iter=100 if workload in D2 else 1, alpha=0.95, anneal_iter=200, num_anneal_temp=200, non_linearity="relu",
         hidden_x=[h, h], hidden_t=[h, h], hidden_xt=[h, h], step_size=eps, learning_rate=1e-3,
         weight_decay=1e-4, adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8, gradient_clip=1.0, warmup_steps=0,
         rtol=1e-5, atol=1e-5, mxstep=1000.0)
@@ -98,6 +106,52 @@ def cpu_baseline(params_flat, fourier, steps_mala, chains, seed=1):
                 n_att=float(stats["n_att_inv"].mean() + stats["n_att_fwd"].mean()))
 
 
+def cpu_baseline_d2(workload, params_flat, fourier, chains, n_eval, K, seed=1):
+    """Oracle on a bounded sample of a d = 2 mixture iteration (MALA or exact-trace flow step + train step + eval_step on the
+    n_eval exact samples): the MALA + train part on all `chains`, eval_step on n_eval / 25 samples (x 25), the flow step on 128
+    chains (x chains / 128), composed into one (K + 1)-iteration cycle."""
+    import numpy as np
+    from oracle import flow, fm, loop, mala, optim, prng, targets
+    from oracle.vfield import VectorFieldNet
+    from tests import gpu_util as gu
+    if workload == "gaussian-mixture":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "gmm16_params.npz"))
+        dist = targets.GaussianMixture(g["modes"], g["covs"], g["weights"])
+    else:
+        dist = targets.GaussianMixture(8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4)
+    args = loop.default_args(example=workload, dim=2, num_chain=chains, hutchs=False, step_size=0.2, seed=seed, mcmc_per_flow_steps=float(K), learning_iter=10000)
+    dist.initialize_model(prng.PRNGKey(seed), chains)
+    model = VectorFieldNet(fourier, dist, args.hidden_x, args.hidden_t, args.hidden_xt, "relu", None)
+    params = gu.unflat_params(model, params_flat)
+    state = optim.TrainState(params, optim.learning_rate_fn(10000, 0, 1e-3))
+    vg = targets.Tempered(dist, 1.0).value_and_grad
+    st = mala.init(dist.init_params, vg)
+    key = prng.PRNGKey(seed + 1)
+    n_ev = max(1024, n_eval // 25)
+    real = dist.sample_model_rows(prng.split(prng.PRNGKey(seed + 2), n_ev))
+    t0 = time.perf_counter()
+    for _ in range(2):
+        key, k1, k2 = prng.split(key, 3)
+        st, _, _ = mala.kernel(prng.split(k1, chains), st, vg, args.step_size)
+        loss, grads = fm.loss_and_grad(model, state.params, k2, st.position, args.sigma)
+        state.apply_gradients(grads)
+    t_mala = (time.perf_counter() - t0) / 2
+    t0 = time.perf_counter()
+    fm.loss_and_grad(model, state.params, key, real, args.sigma, need_grad=False)
+    t_eval = (time.perf_counter() - t0) * n_eval / n_ev
+    nf = min(128, chains)
+    sub = mala.MALAState(st.position[:nf], st.logdensity[:nf], st.logdensity_grad[:nf])
+    stats = {}
+    t0 = time.perf_counter()
+    flow.rwmh_step(prng.split(key, nf), sub, vg, model, state.params, args, stats)
+    t_flow = (time.perf_counter() - t0) * chains / nf
+    cycle = K * t_mala + (t_flow + t_mala) + (K + 1) * t_eval
+    return dict(value=chains * (K + 1) / cycle,
+                sample=f"{chains} chains: 2 MALA+train iterations ({t_mala:.3f}s each), eval_step on {n_ev} of {n_eval} samples (scaled: {t_eval:.3f}s), one exact-trace "
+                       f"flow-MH step on {nf} chains (scaled: {t_flow:.3f}s, mean {float(stats['n_att_inv'].mean() + stats['n_att_fwd'].mean()):.1f} Dopri5 attempts); "
+                       f"composed into a {K + 1}-iteration cycle; float64 numpy oracle")
+
+
 def usable_cores():
     """Host threads this process may actually use: CPU affinity capped by the cgroup CPU quota (a GPU box hands a job a share
     of its cores), not the machine's core count."""
@@ -126,14 +180,14 @@ def pmc_traffic(kernel_class):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc passes of this
     same command, tools/prof_round.sh): 2 * FETCH_SIZE + WRITE_SIZE, both reported in KB; the factor 2 is the gfx950
     correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section).  None when no summary is present."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    try:
-        d = json.load(open(path))
-    except Exception:
-        return None, None
-    for name, c in d.items():
-        if kernel_class in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return int((2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024), "profiles/r01_pmc_summary.json"
+    for rel in ("profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"):       # newest committed summary first
+        try:
+            d = json.load(open(os.path.join(ROOT, rel)))
+        except Exception:
+            continue
+        for name, c in d.items():
+            if kernel_class in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return int((2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024), rel
     return None, None
 
 
@@ -149,28 +203,40 @@ def main():
                                                              # of the 100 iterations after it, noise.hip: produced and used inside)
     ap.add_argument("--chains-per-gpu", type=int, default=0)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="phi-four",
-                    help="phi-four: BASELINE configs[2] (the metric's configuration, default); pines: configs[4] per-GPU shape")
+                    help="phi-four: BASELINE configs[2] (the metric's configuration, default); pines: configs[4] per-GPU shape; "
+                         "gaussian-mixture / 4-mode: the d = 2 mixtures of configs[1] / configs[0] (exact trace + eval_step every iteration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
-    import numpy as np
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        sys.exit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+        # launched bare (`python bench.py --gpus N`): start one rank per GPU as a CHILD torch.distributed.run job -- before this
+        # process has touched the GPU (nothing above imports torch), never by re-exec -- relay its output and exit with its code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    import numpy as np
+    import torch
     # MFM_BENCH_SHARE_GPU=1 + MFM_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a ONE-GPU box (all ranks on device 0,
     # gloo instead of RCCL, which refuses two ranks on one device); never used by the driver's runs
     torch.cuda.set_device(0 if os.environ.get("MFM_BENCH_SHARE_GPU") else local_rank)
     td = None
+    backend = None
     if world > 1:
         import torch.distributed as td
-        td.init_process_group(os.environ.get("MFM_BENCH_BACKEND", "nccl"))           # "nccl" = RCCL on ROCm
+        backend = os.environ.get("MFM_BENCH_BACKEND", "nccl")                         # "nccl" = RCCL on ROCm
+        td.init_process_group(backend)
 
     from mfm_amd import exe_flow_matching as E, random as jr
     from mfm_amd._lib import FLOW_RWMH
-    from mfm_amd.distributions import LogGaussianCoxPines, PhiFour
+    from mfm_amd.distributions import GaussianMixture, LogGaussianCoxPines, PhiFour
     from mfm_amd.engine import Engine
 
     wl_example, wl_dim, wl_h, _, wl_chains, wl_K = WORKLOADS[a.workload]
@@ -178,13 +244,32 @@ def main():
         a.chains_per_gpu = wl_chains
     if a.workload == "pines" and a.steps == 1010 and a.warmup == 201:     # three cycles at this size
         a.steps, a.warmup = 303, 100
+    if a.workload == "4-mode" and a.steps == 1010 and a.warmup == 201:    # K = 10: twenty 11-iteration cycles after two
+        a.steps, a.warmup = 220, 22
     n_total = a.chains_per_gpu * world            # weak scaling: per-GPU work fixed
     args = make_args(n_total, learning_iter=10000, workload=a.workload)
-    dist = PhiFour(wl_dim) if a.workload == "phi-four" else LogGaussianCoxPines(wl_dim)
+    d2 = a.workload in D2
+    if a.workload == "phi-four":
+        dist = PhiFour(wl_dim)
+    elif a.workload == "pines":
+        dist = LogGaussianCoxPines(wl_dim)
+    elif a.workload == "gaussian-mixture":                  # multi_modal.py:39-47 (parameters: tests/golden/gmm16_params.npz)
+        from mfm_amd.multi_modal import gmm16_parameters
+        dist = GaussianMixture(*gmm16_parameters())
+    else:                                                   # multi_modal.py:79-85
+        dist = GaussianMixture(8. * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1]]), np.ones((4, 2)), np.ones(4) / 4)
     key_target, key_sample, key_init, key_dist, key_fourier, key_gen = jr.split(jr.PRNGKey(args.seed), 6)
     dist.initialize_model(key_dist, n_total)
     fourier = args.fourier_std * jr.normal(key_fourier, (args.fourier_dim,))
-    eng = Engine(dist, args, fourier)
+    n_eval = args.eval_iter * n_total if d2 else 0         # eval_step's batch (exe_flow_matching.py:370-374): eval_iter * num_chain
+    eng = Engine(dist, args, fourier, max_eval_samples=n_eval // world)
+    real_samples = key_loss = eval_out = None
+    if d2:
+        key_gen_t, key_loss = jr.split(key_target)          # :371
+        lo = eng.rank * (n_eval // world)
+        rows = dist.sample_rows(jr.split(key_gen_t, n_eval)[lo:lo + n_eval // world])       # :372-373, this rank's slice
+        real_samples = torch.as_tensor(np.ascontiguousarray(rows, dtype=np.float32), device=eng.dev)
+        eval_out = torch.zeros(1, device=eng.dev, dtype=torch.float64)
     model = E.VectorFieldNet(fourier, dist.grad_logprob, args.hidden_x, args.hidden_t, args.hidden_xt).attach(eng)
     eng.ctx.set_params(E.flatten_params(model.init(key_init)))
     ctx = eng.ctx
@@ -221,6 +306,8 @@ def main():
             ctx.noise_prefetch(keys[i + 1:i + 1 + wl_K, 0], keys[i + 1:i + 1 + wl_K, 1])
         # generator (:300-314) + loss/grad + [all-reduce] + AdamW (:362-368): mfm_train_iter on one rank
         eng.train_iter(count, wl_K, FLOW_RWMH, keys[i, 0], keys[i, 1], beta, args.step_size, pos, logp, grad, acc=acc, nsteps=nst)
+        if d2:                                               # eval_step (:370-374, :444-446): same key, same exact samples, every iteration
+            eng.eval_loss(key_loss, real_samples, eval_out, n_total=n_eval, offset=eng.rank * (n_eval // world))
         if flow:
             natt_sum.add_(nst.double().sum()); n_flow[0] += 1
 
@@ -252,8 +339,8 @@ def main():
     # HIP events on the library's stream around every launch of the DOMINANT kernel class only: an event pair per launch of
     # every class costs ~38 us of stream time per iteration (measured: 0.911 -> 0.872 ms/step), which would be charged to
     # `value`.  The other classes are timed in a separate instrumented pass after the timed region.
-    dom_cls = "flow_step" if a.workload == "phi-four" else "fm_fwd_bwd"
-    ctx.profile(True, classes=[dom_cls])
+    dom_cls = {"phi-four": "flow_step", "pines": "fm_fwd_bwd"}.get(a.workload, "fm_eval")
+    ctx.profile(True, classes=sorted({dom_cls, "flow_step"}))      # + the flow step (one launch in K + 1): cycle_weighted_value
     t0 = time.perf_counter()
     for i in range(untimed, total):
         count += 1
@@ -282,7 +369,11 @@ def main():
         alg = {  # algorithmic FLOPs per launch
             "fm_fwd_bwd": B * fl["fm_fwd_bwd"], "wgrad": B * fl["wgrad"],
             "flow_step": B * (4 + 6 * natt_mean) * fl["field_eval"],
+            "fm_eval": (n_eval // world) * fl["fwd"],        # eval_step: forward only on eval_iter * num_chain exact samples (2 P_w each)
         }
+        if d2:                                               # exact trace: d tangent passes per field evaluation (:216-217)
+            P_x = 2 * wl_dim * wl_h + 3 * wl_h * wl_h
+            alg["flow_step"] = B * (4 + 6 * natt_mean) * (fl["fwd"] + wl_dim * 2 * P_x)
         if a.workload == "pines":
             alg["fm_fwd_bwd"] += B * fl["wgrad"]          # the wide family's class 1 covers forward, data and weight gradients
         dom = max((k for k in prof if k in alg and prof[k]["launches"]), key=lambda k: prof[k]["ms"], default=None)
@@ -298,31 +389,57 @@ def main():
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(avg_ms, 5), "algorithmic_flop_per_launch": alg[dom]}
+        desc = {
+            "phi-four": ("phi-four d=256, 4096 chains per GPU", "phi-four d=256, 4096 chains/GPU, mcmc_per_flow_steps=100, --hutch, beta=1 (BASELINE configs[2])"),
+            "pines": ("pines d=1024, 1024 chains per GPU", f"pines LGCP d={wl_dim} (32x32), hidden {wl_h}, {a.chains_per_gpu} chains/GPU, mcmc_per_flow_steps=100, --hutch, "
+                      "beta=1 (BASELINE configs[4] per-GPU shape; wide kernel family)"),
+            "gaussian-mixture": ("gaussian-mixture d=2, 4096 chains per GPU", f"gaussian-mixture (16 modes, d=2), {a.chains_per_gpu} chains/GPU, mcmc_per_flow_steps=100, exact trace, "
+                                 f"eval_step on {n_eval} exact samples every iteration, beta=1 (BASELINE configs[1])"),
+            "4-mode": ("4-mode d=2, 512 chains per GPU", f"4-mode mixture (d=2), {a.chains_per_gpu} chains/GPU, mcmc_per_flow_steps=10, exact trace, eval_step on {n_eval} exact "
+                       "samples every iteration, beta=1 (BASELINE configs[0], the reference's CPU-runnable case)"),
+        }[a.workload]
+        # The metric is defined on the (K + 1)-iteration cycle (one flow step + K MALA iterations).  A --steps that is not a
+        # multiple of the cycle over-represents the flow step (the window starts with one), so besides `value` -- the K timed
+        # steps as asked -- the same run's numbers are also composed into one full cycle: every iteration's non-flow part
+        # (MALA kernel on K of them, training step, eval) at its average inside the timed region + one average flow-step launch.
+        flow_ms = prof.get("flow_step", {"ms": 0.0, "launches": 0})
+        cw = None
+        if flow_ms["launches"]:
+            t_rest = (dt * 1e3 - flow_ms["ms"]) / a.steps
+            cycle_ms = (wl_K + 1) * t_rest + flow_ms["ms"] / flow_ms["launches"]
+            cw = {"cycle_weighted_value": round(n_total * (wl_K + 1) / (cycle_ms * 1e-3), 1), "cycle_ms": round(cycle_ms, 4),
+                  "iteration_ms_excluding_flow_kernel": round(t_rest, 5), "flow_step_avg_ms": round(flow_ms["ms"] / flow_ms["launches"], 4)}
+        par = "single GPU" if world == 1 else (f"chains sharded x{world}, one gradient all-reduce(SUM) per iteration over torch.distributed backend "
+                                               f"'{backend}'" + (" (RCCL over xGMI)" if backend == "nccl" else " (rehearsal backend, NOT RCCL)"))
         out = {
-            "metric": "MFM train-steps/s x chains (phi-four d=256, 4096 chains per GPU)" if a.workload == "phi-four" else "MFM train-steps/s x chains (pines d=1024, 1024 chains per GPU)", "value": round(value, 1),
+            "metric": f"MFM train-steps/s x chains ({desc[0]})", "value": round(value, 1),
             "unit": "chain-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("phi-four d=256, 4096 chains/GPU, mcmc_per_flow_steps=100, --hutch, beta=1 (BASELINE configs[2])" if a.workload == "phi-four" else
-                                    f"pines LGCP d={wl_dim} (32x32), hidden {wl_h}, {a.chains_per_gpu} chains/GPU, mcmc_per_flow_steps=100, --hutch, beta=1 (BASELINE configs[4] per-GPU shape; wide kernel family)"),
-                       "chains_total": n_total, "chains_per_gpu": B, "parallelism": f"chains sharded x{world}, RCCL grad all-reduce" if world > 1 else "single GPU",
+            "config": {"workload": desc[1],
+                       "chains_total": n_total, "chains_per_gpu": B, "parallelism": par,
                        "state_prep_iterations": prep, "flow_steps_timed": n_flow[0], "dopri_attempts_per_chain_per_flow_step": round(natt_mean, 2),
-                       "chain_dim_updates_per_s": round(value * wl_dim, 1)},
+                       "chain_dim_updates_per_s": round(value * wl_dim, 1), **(cw or {})},
             "roofline": roof,
             "kernels_ms_total": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in prof.items() if v["launches"]},
             "kernels_avg_us_instrumented_pass": {k: round(v["ms"] / v["launches"] * 1e3, 2) for k, v in prof_all.items() if v["launches"]},
+            "counters": ctx.counters(),
         }
-        if world == 1 and not a.no_cpu_baseline and a.workload == "phi-four":
+        if world == 1 and not a.no_cpu_baseline and a.workload != "pines":
             try:
                 from threadpoolctl import threadpool_limits
                 cores = usable_cores()
                 params_flat = ctx.get_params()
                 with threadpool_limits(limits=cores):
-                    cb = cpu_baseline(params_flat, fourier, steps_mala=4, chains=512)
-                out["cpu_baseline"] = {"value": round(cb["value"], 1), "unit": "chain-steps/s", "cores": cores, "kind": "port",
-                                       "sample": f"512 chains: 4 MALA+train iterations and 1 flow-MH+train iteration (mean {cb['n_att']:.1f} "
-                                                 f"Dopri5 attempts), same network as the GPU after warm-up; composed into a 101-iteration cycle "
-                                                 f"(t_mala_train={cb['t_mala_train_s']:.3f}s, t_flow_train={cb['t_flow_train_s']:.3f}s); float64 numpy oracle"}
+                    if d2:
+                        cb = cpu_baseline_d2(a.workload, params_flat, fourier, chains=a.chains_per_gpu, n_eval=n_eval, K=wl_K)
+                        sample = cb.pop("sample")
+                    else:
+                        cb = cpu_baseline(params_flat, fourier, steps_mala=4, chains=512)
+                        sample = (f"512 chains: 4 MALA+train iterations and 1 flow-MH+train iteration (mean {cb['n_att']:.1f} "
+                                  f"Dopri5 attempts), same network as the GPU after warm-up; composed into a 101-iteration cycle "
+                                  f"(t_mala_train={cb['t_mala_train_s']:.3f}s, t_flow_train={cb['t_flow_train_s']:.3f}s); float64 numpy oracle")
+                out["cpu_baseline"] = {"value": round(cb["value"], 1), "unit": "chain-steps/s", "cores": cores, "kind": "port", "sample": sample}
             except Exception as e:  # the baseline must never hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "chain-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)

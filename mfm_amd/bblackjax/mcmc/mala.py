@@ -42,22 +42,41 @@ def _engine(dist):
     return dist._engine
 
 
+def _rows(eng, x):
+    """A single chain ``[dim]`` (the reference's un-vmapped call shape) rides as every row of one n_chain_local batch."""
+    return x[None].expand(eng.n_local, -1).contiguous()
+
+
 def init(position, logdensity_fn: Callable) -> MALAState:
     dist, beta = resolve_logdensity(logdensity_fn)
     eng = _engine(dist)
     t = eng.torch
-    logp = t.empty(position.shape[0], device=position.device, dtype=t.float64)
-    grad = t.empty_like(position)
-    eng.ctx.mala_init(position, beta, logp, grad)
+    single = position.ndim == 1
+    pos = _rows(eng, position) if single else position
+    logp = t.empty(pos.shape[0], device=pos.device, dtype=t.float64)
+    grad = t.empty_like(pos)
+    eng.ctx.mala_init(pos, beta, logp, grad)
+    if single:
+        return MALAState(position, logp[0], grad[0])
     return MALAState(position, logp, grad)
 
 
 def build_kernel(textbook: bool = False):
     def kernel(rng_key, state: MALAState, logdensity_fn: Callable, step_size: float):
+        """``mala.py:86-118``.  ``state.position`` ``[n_chain_local, dim]`` with ONE key: the vmapped call of
+        ``exe_flow_matching.py:303,313`` (chain b draws from ``split(rng_key, n_chain_total)[chain_offset + b]``); with keys
+        ``[n_chain_local, 2]``: the caller's own vmap (``smc/base.py:122-123``); ``state.position`` ``[dim]``: the kernel
+        as the reference writes it, one chain and its key."""
         dist, beta = resolve_logdensity(logdensity_fn)
         eng = _engine(dist)
         t = eng.torch
-        pos, logp, grad = state.position.clone(), state.logdensity.clone(), state.logdensity_grad.clone()
+        single = state.position.ndim == 1
+        if single:
+            pos, grad = _rows(eng, state.position), _rows(eng, state.logdensity_grad)
+            logp = state.logdensity.reshape(1).expand(eng.n_local).contiguous()
+            rng_key = np.tile(np.asarray(rng_key, dtype=np.uint32).reshape(1, 2), (eng.n_local, 1))
+        else:
+            pos, logp, grad = state.position.clone(), state.logdensity.clone(), state.logdensity_grad.clone()
         n = pos.shape[0]
         acc = t.empty(n, device=pos.device, dtype=t.float32)
         isacc = t.empty(n, device=pos.device, dtype=t.uint8)
@@ -68,6 +87,8 @@ def build_kernel(textbook: bool = False):
             eng.ctx.mala_step_keys(keys, beta, step_size, pos, logp, grad, acc, isacc, prop, w, textbook=textbook)
         else:
             eng.ctx.mala_step(rng_key, beta, step_size, pos, logp, grad, acc, isacc, prop, w, textbook=textbook)
+        if single:
+            return MALAState(pos[0], logp[0], grad[0]), MALAInfo(acc[0], isacc.bool()[0], prop[0], w[0])
         return MALAState(pos, logp, grad), MALAInfo(acc, isacc.bool(), prop, w)
 
     return kernel

@@ -167,9 +167,22 @@ static void build_ws(const NetDev& n, WsLayout& w) {
   w.z_gate = take(n.dp); w.z_j1 = take(n.hj1); w.z_j2 = take(n.hj2); w.z_out = take(n.dp); w.z_tiles = o;
 }
 
+// Everything mfm_create allocates hangs off the context, so ONE exit path frees it: a failure below returns its status and
+// mfm_create destroys the partially built context (mfm_destroy tolerates null members) -- an out-of-memory create can be
+// retried in-process without leaking what was allocated before the failure.
+static int create_impl(const mfm_config& c, mfm_ctx* x);
+
 extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
   if (!cfg || !out) return fail(MFM_EINVAL, "null argument");
-  const mfm_config& c = *cfg;
+  *out = nullptr;
+  mfm_ctx* x = new mfm_ctx();          // value-initialised: every pointer null, every counter zero
+  const int rc = create_impl(*cfg, x);
+  if (rc != MFM_OK) { (void)mfm_destroy(x); return rc; }
+  *out = x;
+  return MFM_OK;
+}
+
+static int create_impl(const mfm_config& c, mfm_ctx* x) {
   if (c.dim <= 0 || c.fourier_dim <= 0) return fail(MFM_EINVAL, "dim / fourier_dim must be positive");
   const int hs[6] = {c.hidden_t[0], c.hidden_t[1], c.hidden_x[0], c.hidden_x[1], c.hidden_xt[0], c.hidden_xt[1]};
   for (int h : hs)
@@ -181,36 +194,29 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
                 c.chain_offset + c.n_chain_local, c.n_chain_total);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MFM_EHIP, "no HIP device available");
-  mfm_ctx* x = new mfm_ctx();
-  memset(x, 0, sizeof *x);
   x->cfg = c;
   build_net(c, x->net);
   build_ws(x->net, x->ws);
   NetDev& n = x->net;
-  if (c.activation < MFM_ACT_RELU || c.activation > MFM_ACT_SWISH) { delete x; return fail(MFM_EINVAL, "unknown activation %d", c.activation); }
+  if (c.activation < MFM_ACT_RELU || c.activation > MFM_ACT_SWISH) return fail(MFM_EINVAL, "unknown activation %d", c.activation);
   if (x->cfg.ref_std == 0.0) x->cfg.ref_std = 1.0;           // zero-initialised config: the default 'stdgauss'
-  if (!(x->cfg.ref_std > 0.0)) { delete x; return fail(MFM_EINVAL, "ref_std must be positive"); }
+  if (!(x->cfg.ref_std > 0.0)) return fail(MFM_EINVAL, "ref_std must be positive");
   bool use_wide = c.kernel_family == MFM_FAMILY_WIDE;
   if (c.activation >= MFM_ACT_GELU) {      // gelu / swish: the backward pass needs the pre-activations, which only the wide family keeps
-    if (c.kernel_family == MFM_FAMILY_TILE) {
-      delete x;
+    if (c.kernel_family == MFM_FAMILY_TILE)
       return fail(MFM_EUNSUPPORTED, "gelu / swish run on the wide kernel family (the fused tile keeps activations, not pre-activations, in LDS)");
-    }
     use_wide = true;
   }
   {
     const FmLds L = fm_lds_layout(n, true);
     size_t sm_ode; int tpw_ode;
     const bool fits = (size_t)L.total * 4 <= 160 * 1024 && (n.dp / 16 + MLP_WAVES_FM - 1) / MLP_WAVES_FM <= 2 && ode_check(n, sm_ode, tpw_ode) == 0;
-    if (!fits && c.kernel_family == MFM_FAMILY_TILE) {
-      delete x;
+    if (!fits && c.kernel_family == MFM_FAMILY_TILE)
       return fail(MFM_ETOOLARGE, "network does not fit the fused 16-chain tile kernel (LDS %zu B, dim %d)", (size_t)L.total * 4, c.dim);
-    }
     if (!fits) use_wide = true;
   }
-  if (c.kernel_family < 0 || c.kernel_family > MFM_FAMILY_WIDE) { delete x; return fail(MFM_EINVAL, "unknown kernel_family %d", c.kernel_family); }
+  if (c.kernel_family < 0 || c.kernel_family > MFM_FAMILY_WIDE) return fail(MFM_EINVAL, "unknown kernel_family %d", c.kernel_family);
   if (use_wide && !c.hutch) {
-    delete x;
     return fail(MFM_EUNSUPPORTED, "the wide kernel family integrates the log-det with the Hutchinson estimator only (--hutch); "
                                   "the exact trace needs dim tangent passes per evaluation");
   }
@@ -245,7 +251,6 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
     rc = wide::create(n, c.n_chain_local, &x->wide);
     if (rc) return fail(rc, "workspace allocation of the wide kernel family failed");
   }
-  *out = x;
   return MFM_OK;
 }
 

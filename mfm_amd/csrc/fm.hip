@@ -45,15 +45,18 @@ __host__ __device__ inline FmLds fm_lds_layout(const NetDev& n, bool train) {
   FmLds L;
   int o = 0;
   auto take = [&](int rows, int ld) { int r = o; o += rows * ld; return r; };
-  L.ldff = n.F2p + 4;            L.ff = take(16, L.ldff);
+  // leading dimensions = 8 (mod 64) dwords for the usual widths (multiples of 64): the 16-lane groups of a ds_read_b128
+  // A-fragment read (row = lane & 15, k offset 4 (lane >> 4)) then touch 64 distinct banks; K + 4 put two lanes of every
+  // group on the same four banks (2-way conflict on every A read: 1.44e6 conflict cycles per launch in the round-1 profile)
+  L.ldff = n.F2p + 8;            L.ff = take(16, L.ldff);
   L.ldx = n.dp + 8;              L.x = take(16, L.ldx);          // data starts at col 4: x[-1] and x[d] pads exist
-  L.ldt1 = n.ht1 + 4;            L.t1 = take(16, L.ldt1);
-  L.ldcat = n.hx2 + n.ht2 + 4;   L.cat = take(16, L.ldcat);
-  L.ldx1 = n.hx1 + 4;            L.x1 = take(16, L.ldx1);
-  L.ldj1 = n.hj1 + 4;            L.j1 = take(16, L.ldj1);
-  L.ldj2 = n.hj2 + 4;            L.j2 = take(16, L.ldj2);
-  L.ldg = n.dp + 4;              L.g = take(16, L.ldg);
-  L.lddv = n.dp + 4; L.ldd1 = n.hj2 + 4; L.ldd2 = n.hj1 + 4;
+  L.ldt1 = n.ht1 + 8;            L.t1 = take(16, L.ldt1);
+  L.ldcat = n.hx2 + n.ht2 + 8;   L.cat = take(16, L.ldcat);
+  L.ldx1 = n.hx1 + 8;            L.x1 = take(16, L.ldx1);
+  L.ldj1 = n.hj1 + 8;            L.j1 = take(16, L.ldj1);
+  L.ldj2 = n.hj2 + 8;            L.j2 = take(16, L.ldj2);
+  L.ldg = n.dp + 8;              L.g = take(16, L.ldg);
+  L.lddv = n.dp + 8; L.ldd1 = n.hj2 + 8; L.ldd2 = n.hj1 + 8;
   L.dv = L.d1 = L.d2 = L.dcat = 0;
   if (train) {
     L.dv = take(16, L.lddv);

@@ -90,17 +90,17 @@ struct OdeLds {   // float offsets
 __host__ __device__ inline OdeLds ode_lds_layout(const NetDev& n, int NW) {
   OdeLds L; int o = 0;
   auto take = [&](int cnt) { int r = o; o += cnt; return r; };
-  L.ldff = n.F2p + 4; L.ldj1 = n.hj1 + 4;
+  L.ldff = n.F2p + 8; L.ldj1 = n.hj1 + 8;
   { int a = 16 * L.ldff, b = 32 * L.ldj1; L.ff_j1 = take(a > b ? a : b); }
   L.ldx = n.dp + 8; L.x = take(16 * L.ldx); L.z = take(16 * L.ldx);
-  L.ldcat = n.hx2 + n.ht2 + 4; L.cat = take(32 * L.ldcat);
-  L.ldx1 = n.hx1 + 4; L.x1 = take(32 * L.ldx1);
-  L.ldj2 = n.hj2 + 4; L.ldt1 = n.ht1 + 4;
+  L.ldcat = n.hx2 + n.ht2 + 8; L.cat = take(32 * L.ldcat);
+  L.ldx1 = n.hx1 + 8; L.x1 = take(32 * L.ldx1);
+  L.ldj2 = n.hj2 + 8; L.ldt1 = n.ht1 + 8;
   { int a = 32 * L.ldj2, b = 16 * L.ldt1; L.j2_t1 = take(a > b ? a : b); }
   L.red = take(8 * 16 * NW);      // 8 reduction slots of [NW][16 rows]
   L.gcs = take(16 * 24);     // small-d targets: grad[8], hvp[8], inside-mask[8] per row
   L.rs = take(16 * 16);
-  L.ldgc = n.dp + 4; L.gc = L.hz = L.kz = 0;
+  L.ldgc = n.dp + 8; L.gc = L.hz = L.kz = 0;
   if (n.T.kind == MFM_TARGET_LGCP) { L.gc = take(16 * L.ldgc); L.hz = take(16 * L.ldgc); L.kz = take(16 * L.ldgc); }   // grad, masked H z, K^-1 z      // per-row solver state (t, dt, h0, d1, ell, kl[7], natt, done): 16 arrays of 16 rows
   L.total = o;
   return L;

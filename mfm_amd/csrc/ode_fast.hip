@@ -18,6 +18,10 @@
 //  * The per-stage divergence partials are left per wave in LDS and only summed when the attempt is judged; stage
 //    inputs are double buffered, so the out-layer epilogue (which reads x for grad log pi) never races the next write.
 //  * All shapes are compile-time constants: no layer-descriptor loads, no dynamic loops.
+//  * THE OUT LAYER CARRIES NO TANGENT ROWS.  The Hutchinson integrand only needs the SCALAR z . (J z), and the last layer is
+//    linear: z . (W_out^T tj2) = (W_out z) . tj2.  w7z = W_out z (128 values per row) is formed once per solve, next to
+//    z W_x1, and the tangent's contribution to the divergence becomes a 128-term dot product in the j2 epilogue; the out
+//    layer runs on the 16 value rows only (64 instead of 128 MFMAs per wave: 320 instead of 384 per evaluation).
 //
 // Everything that is not the solver core (probes, proposal, target evaluation at the proposal, accept / reject) follows
 // flow_step_kernel in ode.hip.  Other shapes / targets / the exact-trace mode keep using the generic kernels.
@@ -181,6 +185,8 @@ struct FTile {
   int lane, wave, g, c, sign;
   float ffreq, coef, tbeta, clip;
   float tz1[4];
+  float w7z[4];                 // (W_out z)[row 4g + i][col 16 wave + c]: the probe pulled back through the (linear) out layer
+  __amdgpu_buffer_rsrc_t wtr;   // transposed packed weights (pack of W^T), for that pull-back
   // per-lane LDS base offsets in BYTES, opaque to the optimiser (see FS): row state / partial-sum reads (rows 4g..),
   // partial-sum writes, bias column, A-fragment reads and owned-element accesses in the X / Z buffers, A-fragment reads
   // and epilogue writes in region R and in R2 = R + 64 LDH
@@ -231,6 +237,16 @@ struct FTile {
     run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(at(o_xa, S::ZB), wr, W(S::W2, wave, D / 16), W(S::W0, wave, 2 * F / 16), lane, P, Q, acc);
 #pragma unroll
     for (int i = 0; i < 4; ++i) tz1[i] = acc[0][i] + acc[1][i];
+  }
+
+  // W_out z = z W_out^T (no bias), once per solve: the transposed pack of layer 7 IS a [D -> 128] layer like W_x1.
+  // Entry: P = first group of WpT layer 7 tile `wave` (from wtr); exit: P = first group of W2 tile `wave` (precompute_tz1 next).
+  __device__ __forceinline__ void precompute_w7z(f32x4 (&P)[4], f32x4 (&Q)[4]) {
+    f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(at(o_xa, S::ZB), wtr, W(S::W7, wave, D / 16), W(S::W7, wave, D / 16), lane, P, Q, acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w7z[i] = acc[0][i] + acc[1][i];
+    load_group<1, 0>(P, wr, W(S::W2, wave, D / 16), lane);
   }
 
   // ---- the time branch for the five stage times of an attempt (phase 2), or one time replicated (phases 0, 1) ----
@@ -483,6 +499,7 @@ struct FTile {
     FSEC(15);
     __syncthreads();
     FSEC(18);
+    float dp[4];        // this lane's share of z . (J z) per row: the j2-tangent part here, the gate part in the out epilogue
     {   // j2
       f32x4 acc[1][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}};
       run_job<2, 1, 8, LDH, 0, TPW, OUT_T1OFF>(at(o_ha2, 0), wr, W(S::W6, wave, 8), W(S::W7, wave, 8), lane, P, Q, acc);
@@ -492,29 +509,28 @@ struct FTile {
       for (int i = 0; i < 4; ++i) {
         const float pre = acc[0][0][i] + b;
         *at(o_he2, (32 + i) * LDH) = fmaxf(pre, 0.f);
-        *at(o_he2, (48 + i) * LDH) = pre > 0.f ? acc[0][1][i] : 0.f;
+        // z . (W_out^T tj2) = (W_out z) . tj2: the tangent rows stop here (see the header)
+        dp[i] = (pre > 0.f ? acc[0][1][i] : 0.f) * w7z[i];
       }
     }
     FSEC(16);
     __syncthreads();
     FSEC(18);
-    {   // out: v = nn_xt + nn_t * clip(grad log pi(x)) (:88-90);  J z = d nn_xt . z + nn_t * 1[|g| <= clip] * (H z)
+    {   // out: v = nn_xt + nn_t * clip(grad log pi(x)) (:88-90);  z . J z = (W_out z) . tj2 + z . (nn_t * 1[|g| <= clip] * (H z))
       float bo[TPW];
-      f32x4 acc[TPW][2];
+      f32x4 acc[TPW][1];
 #pragma unroll
-      for (int q = 0; q < TPW; ++q) { acc[q][0] = f32x4{0, 0, 0, 0}; acc[q][1] = f32x4{0, 0, 0, 0}; bo[q] = bias(S::B7 + 128 * q); }
+      for (int q = 0; q < TPW; ++q) { acc[q][0] = f32x4{0, 0, 0, 0}; bo[q] = bias(S::B7 + 128 * q); }
       const int wnext = next_is_tbatch ? W(S::W0, wave, 16) : W(S::W2, wave, D / 16);
-      run_job<2, TPW, 8, LDH, OUT_T1OFF, 1, 0>(at(o_ha2, 32 * LDH), wr, W(S::W7, wave, 8), wnext, lane, P, Q, acc);
+      run_job<1, TPW, 8, LDH, OUT_T1OFF, 1, 0>(at(o_ha2, 32 * LDH), wr, W(S::W7, wave, 8), wnext, lane, P, Q, acc);
       FSEC(12);
-      float dp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
         const float b = bo[q];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float v = acc[q][0][i] + b + gt[q][i] * gc[q][i];
-          const float jz = acc[q][1][i] + gt[q][i] * hz[q][i];
-          dp[i] += zz[q][i] * jz;
+          dp[i] += zz[q][i] * (gt[q][i] * hz[q][i]);
           kv[q][i] = sg[i] > 0.f ? v : -v;
         }
       }
@@ -664,8 +680,9 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
     for (int fld = 0; fld < 16; ++fld) T.rs_put(fld, z4);
   }
   f32x4 P[4], Q[4];
-  load_group<1, 0>(P, T.wr, T.W(S::W2, wave, D / 16), T.lane);
+  load_group<1, 0>(P, T.wtr, T.W(S::W7, wave, D / 16), T.lane);
   __syncthreads();
+  T.precompute_w7z(P, Q);
   T.precompute_tz1(P, Q);
 
   int phase = 0, cur = 0;
@@ -930,8 +947,9 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
     T.rs_put(RS_SIGN, m1);                                     // inverse solve first (:267 / :251)
   }
   f32x4 P[4], Q[4];
-  load_group<1, 0>(P, T.wr, T.W(S::W2, wave, D / 16), T.lane);
+  load_group<1, 0>(P, T.wtr, T.W(S::W7, wave, D / 16), T.lane);
   __syncthreads();
+  T.precompute_w7z(P, Q);
   T.precompute_tz1(P, Q);
 
   int phase = 2, cur = 0;
@@ -1178,8 +1196,9 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
       if (tile_sw) {                         // tile-uniform
         if (f.mode == MFM_FLOW_IMH) { T.part_put(S::RED + 4 * 128, r0); T.part_put(S::RED + 5 * 128, r1); }
         __syncthreads();                     // the new probe rows are visible
-        load_group<1, 0>(P, T.wr, T.W(S::W2, wave, D / 16), T.lane);
-        T.precompute_tz1(P, Q);              // z W_x1 of every row (unchanged rows recompute the same values)
+        load_group<1, 0>(P, T.wtr, T.W(S::W7, wave, D / 16), T.lane);
+        T.precompute_w7z(P, Q);              // W_out z and z W_x1 of every row (unchanged rows recompute the same values)
+        T.precompute_tz1(P, Q);
       }
     }
     if (!go) break;
@@ -1194,6 +1213,7 @@ __device__ __forceinline__ void tile_init(FTile<D>& T, const NetDev& n, float* l
   T.lane = threadIdx.x & 63; T.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); T.g = T.lane >> 4; T.c = T.lane & 15;
   T.wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(n.Wp), 0, S::WTOT * 4, 0x00020000);
   T.sr = __builtin_amdgcn_make_buffer_rsrc(scr_wg, 0, SCR_F4_PER_WG * 16, 0x00020000);
+  T.wtr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(n.WpT), 0, S::WTOT * 4, 0x00020000);
   T.sign = 1;
   T.ffreq = n.fourier[16 * T.wave + T.c];
   T.coef = n.T.coef; T.tbeta = n.T.tbeta; T.clip = n.grad_clip;
@@ -1213,7 +1233,7 @@ __device__ __forceinline__ void tile_init(FTile<D>& T, const NetDev& n, float* l
     if (i < S::BIAS || i >= S::BIAS + S::BTOT) lds[i] = 0.f;                   // halo pads, row state, scratch
   for (int i = threadIdx.x; i < S::BTOT; i += NW * 64) lds[S::BIAS + i] = n.bias[i];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) T.tz1[i] = 0.f;
+  for (int i = 0; i < 4; ++i) { T.tz1[i] = 0.f; T.w7z[i] = 0.f; }
   __syncthreads();
 }
 

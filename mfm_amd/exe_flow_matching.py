@@ -19,7 +19,7 @@ from . import wandb_shim as wandb
 from ._lib import FLOW_IMH, FLOW_RWMH
 from .bblackjax.mcmc.mala import MALAInfo, MALAState, build_kernel, init  # noqa: F401  (same import as :28)
 from .distributions import IndepGaussian
-from .engine import Engine, allreduce_sum_
+from .engine import Engine, allgather_cat, allreduce_sum_
 
 logger = logging.getLogger(__name__)
 
@@ -248,6 +248,40 @@ def _finish_metric_rows(eng, metrics, lo, hi):
     rows[:, 1] = mean
 
 
+def final_sampling(eng, dist, args, key_gen, transform_and_logdet, params=None):
+    """``exe_flow_matching.py:453-459``: N = eval_iter * num_chain draws of the reference distribution pushed through the flow
+    with ONE shared Hutchinson key, self-normalised importance weights against the target, resampling with replacement.
+
+    The transform is per-sample independent: every rank integrates its contiguous slice of the N draws.  The resampling is
+    not -- weights are normalised by the GLOBAL maximum and ``jax.random.choice`` searches the GLOBAL cumulative sum with N
+    uniforms -- so flow samples, log-densities and log-weights are all-gathered (N x dim floats: small) and every rank draws
+    the same N indices from the same key.  Returns tensors over all N samples, identical on every rank."""
+    t = eng.torch
+    n_final = args.eval_iter * args.num_chain
+    if n_final % (16 * eng.world):
+        raise ValueError(f"eval_iter * num_chain = {n_final} must be a multiple of 16 x world size")
+    ref = ref_dists[args.ref_dist](args.dim)                                                # :388
+    u_host = ref.sample_rows(jr.split(key_gen, n_final))                                    # :453 (:389)
+    key_hutch, key_choice = jr.split(key_gen)                                               # :454
+    per = n_final // eng.world
+    lo = eng.rank * per
+    u = t.as_tensor(np.ascontiguousarray(u_host[lo:lo + per], dtype=np.float32), device=eng.dev)
+    flow_local, vols = transform_and_logdet(key_hutch, u, params)                           # :455
+    lp_local = _logprob_any(eng, flow_local)                                                # :456
+    ref_lp = (-0.5 * (((u.double() - ref.mean) / ref.std) ** 2).sum(1) - args.dim * np.log(ref.std) - 0.5 * args.dim * np.log(2 * np.pi))   # distributions.py:89-90
+    logw_local = lp_local - ref_lp - vols.double()                                          # :457
+    flow_samples = allgather_cat(flow_local.contiguous())
+    samples_logdensity = allgather_cat(lp_local.contiguous())
+    log_weights = allgather_cat(logw_local.contiguous())
+    idx = t.empty(n_final, device=eng.dev, dtype=t.int32)
+    scratch = t.empty(n_final, device=eng.dev, dtype=t.float64)
+    eng.ctx.choice_logw(key_choice, log_weights, n_final, scratch, idx)                     # :458-459
+    exact_samples = t.empty_like(flow_samples)
+    eng.ctx.gather_rows(flow_samples, idx, exact_samples)
+    return dict(flow_samples=flow_samples, exact_samples=exact_samples, samples_logdensity=samples_logdensity,
+                log_weights=log_weights, idx=idx, vols=vols, u=u)
+
+
 def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     """``exe_flow_matching.py:321-561``: the hot loop runs entirely on the device; metrics are fetched every
     ``log_every`` iterations (the reference syncs to the host every iteration for wandb, :442-449)."""
@@ -335,22 +369,9 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     train_time = time.time() - train_start
     logger.info(f"Final beta= {beta}")
 
-    # ---- final flow samples + importance resampling (:453-459) --------------------------------------------------
-    n_final = n_iter * n_chain
-    ref = ref_dists[args.ref_dist](args.dim)                                                # :388
-    u_host = ref.sample_rows(jr.split(key_gen, n_final))                                    # :453 (:389)
-    key_hutch, key_choice = jr.split(key_gen)                                               # :454
-    lo = eng.rank * (n_final // eng.world)
-    u = torch.as_tensor(np.ascontiguousarray(u_host[lo:lo + n_final // eng.world], dtype=np.float32), device=eng.dev)
-    flow_samples, vols = transform_and_logdet(key_hutch, u, state.params)                   # :455
-    samples_logdensity = _logprob_any(eng, flow_samples)                                    # :456
-    ref_lp = (-0.5 * (((u.double() - ref.mean) / ref.std) ** 2).sum(1) - args.dim * np.log(ref.std) - 0.5 * args.dim * np.log(2 * np.pi))   # distributions.py:89-90
-    log_weights = samples_logdensity - ref_lp - vols.double()                               # :457
-    weights = torch.exp(log_weights - log_weights.max())                                    # :458
-    p_cuml = torch.cumsum(weights, 0)
-    r = p_cuml[-1] * (1.0 - torch.as_tensor(jr.uniform(key_choice, (flow_samples.shape[0],)), device=eng.dev))
-    idx = torch.searchsorted(p_cuml, r).clamp_max(flow_samples.shape[0] - 1)
-    exact_samples = flow_samples[idx]                                                       # :459
+    # ---- final flow samples + importance resampling (:453-459), over ALL N samples on every rank --------------------
+    fin = final_sampling(eng, dist, args, key_gen, transform_and_logdet, state.params)
+    flow_samples, exact_samples, samples_logdensity = fin["flow_samples"], fin["exact_samples"], fin["samples_logdensity"]
     logpdf = samples_logdensity.mean().item()                                               # :469
     logger.info(f"Logpdf of flow samples= {logpdf}")
     stein = stein_disc(eng, flow_samples)                                                   # :471 (mcmc_utils.py:28-85)
@@ -359,10 +380,11 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     logger.info(f"Logpdf of exact samples= {logpdf_}")
     stein_ = stein_disc(eng, exact_samples)                                                 # :475
     logger.info(f"Stein U, V disc of exact samples= {stein_[0]}, {stein_[1]}")
-    if target_gn is not None and eng.world == 1:                                            # :480-487 (mcmc_utils.py:88-111)
-        mmd = eng.ctx.max_mean_disc(real_samples, flow_samples)
+    if target_gn is not None:                                                               # :480-487 (mcmc_utils.py:88-111)
+        real_all = allgather_cat(real_samples)                                              # every rank holds a slice of the exact samples
+        mmd = eng.ctx.max_mean_disc(real_all, flow_samples)
         logger.info(f"Max mean disc of flow samples= {mmd}")
-        mmd_ = eng.ctx.max_mean_disc(real_samples, exact_samples)
+        mmd_ = eng.ctx.max_mean_disc(real_all, exact_samples)
         logger.info(f"Max mean disc of exact samples= {mmd_}")
     else:
         mmd = mmd_ = 0.0                                                                    # :490
@@ -371,7 +393,8 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     wandb.finish()
     if return_extras:
         return res, res_, dict(metrics=metrics.cpu().numpy(), betas=np.array(betas), lrs=np.array(lrs), states=train_states,
-                               engine=eng, state=state, flow_samples=flow_samples, exact_samples=exact_samples, model=model)
+                               engine=eng, state=state, flow_samples=flow_samples, exact_samples=exact_samples, model=model,
+                               final=fin, key_gen=key_gen)
     eng.close()
     return res, res_
 

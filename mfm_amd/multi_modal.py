@@ -30,15 +30,20 @@ def _dirichlet(key, alpha):
     return g / g.sum()
 
 
+def gmm16_parameters(num_modes=16, dim=2, lim=(-16, 16)):
+    """(modes, covs, weights) of the `gaussian-mixture` example, multi_modal.py:39-47 (frozen in tests/golden/gmm16_params.npz)."""
+    key_mode, key_cov, key_weight = jr.split(jr.PRNGKey(0), 3)
+    modes = jr.uniform(key_mode, (num_modes, dim), lim[0] * .8, lim[1] * .8)
+    covs = np.exp(.5 * jr.normal(key_cov, (num_modes, dim)))
+    weights = _dirichlet(key_weight, 4. * np.ones(num_modes))
+    return modes, covs, weights
+
+
 def main(args):
     if args.example == "gaussian-mixture":                                              # :23-47
         print("Setting up Gaussian mixture density...")
         args.dim, args.num_modes, args.lim, args.levels, args.step_size = 2, 16, [-16, 16], 20, 0.2
-        key_mode, key_cov, key_weight = jr.split(jr.PRNGKey(0), 3)
-        modes = jr.uniform(key_mode, (args.num_modes, args.dim), args.lim[0] * .8, args.lim[1] * .8)
-        covs = np.exp(.5 * jr.normal(key_cov, (args.num_modes, args.dim)))
-        weights = _dirichlet(key_weight, 4. * np.ones(args.num_modes))
-        dist = GaussianMixture(modes, covs, weights)
+        dist = GaussianMixture(*gmm16_parameters(args.num_modes, args.dim, args.lim))
     elif args.example == "phi-four":                                                    # :50-63
         print("Setting up Phi four example density...")
         args.dim = 64

@@ -28,7 +28,7 @@ def _accept(keys_acc, a, prev, prop):
     return state, info
 
 
-def rwmh_step(keys, prev, value_and_grad, model, params, args, stats=None, replay=None):
+def rwmh_step(keys, prev, value_and_grad, model, params, args, stats=None, replay=None, round32=False):
     """``exe_flow_matching.py:264-278``.  ``replay = dict(inv=..., fwd=...)``: prescribed step sequences of the two
     solves (parity instrumentation, see ``ode.odeint``)."""
     B, d = prev.position.shape
@@ -37,6 +37,7 @@ def rwmh_step(keys, prev, value_and_grad, model, params, args, stats=None, repla
     st_inv = {} if stats is not None else None
     st_fwd = {} if stats is not None else None
     rp = replay or {}
+    o["round32"] = round32                             # test yardstick only, see ode._augmented
     u0, vol0 = ode.inverse_and_logdet(model, params, kk[:, 3], prev.position, stats=st_inv, replay=rp.get("inv"), **o)   # :267
     up = u0 + (2.38 / np.sqrt(d)) * prng.normal_rows(kk[:, 0], d)                                  # :262,268
     xp, volp = ode.transform_and_logdet(model, params, kk[:, 2], up, stats=st_fwd, replay=rp.get("fwd"), **o)            # :269

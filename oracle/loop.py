@@ -100,3 +100,26 @@ def run(dist, args, target_gn=None, params_override=None, beta_override=None, ti
             timer(count, time.perf_counter() - t0)
     trace["train_time"] = time.perf_counter() - t0
     return dict(trace=trace, states=states, state=state, model=model, beta=beta, keys=k)
+
+
+def final_sampling(model, params, dist, args, key_gen, stats=None):
+    """``exe_flow_matching.py:453-459``: the flow's samples and their self-normalised importance resampling.
+
+    ``key_gen`` is the key the reference reuses here (``:333``, or ``:371`` when exact samples exist): the
+    reference draws split into ``eval_iter * num_chain`` (``:389,453``), and it is split AGAIN into the ONE Hutchinson key
+    shared by all samples and the key of the categorical draw (``:454-455``).  Returns
+    ``(flow_samples, exact_samples, info)``; ``info`` carries every intermediate (``u, vols, samples_logdensity,
+    log_weights, weights, idx``)."""
+    from . import ode
+    n = args.eval_iter * args.num_chain
+    ref = targets.IndepGaussian(dist.dim, var=targets.REF_VARS[args.ref_dist])           # :388 (ref_dists, :48-54)
+    u = ref.sample_model_rows(prng.split(key_gen, n))                                    # :453 (:389)
+    key_hutch, key_choice = prng.split(key_gen)                                          # :454
+    x, vols = ode.transform_and_logdet(model, params, key_hutch, u, args.hutchs, args.rtol, args.atol, args.mxstep,
+                                       n_ts=args.n_ts, stats=stats)                      # :455 (one shared probe key)
+    lp = dist.logprob(x)                                                                 # :456
+    logw = lp - ref.logprob(u) - vols                                                    # :457
+    w = np.exp(logw - logw.max())                                                        # :458
+    idx = prng.choice_p(key_choice, w, (n,))                                             # :459 (with replacement)
+    idx = np.minimum(idx, n - 1)
+    return x, x[idx], dict(u=u, vols=vols, samples_logdensity=lp, log_weights=logw, weights=w, idx=idx)

@@ -190,12 +190,19 @@ def _compress_rounds(dt_seq, acc_seq, ratio_seq, dt_own, act_seq, n_att):
     return out
 
 
-def _augmented(model, params, z, hutch, sign):
-    """RHS of the augmented ODE.  sign=+1: ``:208-218`` (forward); sign=-1: ``:225-239`` (inverse)."""
+def _augmented(model, params, z, hutch, sign, round32=False):
+    """RHS of the augmented ODE.  sign=+1: ``:208-218`` (forward); sign=-1: ``:225-239`` (inverse).
+
+    ``round32`` (a test yardstick, no counterpart in the reference): evaluate the field at the stage input ROUNDED TO FLOAT32
+    -- the least any float32 implementation does to the state.  The difference it makes to a solve measures how
+    well-conditioned that solve is (the clipped field of ``dim > 128`` has a log-det integrand with narrow spikes wherever
+    ``|grad log pi|`` crosses the clip: there it is not)."""
     d = model.dim
 
     def fun(y, t):
         x = y[:, :d]
+        if round32:
+            x = x.astype(np.float32).astype(np.float64)
         tt = t if sign > 0 else 1.0 - t                                     # :229
         if hutch:
             v, jv = model.forward(params, x, tt, tangent=z)                 # :212-214 / :232-234
@@ -210,24 +217,24 @@ def _augmented(model, params, z, hutch, sign):
 
 
 def transform_and_logdet(model, params, keys, ref_sample, hutch, rtol, atol, mxstep, n_ts=2,
-                         stats=None, z=None, replay=None):
+                         stats=None, z=None, replay=None, round32=False):
     """``exe_flow_matching.py:206-221``; ``keys`` [B, 2] (one Hutchinson key per chain) or one key."""
     B, d = ref_sample.shape
     if hutch and z is None:
         keys = np.asarray(keys)
         z = prng.normal_rows(keys, d) if keys.ndim == 2 else np.broadcast_to(prng.normal(keys, (d,)), (B, d))
     y0 = np.concatenate([ref_sample, np.zeros((B, 1))], axis=1)             # :220
-    ys = odeint(_augmented(model, params, z, hutch, +1), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats, replay)
+    ys = odeint(_augmented(model, params, z, hutch, +1, round32), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats, replay)
     return ys[-1][:, :d], ys[-1][:, d]                                      # :221
 
 
 def inverse_and_logdet(model, params, keys, target_sample, hutch, rtol, atol, mxstep, n_ts=2,
-                       stats=None, z=None, replay=None):
+                       stats=None, z=None, replay=None, round32=False):
     """``exe_flow_matching.py:223-242``."""
     B, d = target_sample.shape
     if hutch and z is None:
         keys = np.asarray(keys)
         z = prng.normal_rows(keys, d) if keys.ndim == 2 else np.broadcast_to(prng.normal(keys, (d,)), (B, d))
     y0 = np.concatenate([target_sample, np.zeros((B, 1))], axis=1)          # :241
-    ys = odeint(_augmented(model, params, z, hutch, -1), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats, replay)
+    ys = odeint(_augmented(model, params, z, hutch, -1, round32), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats, replay)
     return ys[-1][:, :d], ys[-1][:, d]                                      # :242

