@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
   }
 #ifdef MFM_STAMPS
   if (g_flow_dbg && threadIdx.x == 0) {
-    unsigned long long* o = g_flow_dbg + blockIdx.x * 32;
+    unsigned long long* o = g_flow_dbg + blockIdx.x * 64;
     o[0] = __builtin_amdgcn_s_memtime() - fc0_; o[1] = __builtin_amdgcn_s_memrealtime() - fr0_;
     o[2] = T.n_eval; o[3] = T.cyc_eval; o[4] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // XCC_ID
   }

@@ -166,6 +166,65 @@ __device__ __forceinline__ void run_job(const float* arow, __amdgpu_buffer_rsrc_
   }
 }
 
+// ---- the same job on FOUR rows (v_mfma_f32_4x4x1_16b_f32), for a tile's last one or two chains -------------------------------
+// A tile whose other chains have finished still pushes 16-row MFMA tiles through every layer: the launch lasts as long as its
+// slowest chain, and that chain runs its last 100-230 attempts alone or with one neighbour (tools/tail_stats.py).  The 4x4x1
+// MFMA computes 16 independent 4 x 4 outer products per instruction (block b = lanes 4b .. 4b + 3: D[i][j] += A_b[i] B_b[j], lane
+// 4b + j supplies A_b[j] and B_b[j] and holds column j of D in its four registers; layout and rate measured in tools/mb/m4.hip:
+// ~9.6 cycles per instruction per wave at two waves per SIMD, against 32 for the 16 x 16 x 4 form).  Fed with the SAME streamed
+// fragment as the 16 x 16 x 4 path -- lane (g, c) holds W[16 kb + 4 g + s][16 nt + c] -- block (g, c >> 2) multiplies rows
+// A[c & 3][16 kb + 4 g + s] into columns 16 nt + c: each lane accumulates, for its own column, the k-subset of its g over the four
+// M-rows, and the four g-groups are summed at the end of the job (gsum).  Same weights, same LDS images, a quarter of the
+// matrix-pipe time per k-block.  M-rows: values of ranks 0, 1, then their tangent rows.
+__device__ __forceinline__ f32x4 mfma1(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+template <int NTL, int LDA>
+__device__ __forceinline__ void exec_group_m(const float* arow, const f32x4 (&bf)[4], f32x4 (&acc)[NTL][4]) {
+  constexpr int KPG = 4 / NTL;
+  f32x4 a[KPG];
+#pragma unroll
+  for (int u = 0; u < KPG; ++u) a[u] = *reinterpret_cast<const f32x4*>(arow + u * 16);
+#pragma unroll
+  for (int u = 0; u < KPG; ++u)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) acc[t][s] = mfma1(a[u][s], bf[u * NTL + t][s], acc[t][s]);      // four independent chains per tile
+}
+template <int NTL, int KB, int LDA, int T1OFF, int NTLN, int T1OFFN>
+__device__ __forceinline__ void run_job_m(const float* arow, __amdgpu_buffer_rsrc_t wr, int w, int wnext, int lane,
+                                          f32x4 (&P)[4], f32x4 (&Q)[4], f32x4 (&acc)[NTL][4]) {
+#ifdef MICRO_DEBUG_16      // development probe: the same job through the 16 x 16 x 4 path, rows 0..3 broadcast from the g = 0 lanes
+  {
+    const float* a16 = arow + ((lane & 12) * LDA) - 4 * (lane >> 4) + 4 * (lane >> 4);      // row (lane & 15) of the 16-row image
+    f32x4 a2[NTL][1];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) a2[t][0] = f32x4{0, 0, 0, 0};
+    run_job<1, NTL, KB, LDA, T1OFF, NTLN, T1OFFN>(a16, wr, w, wnext, lane, P, Q, a2);
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][0][r] = 0.25f * __shfl(a2[t][0][r], lane & 15, 64);     // gsum adds the four copies
+      acc[t][1] = acc[t][2] = acc[t][3] = f32x4{0, 0, 0, 0};
+    }
+    return;
+  }
+#endif
+  constexpr int KPG = 4 / NTL, G = KB / KPG;
+  static_assert(G % 2 == 0, "even number of fragment groups per job");
+#pragma unroll
+  for (int gi = 0; gi < G; gi += 2) {
+    load_group<NTL, T1OFF>(Q, wr, w + (gi + 1) * KPG * 1024, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    exec_group_m<NTL, LDA>(arow + gi * KPG * 16, P, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (gi + 2 < G) load_group<NTL, T1OFF>(P, wr, w + (gi + 2) * KPG * 1024, lane);
+    else load_group<NTLN, T1OFFN>(P, wr, wnext, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    exec_group_m<NTL, LDA>(arow + (gi + 1) * KPG * 16, Q, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 __device__ static const float C5[5] = {1.f / 5, 3.f / 10, 4.f / 5, 8.f / 9, 1.f};     // stage times of DP_TAB rows 2..6
 
 // Row-state fields beyond ode.hip's RS_* (0..15), used by the flow step's per-row solve phases (solve2): every chain of a
@@ -173,6 +232,9 @@ __device__ static const float C5[5] = {1.f / 5, 3.f / 10, 4.f / 5, 8.f / 9, 1.f}
 enum { RS_MODE = 16, RS_SOLVE = 17, RS_SIGN = 18, RS_VOL0 = 19, RS_NTOT = 20, RS_LQ = 21, RS_SW = 22, RS_TILE = 23,
        RS_RANK = 13 /* = RS_DONE, unused by solve2: rank of the row among the rows still integrating, -1 otherwise */ };
 enum { RM_INIT0 = 0, RM_INIT1 = 1, RM_ATT = 2, RM_DONE = 3 };
+#ifndef MICRO_ROWS
+#define MICRO_ROWS 2          // rows at or below which a tile's attempts run on the 4-row MFMA path (eval_m); 0 disables it
+#endif
 
 template <int D>
 struct FTile {
@@ -195,12 +257,16 @@ struct FTile {
   int o_xc;                     // X buffers, row 0, this lane's column (compact evaluation: rows are ranks)
   __device__ __forceinline__ float* at(int off_bytes, int cfloats) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + off_bytes) + cfloats; }
 #ifdef MFM_STAMPS
+  unsigned long long n_em = 0, cyc_em = 0, n_t1 = 0, cyc_t1 = 0;      // micro evaluations, single-tile time batches
   unsigned long long n_tc = 0, cyc_tc = 0;      // compacted time batches
   unsigned long long n_ec = 0, cyc_ec = 0;      // compact evaluations
   unsigned long long n_eval = 0, cyc_eval = 0, n_tb = 0, cyc_tb = 0, cyc_sec[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sec_t0 = 0;
+  unsigned long long cyc_csec[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // sections of the compact evaluation
 #define FSEC(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cyc_sec[i] += t_ - sec_t0; sec_t0 = t_; } while (0)
+#define CSEC(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cyc_csec[i] += t_ - sec_t0; sec_t0 = t_; } while (0)
 #else
 #define FSEC(i) do {} while (0)
+#define CSEC(i) do {} while (0)
 #endif
 
   __device__ __forceinline__ int W(int off_floats, int nt, int KB, int kb = 0) const { return off_floats * 4 + (nt * KB + kb) * 1024; }   // byte offset of a fragment
@@ -559,6 +625,9 @@ struct FTile {
   // back to the lanes that own the chain rows (Runge-Kutta registers) through rows 0..7 of the OTHER X buffer.
   __device__ __forceinline__ void eval_c(int slot, int cur, int dst, bool next_is_tbatch, f32x4 (&P)[4], f32x4 (&Q)[4], float (&kv)[TPW][4],
                                          const f32x4 sg, int rps, const f32x4 rk) {
+#ifdef MFM_STAMPS
+    sec_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int xsel = cur ? S::XB1 * 4 : S::XB0 * 4, xoth = cur ? S::XB0 * 4 : S::XB1 * 4;
     const bool is_t = g >= 2;
     const int jr0 = 4 * (g & 1);                       // this lane's M-rows 4g + i carry rank jr0 + i
@@ -597,32 +666,46 @@ struct FTile {
         dstp[i * LDH] = is_t ? (pp > 0.f ? pre[i] : 0.f) : fmaxf(pv, 0.f);
       }
     };
+    CSEC(0);
     if (wave < NW / 2) target_terms();
+    CSEC(1);
     {   // x1 on [values ; probes]
       f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
       run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(at(o_xa + xsel, 0), wr, W(S::W2, wave, D / 16), W(S::W3, wave, 8), lane, P, Q, acc);
+      CSEC(2);
       if (wave >= NW / 2) target_terms();
       act_store(acc[0] + acc[1], bias(S::B2), at(o_he, 0));
     }
+    CSEC(3);
     __syncthreads();
+    CSEC(4);
     {   // x2
       f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
       run_job<1, 1, 8, LDH, 0, 1, 0, true>(at(o_ha, 0), wr, W(S::W3, wave, 8), W(S::W5, wave, 16, 0), lane, P, Q, acc);
+      CSEC(5);
       act_store(acc[0] + acc[1], bias(S::B3), at(o_he, 32 * LDH));
     }
+    CSEC(6);
     __syncthreads();
+    CSEC(4);
     {   // j1: the st half + bias arrive as the initial accumulator of the value rows
       f32x4 acc[2] = {j1t, {0, 0, 0, 0}};
       run_job<1, 1, 8, LDH, 0, 1, 0, true>(at(o_ha, 32 * LDH), wr, W(S::W5, wave, 16, 0), W(S::W6, wave, 8), lane, P, Q, acc);
+      CSEC(7);
       act_store(acc[0] + acc[1], 0.f, at(o_he2, 0));
     }
+    CSEC(6);
     __syncthreads();
+    CSEC(4);
     {   // j2
       f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
       run_job<1, 1, 8, LDH, 0, TPW, OUT_T1OFF, true>(at(o_ha2, 0), wr, W(S::W6, wave, 8), W(S::W7, wave, 8), lane, P, Q, acc);
+      CSEC(8);
       act_store(acc[0] + acc[1], bias(S::B6), at(o_he2, 32 * LDH));
     }
+    CSEC(6);
     __syncthreads();
+    CSEC(4);
     {   // out
       float bo[TPW];
       f32x4 acc[TPW][1];
@@ -639,6 +722,7 @@ struct FTile {
           else *at(o_xc + xoth, (jr0 + i) * LDX + 128 * q) = acc[q][0][i] + bo[q] + gt[q][i] * gc[q][i];   // v of rank jr0 + i
         }
       }
+      CSEC(9);
       part_put(S::DLP + dst * 128, dp);            // M-row 8 + rank; direction sign applied by the row leaders
     }
     // no workgroup barrier: an owner lane reads what a lane of its OWN wave (same column tile, another row group) stored just
@@ -652,9 +736,125 @@ struct FTile {
         const float v = rk[i] >= 0.f ? *at(o_xc + xoth, (int)rk[i] * LDX + 128 * q) : 0.f;
         kv[q][i] = sg[i] > 0.f ? v : -v;
       }
+    CSEC(10);
+  }
+
+  // sum over the four 16-lane groups; every lane receives the same (bit-identical: float addition commutes) total
+  __device__ __forceinline__ f32x4 gsum(f32x4 v) const {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = v[r];
+      x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));      // lane ^ 16
+      // lane ^ 32: v_permlane32_swap exchanges a[32:63] with b[0:31] in place in BOTH registers.  Through inline assembly: the
+      // builtin's second result is miscompiled by hipcc 7.2 (p[0] + p[1] came out as v_pk_add v, v, v of the FIRST result; found
+      // with tools/mb/m4job.hip), and inline assembly gets no hazard padding from the compiler, hence the s_nop
+      float xa = x, xb = x;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(xa), "+v"(xb));
+      v[r] = xa + xb;
+    }
+    return v;
+  }
+
+  // ---- MICRO field evaluation: at most 2 rows of the tile still integrate (run_job_m) ---------------------------------------
+  // Same data flow as eval_c on a 4-row image: X[cur] rows 0, 1 = stage inputs of ranks 0, 1, rows 2, 3 = their probes; every
+  // layer buffer rows 0, 1 = values, rows 2, 3 = tangents.  After gsum every lane holds all four M-rows of its column; lane
+  // group g finishes M-row g (g < 2: value of rank g; g >= 2: tangent of rank g - 2, masked by the value's pre-activation it
+  // holds itself -- no cross-lane exchange).  Time-branch inputs come from the single-tile time batch (rps = 3).
+  __device__ __forceinline__ void eval_m(int slot, int cur, int dst, bool next_is_tbatch, f32x4 (&P)[4], f32x4 (&Q)[4], float (&kv)[TPW][4],
+                                         const f32x4 sg, const f32x4 rk) {
+    const int xsel = cur ? S::XB1 * 4 : S::XB0 * 4, xoth = cur ? S::XB0 * 4 : S::XB1 * 4;
+    const int rank = g & 1;
+    const bool is_t = g >= 2;
+    const int am = c & 12;                            // the 16 x 16 path reads A row (lane & 15); this one row (c & 3)
+    const int a_x = o_xa + xsel - am * LDX * 4, a_h = o_ha - am * LDH * 4, a_h2 = o_ha2 - am * LDH * 4;
+    const int e_h = o_he - 3 * g * LDH * 4, e_h2 = o_he2 - 3 * g * LDH * 4;      // epilogue row g instead of rows 4 g + i
+    float gt[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) gt[q] = tgather(slot, rank, 3, q);
+    const float j1t = tgather(slot, rank, 3, 2);
+    float gc[TPW], hz[TPW], zz[TPW];
+    auto target_terms = [&]() {
+      const float icoef = 1.f / coef;
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const float* xr = at(o_xc + xsel, rank * LDX + 128 * q);
+        const float* zr = xr + 2 * LDX;
+        const float x = xr[0], z = zr[0];
+        const float graw = -tbeta * (coef * (2.f * x - xr[-1] - xr[1]) - x * (1.f - x * x) * icoef);
+        const float hv = -tbeta * (coef * (2.f * z - zr[-1] - zr[1]) - (1.f - 3.f * x * x) * z * icoef);
+        gc[q] = clip > 0.f ? fminf(fmaxf(graw, -clip), clip) : graw;
+        hz[q] = (!(clip > 0.f) || fabsf(graw) <= clip) ? hv : 0.f;
+        zz[q] = z;
+      }
+    };
+    // finish one layer: M-row g of this lane's column -> the next layer's A image
+    auto act_store = [&](f32x4 (&acc)[1][4], float add, float* dstp) {
+      const f32x4 pre = gsum((acc[0][0] + acc[0][1]) + (acc[0][2] + acc[0][3]));
+      const float pv = (rank ? pre[1] : pre[0]) + add, pt = rank ? pre[3] : pre[2];
+      *dstp = is_t ? (pv > 0.f ? pt : 0.f) : fmaxf(pv, 0.f);
+    };
+    auto zero = [&](f32x4 (&acc)[1][4]) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[0][s] = f32x4{0, 0, 0, 0};
+    };
+    if (wave < NW / 2) target_terms();
+    {   // x1 on [values ; probes]
+      f32x4 acc[1][4]; zero(acc);
+      run_job_m<1, D / 16, LDX, 0, 1, 0>(at(a_x, 0), wr, W(S::W2, wave, D / 16), W(S::W3, wave, 8), lane, P, Q, acc);
+      if (wave >= NW / 2) target_terms();
+      act_store(acc, bias(S::B2), at(e_h, 0));
+    }
+    __syncthreads();
+    {   // x2
+      f32x4 acc[1][4]; zero(acc);
+      run_job_m<1, 8, LDH, 0, 1, 0>(at(a_h, 0), wr, W(S::W3, wave, 8), W(S::W5, wave, 16, 0), lane, P, Q, acc);
+      act_store(acc, bias(S::B3), at(e_h, 32 * LDH));
+    }
+    __syncthreads();
+    {   // j1: the st half + bias of the value rows arrive from the time batch
+      f32x4 acc[1][4]; zero(acc);
+      run_job_m<1, 8, LDH, 0, 1, 0>(at(a_h, 32 * LDH), wr, W(S::W5, wave, 16, 0), W(S::W6, wave, 8), lane, P, Q, acc);
+      act_store(acc, j1t, at(e_h2, 0));
+    }
+    __syncthreads();
+    {   // j2
+      f32x4 acc[1][4]; zero(acc);
+      run_job_m<1, 8, LDH, 0, TPW, OUT_T1OFF>(at(a_h2, 0), wr, W(S::W6, wave, 8), W(S::W7, wave, 8), lane, P, Q, acc);
+      act_store(acc, bias(S::B6), at(e_h2, 32 * LDH));
+    }
+    __syncthreads();
+    {   // out
+      f32x4 acc[TPW][4];
+#pragma unroll
+      for (int q = 0; q < TPW; ++q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[q][s] = f32x4{0, 0, 0, 0};
+      const int wnext = next_is_tbatch ? W(S::W0, wave, 16) : W(S::W2, wave, D / 16);
+      run_job_m<TPW, 8, LDH, OUT_T1OFF, 1, 0>(at(a_h2, 32 * LDH), wr, W(S::W7, wave, 8), wnext, lane, P, Q, acc);
+      float dpv = 0.f;
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const f32x4 pre = gsum((acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]));
+        const float pv = rank ? pre[1] : pre[0], pt = rank ? pre[3] : pre[2];
+        if (is_t) dpv += zz[q] * (pt + gt[q] * hz[q]);                                                  // z . J z of rank
+        else *at(o_xc + xoth, rank * LDX + 128 * q) = pv + bias(S::B7 + 128 * q) + gt[q] * gc[q];      // v of rank
+      }
+      dpv = group16_sum_dpp(dpv);
+      if (is_t && c == 0) *at((64 + wave) * 4, S::DLP + dst * 128 + rank * 8) = dpv;      // M-row 8 + rank of the partial sums (as eval_c)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = rk[i] >= 0.f ? *at(o_xc + xoth, (int)rk[i] * LDX + 128 * q) : 0.f;
+        kv[q][i] = sg[i] > 0.f ? v : -v;
+      }
   }
 };
 
+// (eval_m is a member of FTile: see above)
 // Integrate the augmented ODE from t = 0 to 1 (see ode_solve in ode.hip: same state machine, same controller).
 // Requires: Z filled (probe), halo pads of X0 / X1 / Z zero, biases in LDS.
 // RP: the parity-instrumentation instance (Replay, ode.hip); the production instance (RP = false) carries none of it.
@@ -958,8 +1158,9 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
     // ---- stage input -> X[cur] ----
     float hs[4];
     const f32x4 md4 = T.rs_get(RS_MODE), rk4 = T.rs_get(RS_RANK);
-    const int cmode = (int)*T.at(0, S::RS + RS_TILE * 16 + 1);             // 0: > 8 rows of the tile still integrate, 1: <= 8, 2: <= 3
-    const int rps = cmode == 2 ? 3 : (cmode == 1 ? 8 : 0);
+    const int cmode = (int)*T.at(0, S::RS + RS_TILE * 16 + 1);             // 0: > 8 rows of the tile still integrate, 1: <= 8, 2: <= 3, 3: <= 2
+    const int rps = cmode >= 2 ? 3 : (cmode == 1 ? 8 : 0);
+    const int prow = cmode == 3 ? 2 : 8;                                   // first probe row of the compact / micro input image
     {
       float cf[6];
 #pragma unroll
@@ -983,8 +1184,8 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
             *T.at(T.o_xc + xsel, (int)rk4[i] * LDX + 128 * q) = xin;
             if (phase == 2) {
               const float z = *T.at(T.o_xo, S::ZB + i * LDX + 128 * q);
-              *T.at(T.o_xc + S::XB0 * 4, (8 + (int)rk4[i]) * LDX + 128 * q) = z;
-              *T.at(T.o_xc + S::XB1 * 4, (8 + (int)rk4[i]) * LDX + 128 * q) = z;
+              *T.at(T.o_xc + S::XB0 * 4, (prow + (int)rk4[i]) * LDX + 128 * q) = z;
+              *T.at(T.o_xc + S::XB1 * 4, (prow + (int)rk4[i]) * LDX + 128 * q) = z;
             }
           }
         }
@@ -996,13 +1197,13 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
     if (phase == 2) {
       float cvv[5][4], svv[5][4];
       T.template tb_trig<true>(2, cvv, svv);
-      if (cmode == 2) T.template tbatch<true, 1>(2, P, Q, cvv, svv);
+      if (cmode >= 2) T.template tbatch<true, 1>(2, P, Q, cvv, svv);
       else if (cmode == 1) T.template tbatch<true, 3>(2, P, Q, cvv, svv);
       else T.template tbatch<true, 5>(2, P, Q, cvv, svv);
     } else __syncthreads();
 #ifdef MFM_STAMPS
     if (phase == 2) { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - tb0_;
-      if (cmode == 0) { T.cyc_tb += d_; T.n_tb += 1; } else { T.cyc_tc += d_; T.n_tc += 1; } }
+      if (cmode == 0) { T.cyc_tb += d_; T.n_tb += 1; } else if (cmode == 1) { T.cyc_tc += d_; T.n_tc += 1; } else { T.cyc_t1 += d_; T.n_t1 += 1; } }
 #endif
     float kv[TPW][4];
     const int dst = phase - 1;
@@ -1010,10 +1211,11 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
     const unsigned long long ce0_ = __builtin_amdgcn_s_memtime();
 #endif
     if (cmode == 0) T.eval(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN), 0, rk4);
+    else if (cmode == 3) T.eval_m(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN), rk4);
     else T.eval_c(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN), rps, rk4);
 #ifdef MFM_STAMPS
     { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - ce0_;
-      if (cmode == 0) { T.cyc_eval += d_; T.n_eval += 1; } else { T.cyc_ec += d_; T.n_ec += 1; } }
+      if (cmode == 0) { T.cyc_eval += d_; T.n_eval += 1; } else if (cmode == 3) { T.cyc_em += d_; T.n_em += 1; } else { T.cyc_ec += d_; T.n_ec += 1; } }
 #endif
     cur ^= 1;
 #pragma unroll
@@ -1154,7 +1356,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
       // rank of this row among the rows that take part in the next attempt: with <= 3 of them the time batch is compacted
       const unsigned long long bal = __ballot(any != 0);
       R1(RS_RANK) = any ? (float)__popcll(bal & ((1ull << T.lane) - 1ull)) : -1.f;
-      if (T.lane == 0) { const int na = __popcll(bal); *T.at(0, S::RS + RS_TILE * 16 + 1) = na <= 3 ? 2.f : (na <= 8 ? 1.f : 0.f); }
+      if (T.lane == 0) { const int na = __popcll(bal); *T.at(0, S::RS + RS_TILE * 16 + 1) = na <= MICRO_ROWS ? 3.f : (na <= 3 ? 2.f : (na <= 8 ? 1.f : 0.f)); }
     }
     const int go = __syncthreads_or(any);
     // ---- every lane: apply the decision of its rows (branch-free selects) ----
@@ -1390,11 +1592,13 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
   if (nz.n_items > 0) noise_tail(nz, reinterpret_cast<volatile int*>(lds + S::RS));
 #ifdef MFM_STAMPS
   if (g_flow_dbg && (threadIdx.x == 0 || threadIdx.x == 256)) {
-    unsigned long long* o = g_flow_dbg + (blockIdx.x + (threadIdx.x ? gridDim.x : 0)) * 32;
+    unsigned long long* o = g_flow_dbg + (blockIdx.x + (threadIdx.x ? gridDim.x : 0)) * 64;
     o[0] = __builtin_amdgcn_s_memtime() - fc0_; o[1] = __builtin_amdgcn_s_memrealtime() - fr0_;
     o[2] = T.n_eval; o[3] = T.cyc_eval; o[5] = T.n_tb; o[6] = T.cyc_tb;
     for (int i = 0; i < 20; ++i) o[8 + i] = T.cyc_sec[i];
     o[28] = T.n_tc; o[29] = T.cyc_tc; o[30] = T.n_ec; o[31] = T.cyc_ec;
+    for (int i = 0; i < 16; ++i) o[32 + i] = T.cyc_csec[i];
+    o[48] = T.n_em; o[49] = T.cyc_em; o[50] = T.n_t1; o[51] = T.cyc_t1;
   }
 #endif
 }

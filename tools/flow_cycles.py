@@ -20,7 +20,7 @@ eng = Engine(dist, args, fourier)
 model = E.VectorFieldNet(fourier, dist.grad_logprob, args.hidden_x, args.hidden_t, args.hidden_xt).attach(eng)
 eng.ctx.set_params(E.flatten_params(model.init(k[2])))
 ctx = eng.ctx
-dbg = torch.zeros(2 * B // 16 * 32, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(2 * B // 16 * 64, dtype=torch.int64, device="cuda")
 fn = ctx.lib.mfm_debug_flow_buffer; fn.restype = C.c_int; fn.argtypes = [C.c_void_p]
 assert fn(dbg.data_ptr()) == 0
 pos = eng.local(dist.init_params); logp = torch.empty(B, device="cuda", dtype=torch.float64); grad = torch.empty_like(pos)
@@ -34,7 +34,7 @@ for count in range(1, 304):
         e0.record(); ctx.flow_step(FLOW_RWMH, kg, 1.0, pos, logp, grad, acc, None, None, nst); e1.record()
         torch.cuda.synchronize()
         n = nst.cpu().numpy().astype(float); t = n.reshape(-1, 16)
-        dall = dbg.cpu().numpy().reshape(2, -1, 32).astype(float)
+        dall = dbg.cpu().numpy().reshape(2, -1, 64).astype(float)
         d = dall[0]
         cyc, rt, nev, cev = d[:, 0], d[:, 1], d[:, 2], d[:, 3]
         ms = e0.elapsed_time(e1)
@@ -62,6 +62,16 @@ for count in range(1, 304):
             f = nec > 0
             if f.any():
                 print(f"   compact evaluations (<= 8 rows): per WG mean {nec.mean():.0f}, slowest WG {nec[np.argmax(cyc)]:.0f}; cycles/evaluation {np.median(cec[f] / nec[f]):.0f}")
+        if d[:, 48].max() > 0:
+            f = d[:, 48] > 0; f1 = d[:, 50] > 0
+            print(f"   micro evaluations (<= 2 rows): per WG mean {d[:, 48].mean():.0f}, slowest WG {d[np.argmax(cyc), 48]:.0f}; cycles/evaluation {np.median(d[f, 49] / d[f, 48]):.0f} | "
+                  f"single-tile time batches (<= 3 rows): per WG mean {d[:, 50].mean():.0f}, slowest WG {d[np.argmax(cyc), 50]:.0f}; cycles/batch {np.median(d[f1, 51] / d[f1, 50]):.0f}")
+        for wname, dd in (("wave 0", d), ("wave 4", d4)):
+            f = dd[:, 30] > 0
+            if f.any() and dd[:, 32:48].max() > 0:
+                c = np.median(dd[f, 32:48] / dd[f, 30:31], axis=0).astype(int)
+                print(f"   COMPACT eval sections, {wname}, cycles per evaluation: gathers {c[0]} target(pre) {c[1]} x1 job {c[2]} target(post)+epi {c[3]} barriers(4) {c[4]} "
+                      f"x2 job {c[5]} epilogues x2/j1/j2 {c[6]} j1 job {c[7]} j2 job {c[8]} out job+epi {c[9]} partials+readback {c[10]}")
         print(f"   WG time: mean/max {cyc.mean()/cyc.max():.3f}; alg evals (4+6 natt) mean {4+6*n.mean():.0f}; executed/alg {nev.mean()/(4+6*n.mean()):.3f}; max-WG/alg {nev.max()/(4+6*n.mean()):.3f}")
     else:
         ctx.mala_step(kg, 1.0, args.step_size, pos, logp, grad, acc)
