@@ -532,7 +532,7 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
   LAUNCHCHK();
   if (train) return MFM_OK;            // the training path totals the loss partials in its slab-reduction kernel
   ProfScope ps2_(x, PROF_REDUCE);
-  launch_reduce_loss(x->loss_part, n / 16, d_loss, 0, x->stream);
+  launch_reduce_loss(x->loss_part, fm_eval_parts(x->net, n), d_loss, 0, x->stream);
   LAUNCHCHK();
   return MFM_OK;
 }

@@ -402,6 +402,207 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   FM_STAMP(5);
 }
 
+// ---- K9: eval_step's loss on LARGE sample sets of a low-dimensional target (exe_flow_matching.py:370-374) -------------------
+// The mixture examples evaluate the flow-matching loss on eval_iter * num_chain = 409,600 exact samples EVERY iteration
+// (94.6 GFLOP forward: it dominates their iteration).  One workgroup per 16 samples streams the
+// whole network (461 KB) per 16 rows: 11.8 GB of L2 -> CU weight traffic per call, the 16-row kernel's bound (2.24 ms = 27 % of
+// the f32-MFMA peak).  This forward-only kernel takes 64 samples per workgroup -- four MFMA row tiles per streamed weight
+// fragment, a quarter of the weight traffic -- and aliases the layer buffers (Fourier features / concatenated branch outputs,
+// t1 / j1, x1 / j2) so that 64 rows fit in LDS.  Same per-sample arithmetic as fm_fwd_bwd_kernel<.., TRAIN = false> (same
+// k-order per accumulator); the per-workgroup loss partial covers 64 samples instead of 16.  For dp <= 16 (the mixtures).
+struct FmEvalLds { int a, lda, b, ldb, c, ldc, x, ldx, g, ldg, tgt, tt, gcs, red, gmm, total; };
+__host__ __device__ inline FmEvalLds fm_eval_lds_layout(const NetDev& n) {
+  FmEvalLds L; int o = 0;
+  auto take = [&](int cnt) { int r = o; o += cnt; return r; };
+  auto mx = [](int a, int b) { return a > b ? a : b; };
+  L.lda = mx(n.F2p, n.hx2 + n.ht2) + 8; L.a = take(64 * L.lda);       // Fourier features, then [sx | st]
+  L.ldb = mx(n.ht1, n.hj1) + 8;         L.b = take(64 * L.ldb);       // t1, then j1
+  L.ldc = mx(n.hx1, n.hj2) + 8;         L.c = take(64 * L.ldc);       // x1, then j2
+  L.ldx = n.dp + 8;                     L.x = take(64 * L.ldx);       // cond (data at column 4)
+  L.ldg = n.dp + 8;                     L.g = take(64 * L.ldg);       // gate
+  L.tgt = take(64 * n.dp); L.tt = take(64); L.gcs = take(64 * 8); L.red = take(32);
+  L.gmm = take(n.T.kind == MFM_TARGET_GMM ? n.T.n_modes * (2 * n.d + 1) : 0);      // mixture parameters, staged once per workgroup
+  L.total = o;
+  return L;
+}
+__global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_eval64_kernel(FmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const NetDev& n = a.net;
+  const FmEvalLds L = fm_eval_lds_layout(n);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * 64, d = n.d;
+  constexpr int NT_ = MLP_WAVES_FM * 64;
+  float* bA = lds + L.a; float* bB = lds + L.b; float* bC = lds + L.c; float* bX = lds + L.x; float* bG = lds + L.g;
+  float* bT = lds + L.tgt; float* btt = lds + L.tt; float* gcs = lds + L.gcs; double* red = reinterpret_cast<double*>(lds + L.red);
+  FM_STAMP(0);
+  // ---- batch construction (:151-169 / :139-147), rows past the end of the batch are zero rows that do not count ----
+  for (int i = threadIdx.x; i < 64 * L.ldx; i += NT_) bX[i] = 0.f;
+  for (int i = threadIdx.x; i < 64 * n.dp; i += NT_) bT[i] = 0.f;
+  for (int r = threadIdx.x; r < 64; r += NT_)
+    btt[r] = b0 + r < a.B ? (float)uniform01(a.key_time, a.chain_offset + (uint32_t)(b0 + r), a.n_total) : 0.f;      // :154 / :142
+  TargetDev Tl = n.T;                       // the mixture's parameters from LDS: gmm_eval walks them twice per row, one row per thread
+  if (n.T.kind == MFM_TARGET_GMM) {
+    float* gm = lds + L.gmm;
+    const int K = n.T.n_modes;
+    for (int i = threadIdx.x; i < K * d; i += NT_) { gm[i] = n.T.gmm_mode[i]; gm[K * d + i] = n.T.gmm_std[i]; }
+    for (int i = threadIdx.x; i < K; i += NT_) gm[2 * K * d + i] = n.T.gmm_logw[i];
+    Tl.gmm_mode = gm; Tl.gmm_std = gm + K * d; Tl.gmm_logw = gm + 2 * K * d;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * d; e += NT_) {          // only the d live columns draw (the pads of cond / target stay zero)
+    const int row = e / d, col = e - row * d;
+    if (b0 + row < a.B) {
+      const uint32_t bg = a.chain_offset + (uint32_t)(b0 + row);
+      const double x1v = a.pos[(size_t)(b0 + row) * d + col], t = btt[row];
+      double cnd, tgd;
+      if (a.cond_flow) {
+        const double x0 = a.ref_std * normal64(split_at(a.key_ref, a.n_total, bg), (uint32_t)col, (uint32_t)d);                 // :155
+        const double ne = normal64(a.key_gauss, bg * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);                    // :166
+        cnd = (double)a.sigma * ne + t * x1v + (1.0 - t) * x0; tgd = x1v - x0;                                                  // :167-168
+      } else {
+        const double x0 = normal64(a.key_ref, bg * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);                      // :143
+        cnd = t * x1v + (1.0 - (1.0 - (double)a.sigma) * t) * x0; tgd = x1v - (1.0 - (double)a.sigma) * x0;                      // :144-146
+      }
+      bX[row * L.ldx + 4 + col] = (float)cnd; bT[row * n.dp + col] = (float)tgd;
+    }
+  }
+  FM_STAMP(1);
+  // Fourier features (:70-71): cos block, then sin block; ONE sincos per (row, frequency), and a thread keeps its frequency
+  // while it walks the rows (the workgroup size is a multiple of the usual F: the frequency load leaves the loop)
+  if (NT_ % n.F == 0) {
+    const int col = threadIdx.x % n.F;
+    const double f = n.fourier[col];
+    for (int row = threadIdx.x / n.F; row < 64; row += NT_ / n.F) {
+      double ft = f * (double)btt[row];
+      ft -= rint(ft);
+      float sv, cvv;
+      sincospif(2.f * (float)ft, &sv, &cvv);
+      bA[row * L.lda + col] = cvv; bA[row * L.lda + n.F + col] = sv;
+    }
+  } else {
+    for (int e = threadIdx.x; e < 64 * n.F; e += NT_) {
+      const int row = e / n.F, col = e - row * n.F;
+      double ft = (double)n.fourier[col] * (double)btt[row];
+      ft -= rint(ft);
+      float sv, cvv;
+      sincospif(2.f * (float)ft, &sv, &cvv);
+      bA[row * L.lda + col] = cvv; bA[row * L.lda + n.F + col] = sv;
+    }
+  }
+  for (int e = threadIdx.x; e < 64 * (n.F2p - 2 * n.F); e += NT_) {      // pad columns of the first layer's K (F2p = ceil16(2 F))
+    const int w = n.F2p - 2 * n.F, row = e / w;
+    bA[row * L.lda + 2 * n.F + (e - row * w)] = 0.f;
+  }
+  __syncthreads();
+  FM_STAMP(2);
+  // grad log pi of the mixture (distributions.py:58-61 in its log-sum-exp form).  With K <= 16 modes: ONE MODE PER LANE, 16 lanes
+  // per row -- component log-weights, their maximum, the responsibilities and the d gradient sums by DPP row reductions, all
+  // 512 threads busy (the serial per-row walk over the modes was ~3.4 k instructions on one wave, 8-14 k cycles on the critical
+  // path of every workgroup).  The sums run over the modes in another order than gmm_eval's loop: float rounding only.
+  if (n.T.kind == MFM_TARGET_GMM && n.T.n_modes <= 16) {
+    const int K = n.T.n_modes;
+    for (int p = threadIdx.x; p < 64 * 16; p += NT_) {
+      const int row = p >> 4, k = p & 15;
+      const bool live = k < K;
+      const float* xr = bX + row * L.ldx + 4;
+      float comp = -INFINITY, aj[8];
+      if (live) comp = Tl.gmm_logw[k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        aj[j] = 0.f;
+        if (j < d && live) {
+          const float sd = Tl.gmm_std[k * d + j], dx = xr[j] - Tl.gmm_mode[k * d + j], z = dx / sd;
+          comp -= 0.5f * z * z;
+          aj[j] = -dx / (sd * sd);
+        }
+      }
+      const float m = group16_max_dpp(comp);
+      const float e = live ? expf(comp - m) : 0.f;
+      const float inv = 1.f / group16_sum_dpp(e);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < d) {
+          const float gj = group16_sum_dpp(e * aj[j]) * inv;
+          if (k == 0) gcs[row * 8 + j] = gj;
+        }
+    }
+  } else if (n.T.kind == MFM_TARGET_GMM && wave == MLP_WAVES_FM - 1) {
+    const int row = lane;
+    double lp; float gg[8];
+    gmm_eval<8>(Tl, bX + row * L.ldx + 4, &lp, gg);
+    for (int j = 0; j < d; ++j) gcs[row * 8 + j] = gg[j];
+  }
+  FM_STAMP(3);
+  auto relu_store = [&](float* out, int ldo, int coff) {
+    return [&, out, ldo, coff](int q, int nt, int m, f32x4 acc, float bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[(16 * m + 4 * g + i) * ldo + coff + nt * 16 + c] = act_f(acc[i] + bias, n.act);
+    };
+  };
+  auto L_ = [&](int l) -> const LayerDesc& { return n.L[l]; };
+  layer_gemm<4, MLP_WAVES_FM>(bA, L.lda, n.Wp + L_(0).w_off, n.bias + L_(0).b_off, L_(0).Kp / 16, L_(0).Np / 16, wave, lane, relu_store(bB, L.ldb, 0));       // t1
+  FM_STAMP(4);
+  layer_gemm<4, MLP_WAVES_FM>(bX + 4, L.ldx, n.Wp + L_(2).w_off, n.bias + L_(2).b_off, L_(2).Kp / 16, L_(2).Np / 16, wave, lane, relu_store(bC, L.ldc, 0));   // x1
+  __syncthreads();
+  FM_STAMP(5);
+  layer_gemm<4, MLP_WAVES_FM>(bB, L.ldb, n.Wp + L_(1).w_off, n.bias + L_(1).b_off, L_(1).Kp / 16, L_(1).Np / 16, wave, lane, relu_store(bA, L.lda, n.hx2));   // st
+  layer_gemm<4, MLP_WAVES_FM>(bC, L.ldc, n.Wp + L_(3).w_off, n.bias + L_(3).b_off, L_(3).Kp / 16, L_(3).Np / 16, wave, lane, relu_store(bA, L.lda, 0));       // sx
+  __syncthreads();
+  FM_STAMP(6);
+  // gate and out have dp / 16 = 1 column tile: instead of ONE wave pushing the four row tiles through it (the other seven
+  // waiting at the barrier), four waves take one row tile each
+  const bool narrow = n.dp == 16;
+  if (narrow) {
+    if (wave < 4)
+      layer_gemm<1, 1>(bA + n.hx2 + wave * 16 * L.lda, L.lda, n.Wp + L_(4).w_off, n.bias + L_(4).b_off, L_(4).Kp / 16, 1, 0, lane,
+                       [&](int q, int nt, int m, f32x4 acc, float bias) {
+#pragma unroll
+                         for (int i = 0; i < 4; ++i) bG[(16 * wave + 4 * g + i) * L.ldg + c] = acc[i] + bias;
+                       });
+  } else
+  layer_gemm<4, MLP_WAVES_FM>(bA + n.hx2, L.lda, n.Wp + L_(4).w_off, n.bias + L_(4).b_off, L_(4).Kp / 16, L_(4).Np / 16, wave, lane,                         // gate
+                              [&](int q, int nt, int m, f32x4 acc, float bias) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) bG[(16 * m + 4 * g + i) * L.ldg + nt * 16 + c] = acc[i] + bias;
+                              });
+  layer_gemm<4, MLP_WAVES_FM>(bA, L.lda, n.Wp + L_(5).w_off, n.bias + L_(5).b_off, L_(5).Kp / 16, L_(5).Np / 16, wave, lane, relu_store(bB, L.ldb, 0));       // j1
+  __syncthreads();
+  FM_STAMP(7);
+  layer_gemm<4, MLP_WAVES_FM>(bB, L.ldb, n.Wp + L_(6).w_off, n.bias + L_(6).b_off, L_(6).Kp / 16, L_(6).Np / 16, wave, lane, relu_store(bC, L.ldc, 0));       // j2
+  __syncthreads();
+  FM_STAMP(8);
+  float loss_loc = 0.f;        // out + loss (:88-90, :177-178)
+  auto out_epi = [&](int mt, int nt, f32x4 acc, float bias) {
+    const int col = nt * 16 + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * mt + 4 * g + i;
+      if (col < d && b0 + row < a.B) {
+        const float gc = target_gclip(n, bX, L.ldx, gcs, nullptr, 0, row, col);
+        const float r = acc[i] + bias + bG[row * L.ldg + col] * gc - bT[row * n.dp + col];
+        loss_loc += r * r;
+      }
+    }
+  };
+  if (narrow) {
+    if (wave < 4)
+      layer_gemm<1, 1>(bC + wave * 16 * L.ldc, L.ldc, n.Wp + L_(7).w_off, n.bias + L_(7).b_off, L_(7).Kp / 16, 1, 0, lane,
+                       [&](int q, int nt, int m, f32x4 acc, float bias) { out_epi(wave, 0, acc, bias); });
+  } else
+  layer_gemm<4, MLP_WAVES_FM>(bC, L.ldc, n.Wp + L_(7).w_off, n.bias + L_(7).b_off, L_(7).Kp / 16, L_(7).Np / 16, wave, lane,
+                              [&](int q, int nt, int m, f32x4 acc, float bias) { out_epi(m, nt, acc, bias); });
+  FM_STAMP(9);
+  const double lw = wave_sum((double)loss_loc);
+  if (lane == 0) red[wave] = lw;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < MLP_WAVES_FM; ++w) tot += red[w];
+    a.loss_part[blockIdx.x] = tot;
+  }
+  FM_STAMP(10);
+}
+
 // ---- weight gradients: dW[k][n] = sum_b A[b][k] dZ[b][n], db[n] = sum_b dZ[b][n] ------------------------------
 // One workgroup (4 waves) per 64 x 64 output block, one wave per 32 x 32 quadrant (2 x 2 MFMA tiles), SPLIT slices of the
 // chain axis.  Both operands come from the packed workspaces as float4 per lane; partial sums go to slab[split][n_params] in the
@@ -575,7 +776,19 @@ __global__ void reduce_loss_kernel(const double* part, int n, double* out, int a
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------
+// number of per-workgroup loss partials the forward-only launch of `n` samples leaves in loss_part
+static bool fm_eval64_ok(const NetDev& n, int B) {
+  return n.dp <= 16 && n.T.kind != MFM_TARGET_LGCP && B >= 64 * 256 && (size_t)fm_eval_lds_layout(n).total * sizeof(float) <= 160 * 1024 && !getenv("MFM_EVAL16");
+}
+int fm_eval_parts(const NetDev& n, int B) { return fm_eval64_ok(n, B) ? (B + 63) / 64 : B / 16; }
+
 int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
+  if (!train && fm_eval64_ok(a.net, a.B)) {
+    const size_t sm64 = (size_t)fm_eval_lds_layout(a.net).total * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)fm_eval64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm64);
+    hipLaunchKernelGGL(fm_eval64_kernel, dim3((a.B + 63) / 64), dim3(MLP_WAVES_FM * 64), sm64, stream, a);
+    return 0;
+  }
   const FmLds L = fm_lds_layout(a.net, train);
   const size_t sm = (size_t)L.total * sizeof(float);
   if (sm > 160 * 1024) return -3;

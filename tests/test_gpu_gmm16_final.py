@@ -128,6 +128,23 @@ def test_gmm16_full_size_iteration_and_eval_batch():
     ctx.fm_loss(key_loss, xs[:1024], part, n_total=n_eval, offset=0)
     lo, _ = fm.loss_and_grad(model, params, key_loss, real[:1024].astype(np.float64), args.sigma, need_grad=False, n_total=n_eval, start=0)
     assert abs(part.item() - lo) < 2e-5 * abs(lo)
+    # large sample sets of the mixtures run the 64-samples-per-workgroup forward kernel (fm_eval64_kernel); MFM_EVAL16 routes
+    # them through the 16-row kernel every other call uses: the same per-sample arithmetic, another grouping of the partial sums.
+    # Also a sample count that is not a multiple of 64 (the last workgroup is partly empty) and the oracle on that set.
+    import os
+    n_odd = 16384 + 48
+    ctx.fm_loss(key_loss, xs[:n_odd], part, n_total=n_eval, offset=0); l64 = part.item()
+    os.environ["MFM_EVAL16"] = "1"
+    try:
+        ctx.fm_loss(key_loss, xs[:n_odd], part, n_total=n_eval, offset=0); l16 = part.item()
+        ctx.fm_loss(key_loss, xs, part, n_total=n_eval, offset=0); f16 = part.item()
+    finally:
+        del os.environ["MFM_EVAL16"]
+    # (each lane first sums its own squared residuals in float32 -- 4 with 16 rows per workgroup, 16 with 64 -- before the float64
+    # reduction: measured 1.4e-9 relative)
+    assert abs(l64 - l16) < 1e-7 * abs(l16) and abs(full.item() - f16) < 1e-7 * abs(f16), (l64, l16, full.item(), f16)
+    lo, _ = fm.loss_and_grad(model, params, key_loss, real[:n_odd].astype(np.float64), args.sigma, need_grad=False, n_total=n_eval, start=0)
+    assert abs(l64 - lo) < 2e-5 * abs(lo)
     # (b) one iteration's kernels at 4096 chains vs the oracle on chains [0, 64)
     x32 = dist.init_params.astype(np.float32)
     pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, 2, device="cuda")
