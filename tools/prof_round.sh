@@ -3,7 +3,7 @@
 # domains besides --kernel-trace).  usage (on the GPU box): tools/prof_round.sh TAG
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
