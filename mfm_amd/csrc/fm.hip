@@ -235,10 +235,13 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     }
   }
   __syncthreads();
-  if (n.T.kind == MFM_TARGET_GMM && threadIdx.x < 16) {
+  if (n.T.kind == MFM_TARGET_GMM && (n.T.n_modes <= 16 ? threadIdx.x < 256 : threadIdx.x < 16)) {      // one mode per lane (targets.cuh)
     double lp; float gg[8];
-    gmm_eval<8>(n.T, bX + threadIdx.x * L.ldx + 4, &lp, gg);
-    for (int j = 0; j < d; ++j) gcs[threadIdx.x * 8 + j] = gg[j];
+    const int row = n.T.n_modes <= 16 ? (int)(threadIdx.x >> 4) : (int)threadIdx.x;
+    if (n.T.n_modes <= 16) gmm_eval_lanes16<8>(n.T, bX + row * L.ldx + 4, threadIdx.x & 15, &lp, gg);
+    else gmm_eval<8>(n.T, bX + row * L.ldx + 4, &lp, gg);
+    if (n.T.n_modes > 16 || (threadIdx.x & 15) == 0)
+      for (int j = 0; j < d; ++j) gcs[row * 8 + j] = gg[j];
   }
 
   FM_STAMP(2);
@@ -500,31 +503,12 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_eval64_kernel(FmArgs a
   // 512 threads busy (the serial per-row walk over the modes was ~3.4 k instructions on one wave, 8-14 k cycles on the critical
   // path of every workgroup).  The sums run over the modes in another order than gmm_eval's loop: float rounding only.
   if (n.T.kind == MFM_TARGET_GMM && n.T.n_modes <= 16) {
-    const int K = n.T.n_modes;
     for (int p = threadIdx.x; p < 64 * 16; p += NT_) {
-      const int row = p >> 4, k = p & 15;
-      const bool live = k < K;
-      const float* xr = bX + row * L.ldx + 4;
-      float comp = -INFINITY, aj[8];
-      if (live) comp = Tl.gmm_logw[k];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        aj[j] = 0.f;
-        if (j < d && live) {
-          const float sd = Tl.gmm_std[k * d + j], dx = xr[j] - Tl.gmm_mode[k * d + j], z = dx / sd;
-          comp -= 0.5f * z * z;
-          aj[j] = -dx / (sd * sd);
-        }
-      }
-      const float m = group16_max_dpp(comp);
-      const float e = live ? expf(comp - m) : 0.f;
-      const float inv = 1.f / group16_sum_dpp(e);
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < d) {
-          const float gj = group16_sum_dpp(e * aj[j]) * inv;
-          if (k == 0) gcs[row * 8 + j] = gj;
-        }
+      const int row = p >> 4;
+      double lp; float gg[8];
+      gmm_eval_lanes16<8>(Tl, bX + row * L.ldx + 4, p & 15, &lp, gg);
+      if ((p & 15) == 0)
+        for (int j = 0; j < d; ++j) gcs[row * 8 + j] = gg[j];
     }
   } else if (n.T.kind == MFM_TARGET_GMM && wave == MLP_WAVES_FM - 1) {
     const int row = lane;

@@ -53,7 +53,20 @@ __device__ __forceinline__ double row_value_grad(const TargetDev& T, double beta
       if (j < d) { acc += (double)xs[j] * (double)T.counts[j] - (double)T.poisson_a * (double)expf(xs[j]); gout[it] = 0.f; }
     }
     return beta * wave_sum(acc);
-  } else {  // GMM: lane 0 evaluates the row, gradient broadcast through LDS scratch
+  } else if (T.n_modes <= 16) {  // GMM, one mode per lane: every 16-lane group of the wave evaluates the row (targets.cuh)
+    double lp = 0.0;
+    float g[MALA_MAXD_SMALL];
+    gmm_eval_lanes16<MALA_MAXD_SMALL>(T, xs, lane & 15, &lp, g);
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int j = lane + 64 * it;
+      float gj = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < MALA_MAXD_SMALL; ++jj) gj = (jj == j) ? g[jj] : gj;
+      if (j < d) gout[it] = (float)beta * gj;
+    }
+    return beta * lp;
+  } else {  // GMM with more than 16 modes: lane 0 evaluates the row, gradient broadcast through LDS scratch
     double lp = 0.0;
     if (lane == 0) {
       float g[MALA_MAXD_SMALL];

@@ -237,16 +237,21 @@ struct OdeTile {
         }
       }
     }
-    if (N.T.kind == MFM_TARGET_GMM && threadIdx.x < 16) {    // small-d target: grad / hvp per row by one thread
+    if (N.T.kind == MFM_TARGET_GMM && (N.T.n_modes <= 16 ? threadIdx.x < 256 : threadIdx.x < 16)) {
+      // small-d target: grad / hvp per row -- one mode per lane, 16 lanes per row (targets.cuh); > 16 modes: one thread per row
       double lp; float gg[8], hv[8];
-      const float* xr = bX() + threadIdx.x * L.ldx + 4;
-      const float* zr = bZ() + threadIdx.x * L.ldx + 4;
-      gmm_eval<8>(N.T, xr, &lp, gg, hutch ? zr : nullptr, hv);
-      float* o = gcs() + threadIdx.x * 24;
-      for (int j = 0; j < d; ++j) {
-        const bool inside = !(N.grad_clip > 0.f) || fabsf(gg[j]) <= N.grad_clip;
-        o[j] = clipf(gg[j], N.grad_clip);
-        o[8 + j] = (hutch && inside) ? hv[j] : 0.f;
+      const int row = N.T.n_modes <= 16 ? (int)(threadIdx.x >> 4) : (int)threadIdx.x;
+      const float* xr = bX() + row * L.ldx + 4;
+      const float* zr = bZ() + row * L.ldx + 4;
+      if (N.T.n_modes <= 16) gmm_eval_lanes16<8>(N.T, xr, threadIdx.x & 15, &lp, gg, hutch ? zr : nullptr, hv);
+      else gmm_eval<8>(N.T, xr, &lp, gg, hutch ? zr : nullptr, hv);
+      if (N.T.n_modes > 16 || (threadIdx.x & 15) == 0) {
+        float* o = gcs() + row * 24;
+        for (int j = 0; j < d; ++j) {
+          const bool inside = !(N.grad_clip > 0.f) || fabsf(gg[j]) <= N.grad_clip;
+          o[j] = clipf(gg[j], N.grad_clip);
+          o[8 + j] = (hutch && inside) ? hv[j] : 0.f;
+        }
       }
     }
     if (N.T.kind == MFM_TARGET_LGCP)      // grad log pi(x) = c - a exp(x) - K^-1 (x - mu);  H z = -a exp(x) z - K^-1 z
@@ -998,11 +1003,16 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
     }
   } else {
     double* rd = reinterpret_cast<double*>(T.red(0));
-    if (threadIdx.x < 16) {
+    const bool lanes16 = N.T.n_modes <= 16;
+    if (lanes16 ? threadIdx.x < 256 : threadIdx.x < 16) {
       double lp; float gg[8];
-      gmm_eval<8>(N.T, T.bX() + threadIdx.x * T.L.ldx + 4, &lp, gg);
-      rd[threadIdx.x] = lp;
-      for (int j = 0; j < d; ++j) T.gcs()[threadIdx.x * 24 + j] = gg[j];
+      const int row = lanes16 ? (int)(threadIdx.x >> 4) : (int)threadIdx.x;
+      if (lanes16) gmm_eval_lanes16<8>(N.T, T.bX() + row * T.L.ldx + 4, threadIdx.x & 15, &lp, gg);
+      else gmm_eval<8>(N.T, T.bX() + row * T.L.ldx + 4, &lp, gg);
+      if (!lanes16 || (threadIdx.x & 15) == 0) {
+        rd[row] = lp;
+        for (int j = 0; j < d; ++j) T.gcs()[row * 24 + j] = gg[j];
+      }
     }
     __syncthreads();
 #pragma unroll

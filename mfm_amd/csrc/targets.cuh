@@ -69,6 +69,48 @@ __device__ __forceinline__ float gmm_comp(const TargetDev& T, const float (&x)[M
   return s;
 }
 
+// The same evaluation with ONE MODE PER LANE: the 16 lanes that share (lane >> 4) evaluate one row of a mixture of
+// K <= 16 modes -- component log-weights, their maximum, the responsibilities and the gradient / Hessian-vector sums by DPP
+// row reductions.  gmm_eval's serial walk over the modes (two passes, ~3.4 k instructions at K = 16) sat on one lane per row;
+// here every lane of the group returns the row's results after ~150 instructions.  `k` = lane & 15.  The sums run over the
+// modes in the reduction tree's order instead of the loop's: float rounding only.
+template <int MAXD>
+__device__ __forceinline__ void gmm_eval_lanes16(const TargetDev& T, const float* xp, int k, double* logp, float* grad,
+                                                 const float* vp = nullptr, float* hv = nullptr) {
+  const int d = T.dim;
+  const bool live = k < T.n_modes;
+  float comp = -INFINITY, a[MAXD], w[MAXD], av = 0.f;
+  if (live) comp = T.gmm_logw[k];
+#pragma unroll
+  for (int j = 0; j < MAXD; ++j) {
+    a[j] = 0.f; w[j] = 0.f;
+    if (j < d && live) {
+      const float sd = T.gmm_std[k * d + j], dx = xp[j] - T.gmm_mode[k * d + j], z = dx / sd;
+      comp -= 0.5f * z * z;
+      a[j] = -dx / (sd * sd);
+      if (vp) { av += a[j] * vp[j]; w[j] = vp[j] / (sd * sd); }
+    }
+  }
+  const float m = group16_max_dpp(comp);
+  const float e = live ? expf(comp - m) : 0.f;
+  const float se = group16_sum_dpp(e), inv = 1.f / se;
+  *logp = (double)m + (double)logf(se);
+  float gv = 0.f, t1[MAXD];
+#pragma unroll
+  for (int j = 0; j < MAXD; ++j) {
+    grad[j] = 0.f; t1[j] = 0.f;
+    if (j < d) {
+      grad[j] = group16_sum_dpp(e * a[j]) * inv;
+      if (vp) { t1[j] = group16_sum_dpp(e * (a[j] * av - w[j])) * inv; gv += grad[j] * vp[j]; }
+    }
+  }
+  if (vp) {
+#pragma unroll
+    for (int j = 0; j < MAXD; ++j)
+      if (j < d) hv[j] = t1[j] - grad[j] * gv;
+  }
+}
+
 template <int MAXD>
 __device__ __forceinline__ void gmm_eval(const TargetDev& T, const float* xp, double* logp, float* grad,
                                          const float* vp = nullptr, float* hv = nullptr) {
