@@ -176,17 +176,22 @@ def usable_cores():
     return max(1, n)
 
 
-def pmc_traffic(kernel_class):
+def pmc_traffic(kernel_class, workload="phi-four"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc passes of this
     same command, tools/prof_round.sh): 2 * FETCH_SIZE + WRITE_SIZE, both reported in KB; the factor 2 is the gfx950
     correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section).  None when no summary is present."""
-    for rel in ("profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"):       # newest committed summary first
+    files = {"phi-four": ("profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"),       # newest committed summary first
+             "gaussian-mixture": ("profiles/r02_gmm_pmc_summary.json",), "pines": ("profiles/r02_pines_pmc_summary.json",)}.get(workload, ())
+    pattern = {"fm_eval": "fm_eval64"}.get(kernel_class, kernel_class)
+    if workload == "pines":
+        return None, None      # its roofline entry is the whole training step (many launches): per-kernel traffic is in the summary file
+    for rel in files:
         try:
             d = json.load(open(os.path.join(ROOT, rel)))
         except Exception:
             continue
         for name, c in d.items():
-            if kernel_class in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            if pattern in name and isinstance(c.get("FETCH_SIZE"), dict) and isinstance(c.get("WRITE_SIZE"), dict):
                 return int((2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024), rel
     return None, None
 
@@ -242,8 +247,8 @@ def main():
     wl_example, wl_dim, wl_h, _, wl_chains, wl_K = WORKLOADS[a.workload]
     if not a.chains_per_gpu:
         a.chains_per_gpu = wl_chains
-    if a.workload == "pines" and a.steps == 1010 and a.warmup == 201:     # three cycles at this size
-        a.steps, a.warmup = 303, 100
+    if a.workload == "pines" and a.steps == 1010 and a.warmup == 201:     # two cycles after two cycles of training: the timed flow
+        a.steps, a.warmup = 202, 202                                       # steps integrate a field that has trained for 200+ iterations
     if a.workload == "4-mode" and a.steps == 1010 and a.warmup == 201:    # K = 10: twenty 11-iteration cycles after two
         a.steps, a.warmup = 220, 22
     n_total = a.chains_per_gpu * world            # weak scaling: per-GPU work fixed
@@ -385,7 +390,7 @@ def main():
         if dom is not None:
             avg_ms = src[dom]["ms"] / src[dom]["launches"]
             ach = alg[dom] / (avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic(dom) if a.workload == "phi-four" else (None, None)
+            traffic, traffic_src = pmc_traffic(dom, a.workload)
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(avg_ms, 5), "algorithmic_flop_per_launch": alg[dom]}

@@ -138,6 +138,8 @@ class Engine:
         self.dev = dev
         self.grads = torch.zeros(self.n_params, device=dev, dtype=torch.float32)
         self.loss = torch.zeros(1, device=dev, dtype=torch.float64)
+        import os
+        self._split_calls = bool(os.environ.get("MFM_SPLIT_CALLS"))     # development: time the multi-rank call sequence on one rank
         self._deferred = DeferredAllReduce(lambda: self.ctx.adamw_step(self.grads))
         self.ctx.before_params = self._deferred.flush
 
@@ -179,7 +181,7 @@ class Engine:
         (``mfm_train_iter``).  More ranks: the separate calls, so that the MALA step — which needs neither the parameters
         nor the gradient buffer — runs while the previous iteration's gradient all-reduce is still in flight."""
         loss = self.loss if loss_out is None else loss_out
-        if self.world == 1:
+        if self.world == 1 and not self._split_calls:
             self.ctx.train_iter(count, K, flow_mode, key_gen, key_train, beta, step_size, pos, logp, grad, loss, self.grads,
                                 acc=acc, nsteps=nsteps)
             return loss
