@@ -90,13 +90,16 @@ struct OdeLds {   // float offsets
 __host__ __device__ inline OdeLds ode_lds_layout(const NetDev& n, int NW) {
   OdeLds L; int o = 0;
   auto take = [&](int cnt) { int r = o; o += cnt; return r; };
+  // rows of the value + tangent images: 32 (values + one tangent), 48 for d = 2, whose exact trace pushes the tangents of
+  // BOTH basis vectors through in one pass (OdeTile::eval_x2)
+  const int RT = n.d == 2 ? 48 : 32;
   L.ldff = n.F2p + 8; L.ldj1 = n.hj1 + 8;
-  { int a = 16 * L.ldff, b = 32 * L.ldj1; L.ff_j1 = take(a > b ? a : b); }
+  { int a = 16 * L.ldff, b = RT * L.ldj1; L.ff_j1 = take(a > b ? a : b); }
   L.ldx = n.dp + 8; L.x = take(16 * L.ldx); L.z = take(16 * L.ldx);
-  L.ldcat = n.hx2 + n.ht2 + 8; L.cat = take(32 * L.ldcat);
-  L.ldx1 = n.hx1 + 8; L.x1 = take(32 * L.ldx1);
+  L.ldcat = n.hx2 + n.ht2 + 8; L.cat = take(RT * L.ldcat);
+  L.ldx1 = n.hx1 + 8; L.x1 = take(RT * L.ldx1);
   L.ldj2 = n.hj2 + 8; L.ldt1 = n.ht1 + 8;
-  { int a = 32 * L.ldj2, b = 16 * L.ldt1; L.j2_t1 = take(a > b ? a : b); }
+  { int a = RT * L.ldj2, b = 16 * L.ldt1; L.j2_t1 = take(a > b ? a : b); }
   L.red = take(8 * 16 * NW);      // 8 reduction slots of [NW][16 rows]
   L.gcs = take(16 * 24);     // small-d targets: grad[8], hvp[8], inside-mask[8] per row
   L.rs = take(16 * 16);
@@ -133,6 +136,7 @@ struct OdeTile {
   bool exact;               // exact trace: d basis probes per RHS evaluation instead of one Hutchinson probe
   int sign;                 // +1 forward (:208-218), -1 inverse (:225-239)
   float tz1[2][4];          // z W_x1 for this lane's x1-layer tiles (<= 2 tiles per wave)
+  float tze[2][2];          // exact trace, d = 2: e_j W_x1 = row j of W_x1 at this lane's column of its x1-layer tiles
   float gate[TPW][4];       // nn_t of the last evaluated stage time (kept for stages that share it)
 
   __device__ __forceinline__ float* bFF() { return lds + L.ff_j1; }
@@ -413,6 +417,147 @@ struct OdeTile {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dl[i] = sign > 0 ? -dpart[i] : dpart[i];     // :218 / :239
   }
+
+  // ---- exact trace for d = 2 (the mixture examples, no --hutch: trace(jacfwd(v)), :216-217 / :236-237) in ONE pass ----------
+  // The generic exact mode runs the whole evaluation once per basis vector (value rows recomputed, 12 barriers, the target
+  // evaluated twice).  With two basis vectors the tangent rows of BOTH ride behind the value rows: M = 48 through x2 / j1 / j2 /
+  // out (every weight fragment feeds three row tiles), the x1 tangent is row j of W_x1 itself (no probe image), the
+  // Hessian-vector products of e_1 and e_2 come from two calls of the mode-per-lane mixture evaluation, and
+  // trace J = (J e_1)_1 + (J e_2)_2 is picked out of the out layer's tangent tiles.  Same arithmetic per entry as `eval`.
+  __device__ __forceinline__ void precompute_tze() {
+    const LayerDesc& l2 = n->L[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int nt = wave + NW * q;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        tze[q][j] = nt < l2.Np / 16 ? n->Wp[l2.w_off + pack_index(j, nt * 16 + c, l2.Kp / 16)] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void eval_x2(const float (&tt)[4], float (&kv)[TPW][4], float (&dl)[4], int red_slot, bool reuse_time) {
+    const NetDev& N = *n;
+    const int d = N.d;
+    if (!reuse_time) {
+      for (int nt = wave; nt * 16 < N.F2p; nt += NW) {
+        const int col = nt * 16 + c;
+        const bool is_sin = col >= N.F;
+        const double f = col < 2 * N.F ? (double)N.fourier[is_sin ? col - N.F : col] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = 0.f;
+          if (col < 2 * N.F) {
+            const double te = sign > 0 ? (double)tt[i] : 1.0 - (double)tt[i];          // :229
+            double ft = f * te;
+            ft -= rint(ft);
+            float sv, cv;
+            sincospif(2.f * (float)ft, &sv, &cv);
+            v = is_sin ? sv : cv;
+          }
+          bFF()[(4 * g + i) * L.ldff + col] = v;
+        }
+      }
+    }
+    if (N.T.n_modes <= 16 ? threadIdx.x < 256 : threadIdx.x < 16) {          // grad log pi, H e_1, H e_2 per row
+      const bool l16 = N.T.n_modes <= 16;
+      const int row = l16 ? (int)(threadIdx.x >> 4) : (int)threadIdx.x;
+      const float* xr = bX() + row * L.ldx + 4;
+      const float e1[8] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, e2[8] = {0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      double lp; float gg[8], h1[8], h2[8];
+      if (l16) { gmm_eval_lanes16<8>(N.T, xr, threadIdx.x & 15, &lp, gg, e1, h1); gmm_eval_lanes16<8>(N.T, xr, threadIdx.x & 15, &lp, gg, e2, h2); }
+      else { gmm_eval<8>(N.T, xr, &lp, gg, e1, h1); gmm_eval<8>(N.T, xr, &lp, gg, e2, h2); }
+      if (!l16 || (threadIdx.x & 15) == 0) {
+        float* o = gcs() + row * 24;
+        for (int j = 0; j < d; ++j) {
+          const bool inside = !(N.grad_clip > 0.f) || fabsf(gg[j]) <= N.grad_clip;
+          o[j] = clipf(gg[j], N.grad_clip);
+          o[8 + j] = inside ? h1[j] : 0.f;
+          o[16 + j] = inside ? h2[j] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    if (!reuse_time)
+    layer_gemm<1, NW, 1>(bFF(), L.ldff, N.Wp + N.L[0].w_off, N.bias + N.L[0].b_off, N.L[0].Kp / 16, N.L[0].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc, float b) {
+#pragma unroll
+                       for (int i = 0; i < 4; ++i) bT1()[(4 * g + i) * L.ldt1 + nt * 16 + c] = act_f(acc[i] + b, N.act);
+                     });
+    layer_gemm<1, NW, 1>(bX() + 4, L.ldx, N.Wp + N.L[2].w_off, N.bias + N.L[2].b_off, N.L[2].Kp / 16, N.L[2].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc, float b) {
+#pragma unroll
+                       for (int i = 0; i < 4; ++i) {
+                         const float pre = acc[i] + b;
+                         const int o = (4 * g + i) * L.ldx1 + nt * 16 + c;
+                         bX1()[o] = act_f(pre, N.act);
+                         bX1()[16 * L.ldx1 + o] = mask_pre(pre, q == 0 ? tze[0][0] : tze[1][0], N.act);
+                         bX1()[32 * L.ldx1 + o] = mask_pre(pre, q == 0 ? tze[0][1] : tze[1][1], N.act);
+                       }
+                     });
+    __syncthreads();
+    if (!reuse_time)
+    layer_gemm<1, NW, 1>(bT1(), L.ldt1, N.Wp + N.L[1].w_off, N.bias + N.L[1].b_off, N.L[1].Kp / 16, N.L[1].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc, float b) {
+#pragma unroll
+                       for (int i = 0; i < 4; ++i) bCat()[(4 * g + i) * L.ldcat + N.hx2 + nt * 16 + c] = act_f(acc[i] + b, N.act);
+                     });
+    // value + two tangent row tiles through one layer: m = 0 keeps the value's pre-activation for the masks of m = 1, 2
+    auto three = [&](const float* A, int lda, int layer, float* out, int ldo) {
+      f32x4 keep = {0, 0, 0, 0};
+      layer_gemm<3, NW, 1>(A, lda, N.Wp + N.L[layer].w_off, N.bias + N.L[layer].b_off, N.L[layer].Kp / 16, N.L[layer].Np / 16, wave, lane,
+                       [&](int q, int nt, int m, f32x4 acc, float b) {
+#pragma unroll
+                         for (int i = 0; i < 4; ++i) {
+                           const int o = (4 * g + i) * ldo + nt * 16 + c;
+                           if (m == 0) { keep[i] = acc[i] + b; out[o] = act_f(keep[i], N.act); }
+                           else out[16 * m * ldo + o] = mask_pre(keep[i], acc[i], N.act);
+                         }
+                       });
+    };
+    three(bX1(), L.ldx1, 3, bCat(), L.ldcat);
+    __syncthreads();
+    if (!reuse_time)
+    layer_gemm<1, NW, 1>(bCat() + N.hx2, L.ldcat, N.Wp + N.L[4].w_off, N.bias + N.L[4].b_off, N.L[4].Kp / 16, N.L[4].Np / 16, wave, lane,
+                     [&](int q, int nt, int m, f32x4 acc, float b) {
+#pragma unroll
+                       for (int qq = 0; qq < TPW; ++qq)
+                         if (qq == q) {
+#pragma unroll
+                           for (int i = 0; i < 4; ++i) gate[qq][i] = acc[i] + b;
+                         }
+                     });
+    three(bCat(), L.ldcat, 5, bJ1(), L.ldj1);
+    __syncthreads();
+    three(bJ1(), L.ldj1, 6, bJ2(), L.ldj2);
+    __syncthreads();
+    float dpart[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      f32x4 hz1 = {0, 0, 0, 0}, hz2 = {0, 0, 0, 0};
+      layer_gemm<3, NW, 1>(bJ2(), L.ldj2, N.Wp + N.L[7].w_off, N.bias + N.L[7].b_off, N.L[7].Kp / 16, N.L[7].Np / 16, wave, lane,
+                       [&](int q, int nt, int m, f32x4 acc, float b) {
+                         const int col = nt * 16 + c;
+#pragma unroll
+                         for (int i = 0; i < 4; ++i) {
+                           const int row = 4 * g + i;
+                           float gt = 0.f;
+#pragma unroll
+                           for (int qq = 0; qq < TPW; ++qq) gt = (qq == q) ? gate[qq][i] : gt;
+                           if (m == 0) {
+                             float gc = 0.f;
+                             if (col < d) { gc = gcs()[row * 24 + col]; hz1[i] = gcs()[row * 24 + 8 + col]; hz2[i] = gcs()[row * 24 + 16 + col]; }
+                             const float v = col < d ? acc[i] + b + gt * gc : 0.f;
+#pragma unroll
+                             for (int qq = 0; qq < TPW; ++qq)
+                               if (qq == q) kv[qq][i] = sign > 0 ? v : -v;
+                           } else if (col == m - 1) {                    // (J e_m)_m: the diagonal entry of this basis vector
+                             dpart[i] += acc[i] + gt * (m == 1 ? hz1[i] : hz2[i]);
+                           }
+                         }
+                       });
+    }
+    row_reduce(dpart, red_slot);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dl[i] = sign > 0 ? -dpart[i] : dpart[i];     // :218 / :239
+  }
 };
 
 // Integrate the augmented ODE from t = 0 to 1 for the tile whose start positions are in y[][] (accumulator layout);
@@ -459,7 +604,9 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
     for (int fld = 0; fld < 14; ++fld) T.rs_put(fld, z4);
   }
   __syncthreads();
-  if (!T.exact) T.precompute_tz1();     // Hutchinson probe: z W_x1 once per solve (reads bZ only)
+  const bool ex2 = T.exact && N.d == 2 && N.T.kind == MFM_TARGET_GMM;      // exact trace of the d = 2 mixtures: one fused pass
+  if (ex2) T.precompute_tze();
+  else if (!T.exact) T.precompute_tz1();     // Hutchinson probe: z W_x1 once per solve (reads bZ only)
 
   int phase = 0;
 #pragma unroll 1
@@ -497,10 +644,10 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
       for (int i = 0; i < 4; ++i) kv[q][i] = 0.f;      // waves that own no output tile never write kv
     // Hutchinson: one probe z (drawn once per solve).  Exact trace (:216-217 / :236-237): trace J = sum_j e_j . J e_j,
     // one tangent pass per basis vector; passes after the first reuse the time branch of the first.
-    const int nprobe = T.exact ? d : 1;
+    const int nprobe = (T.exact && !ex2) ? d : 1;
 #pragma unroll 1
     for (int pj = 0; pj < nprobe; ++pj) {
-      if (T.exact) {
+      if (T.exact && !ex2) {
         for (int idx = threadIdx.x; idx < 16 * N.dp; idx += NW * 64) {
           const int row = idx / N.dp, col = idx - row * N.dp;
           T.bZ()[row * T.L.ldx + 4 + col] = col == pj ? 1.f : 0.f;
@@ -512,7 +659,8 @@ __device__ __forceinline__ void ode_solve(OdeTile<TPW, NW>& T, float rtol, float
 #ifdef MFM_STAMPS
       const unsigned long long c0_ = __builtin_amdgcn_s_memtime();
 #endif
-      T.eval(ts, kv, dl1, (phase + pj) & 1, nullptr, phase == 7 || pj > 0);
+      if (ex2) T.eval_x2(ts, kv, dl1, phase & 1, phase == 7);
+      else T.eval(ts, kv, dl1, (phase + pj) & 1, nullptr, phase == 7 || pj > 0);
 #ifdef MFM_STAMPS
       T.cyc_eval += __builtin_amdgcn_s_memtime() - c0_; T.n_eval += 1;
 #endif

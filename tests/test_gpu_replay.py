@@ -153,7 +153,7 @@ def _flow_replay_raw(ctx, model, params, args, dist, beta, x32, key, yardstick=F
                 own=own.cpu().numpy(), pos=pos.cpu().numpy(), logp=logp.cpu().numpy())
 
 
-@pytest.mark.parametrize("d,hidden,F", [(256, 128, 128), (64, 32, 16)])
+@pytest.mark.parametrize("d,hidden,F", [(256, 128, 128), (128, 128, 128), (64, 32, 16)])      # shape-specialised kernel x2, generic tile
 def test_flow_step_on_prescribed_steps_matches_oracle(d, hidden, F):
     """Well-conditioned field: inverse solve -> latent proposal -> forward solve -> target -> log acceptance ratio, per chain, on
     the oracle's step sequences.  d = 256 is the shape-specialised kernel (per-row solve phases, tail compaction)."""

@@ -6,8 +6,12 @@ import numpy as np, torch
 np.set_printoptions(suppress=True, linewidth=250)
 from tests import gpu_util as gu
 from mfm_amd import _lib
-B, d = 4096, 256
-args, dist, k, model, state = gu.phi4_setup(d=d, B=B)
+if os.environ.get("EVAL_STAMPS_CFG") == "gmm":          # the 16-mode mixture (d = 2), Hutchinson-style single tangent pass
+    B, d = 4096, 2
+    args, dist, k, model, state = gu.gmm16_setup(B=B, hutchs=True)
+else:
+    B, d = 4096, 256
+    args, dist, k, model, state = gu.phi4_setup(d=d, B=B)
 params = gu.rand_params(model, seed=1, out_scale=0.05)
 ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
 x = torch.from_numpy(dist.init_params.astype(np.float32)).cuda(); t = torch.rand(B, device="cuda"); z = torch.randn(B, d, device="cuda")
