@@ -234,10 +234,12 @@ def main():
     torch.cuda.set_device(0 if os.environ.get("MFM_BENCH_SHARE_GPU") else local_rank)
     td = None
     backend = None
-    if world > 1:
-        import torch.distributed as td
+    if world > 1 or os.environ.get("MFM_COLLECTIVES_AT_WORLD1"):                      # the latter: rehearsal of the RCCL call
+        import torch.distributed as td                                                # pattern on a one-rank communicator
         backend = os.environ.get("MFM_BENCH_BACKEND", "nccl")                         # "nccl" = RCCL on ROCm
-        td.init_process_group(backend)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        td.init_process_group(backend, **({"device_id": torch.device("cuda", torch.cuda.current_device())} if backend == "nccl" else {}))
 
     from mfm_amd import exe_flow_matching as E, random as jr
     from mfm_amd._lib import FLOW_RWMH
@@ -414,7 +416,7 @@ def main():
             cycle_ms = (wl_K + 1) * t_rest + flow_ms["ms"] / flow_ms["launches"]
             cw = {"cycle_weighted_value": round(n_total * (wl_K + 1) / (cycle_ms * 1e-3), 1), "cycle_ms": round(cycle_ms, 4),
                   "iteration_ms_excluding_flow_kernel": round(t_rest, 5), "flow_step_avg_ms": round(flow_ms["ms"] / flow_ms["launches"], 4)}
-        par = "single GPU" if world == 1 else (f"chains sharded x{world}, one gradient all-reduce(SUM) per iteration over torch.distributed backend "
+        par = ("single GPU" + (f" (REHEARSAL: the multi-rank call sequence with its collectives on a one-rank '{backend}' communicator)" if td is not None else "")) if world == 1 else (f"chains sharded x{world}, one gradient all-reduce(SUM) per iteration over torch.distributed backend "
                                                f"'{backend}'" + (" (RCCL over xGMI)" if backend == "nccl" else " (rehearsal backend, NOT RCCL)"))
         out = {
             "metric": f"MFM train-steps/s x chains ({desc[0]})", "value": round(value, 1),

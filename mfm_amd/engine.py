@@ -21,6 +21,14 @@ def _dist():
     return None
 
 
+def _collective(td):
+    """Whether the collectives are issued: more than one rank -- or MFM_COLLECTIVES_AT_WORLD1=1, the rehearsal of the RCCL
+    call pattern (async all-reduce on RCCL's stream, waits, all-gathers) on a ONE-rank communicator, which is all a
+    one-GPU box can host (RCCL refuses two ranks on one device)."""
+    import os
+    return td is not None and (td.get_world_size() > 1 or bool(os.environ.get("MFM_COLLECTIVES_AT_WORLD1")))
+
+
 def shard(n_total, rank, world):
     """Contiguous shard of the chain axis; every shard must be a multiple of 16 chains (one MFMA M-tile)."""
     if n_total % world:
@@ -34,7 +42,7 @@ def shard(n_total, rank, world):
 def allreduce_sum_(*tensors):
     """In-place SUM all-reduce of each tensor over the default process group (no-op without one)."""
     td = _dist()
-    if td and td.get_world_size() > 1:
+    if _collective(td):
         for t in tensors:
             td.all_reduce(t, op=td.ReduceOp.SUM)
     return tensors
@@ -44,7 +52,7 @@ def allgather_cat(t):
     """Concatenate equally sized per-rank shards in rank order."""
     import torch
     td = _dist()
-    if td and td.get_world_size() > 1:
+    if _collective(td):
         parts = [torch.empty_like(t) for _ in range(td.get_world_size())]
         td.all_gather(parts, t)
         return torch.cat(parts)
@@ -76,7 +84,7 @@ class DeferredAllReduce:
 
     def submit(self, *tensors):
         td = _dist()
-        if td is None or td.get_world_size() == 1:
+        if not _collective(td):
             self.apply()
             return
         self.flush()
@@ -139,7 +147,7 @@ class Engine:
         self.grads = torch.zeros(self.n_params, device=dev, dtype=torch.float32)
         self.loss = torch.zeros(1, device=dev, dtype=torch.float64)
         import os
-        self._split_calls = bool(os.environ.get("MFM_SPLIT_CALLS"))     # development: time the multi-rank call sequence on one rank
+        self._split_calls = bool(os.environ.get("MFM_SPLIT_CALLS")) or _collective(td)   # development: the multi-rank call sequence on one rank
         self._deferred = DeferredAllReduce(lambda: self.ctx.adamw_step(self.grads))
         self.ctx.before_params = self._deferred.flush
 
