@@ -20,6 +20,7 @@
 //
 // Replaces the same reference code as fm.hip / ode.hip: exe_flow_matching.py:56-90 (VectorFieldNet), :151-178 (loss),
 // :206-242 (CNF transforms), :246-278 (flow-MH steps), jax.value_and_grad at :364-365.
+#include <type_traits>
 #include "mlp.cuh"
 #include "prng.cuh"
 
@@ -45,75 +46,9 @@ struct Gemm {
   const float* add; int lda, acol;       // backward: pre += add (second contribution to the same activation)
 };
 
-template <int MTW, int NTW, bool DUAL>
-__global__ __launch_bounds__(256) void gemm_kernel(Gemm a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-  const int mt0 = (blockIdx.y * 2 + (wave >> 1)) * MTW, nt0 = (blockIdx.x * 2 + (wave & 1)) * NTW;
-  const int MT = a.rows >> 4;
-  if (mt0 >= MT || nt0 >= a.NT) return;                       // no barriers in this kernel
-  const f32x4* wp[NTW];
-  const float* xp[MTW];
-  const float* xtp[MTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) wp[j] = reinterpret_cast<const f32x4*>(a.W) + (size_t)(nt0 + j < a.NT ? nt0 + j : nt0) * a.KB * 64 + lane;
-#pragma unroll
-  for (int m = 0; m < MTW; ++m) {
-    const size_t row = (size_t)(mt0 + m < MT ? mt0 + m : mt0) * 16 + c;
-    xp[m] = a.X + row * a.ldx + 4 * g;
-    xtp[m] = DUAL ? a.XT + row * a.ldx + 4 * g : nullptr;
-  }
-  f32x4 acc[NTW][MTW], acT[NTW][MTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j)
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) { acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f}; acT[j][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-  struct Frag { f32x4 w[NTW], x[MTW], t[MTW]; };
-  auto load = [&](Frag& f, int kb) {
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) f.w[j] = wp[j][(size_t)kb * 64];
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) f.x[m] = *reinterpret_cast<const f32x4*>(xp[m] + kb * 16);
-    if (DUAL) {
-      if (kb < a.KBT) {
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) f.t[m] = *reinterpret_cast<const f32x4*>(xtp[m] + kb * 16);
-      }
-    }
-  };
-  auto mac = [&](const Frag& f, int kb) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j)
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[j][s], f.x[m][s], acc[j][m], 0, 0, 0);
-    if (DUAL) {
-      if (kb < a.KBT) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int j = 0; j < NTW; ++j)
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) acT[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[j][s], f.t[m][s], acT[j][m], 0, 0, 0);
-      }
-    }
-  };
-  // a ring of four fragment sets: the loads of block kb + 3 are issued before block kb is multiplied, i.e. three blocks
-  // (3 x 16 MTW NTW MFMA issue slots) of latency cover for a wave that is often alone on its SIMD (the launch is ~one
-  // workgroup per CU at the pines shape)
-  Frag f[4];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-    if (j < a.KB) load(f[j], j);
-  for (int kb = 0; kb < a.KB; kb += 4) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (kb + j + 3 < a.KB) load(f[(j + 3) & 3], kb + j + 3);
-      if (kb + j < a.KB) mac(f[j], kb + j);
-    }
-  }
-  // epilogue: lane (g, c) holds features 16 nt + 4 g .. + 3 of row 16 mt + c
+// Epilogue shared by the GEMM kernels: lane (g, c) holds features 16 nt + 4 g .. + 3 of row 16 mt + c.
+template <int MTW, int NTW>
+__device__ __forceinline__ void gemm_epilogue(const Gemm& a, f32x4 (&acc)[NTW][MTW], f32x4 (&acT)[NTW][MTW], int mt0, int nt0, int MT, int g, int c) {
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     const int nt = nt0 + j;
@@ -152,6 +87,277 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm a) {
   }
 }
 
+// Keeps a group of prefetch requests where the source puts them: (1) a compiler memory barrier -- without it the optimizer
+// folds "phi of loads" into a load of a phi of addresses at the top of the iteration that USES the data; (2) a scheduling
+// barrier -- without it the machine scheduler sinks the requests below the MFMAs of the blocks in front of them (both seen in
+// the ISA of round 1's kernels: vmcnt(0) two instructions after the request, 50 % / 28 % MFMA occupancy)
+#define WIDE_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int MTW, int NTW, bool DUAL, int RING = 4>
+__global__ __launch_bounds__(256) void gemm_kernel(Gemm a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int mt0 = (blockIdx.y * 2 + (wave >> 1)) * MTW, nt0 = (blockIdx.x * 2 + (wave & 1)) * NTW;
+  const int MT = a.rows >> 4;
+  if (mt0 >= MT || nt0 >= a.NT) return;                       // no barriers in this kernel
+  const f32x4* wp[NTW];
+  const float* xp[MTW];
+  const float* xtp[MTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) wp[j] = reinterpret_cast<const f32x4*>(a.W) + (size_t)(nt0 + j < a.NT ? nt0 + j : nt0) * a.KB * 64 + lane;
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const size_t row = (size_t)(mt0 + m < MT ? mt0 + m : mt0) * 16 + c;
+    xp[m] = a.X + row * a.ldx + 4 * g;
+    xtp[m] = DUAL ? a.XT + row * a.ldx + 4 * g : nullptr;
+  }
+  f32x4 acc[NTW][MTW], acT[NTW][MTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) { acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f}; acT[j][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  struct Frag { f32x4 w[NTW], x[MTW], t[MTW]; };
+  using WithT = std::integral_constant<bool, true>;
+  using NoT = std::integral_constant<bool, false>;
+  auto load = [&](Frag& f, int kb, auto with_t) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) f.w[j] = wp[j][(size_t)kb * 64];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) f.x[m] = *reinterpret_cast<const f32x4*>(xp[m] + kb * 16);
+    if constexpr (DUAL && decltype(with_t)::value) {
+      const int kt = kb < a.KBT ? kb : a.KBT - 1;
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) f.t[m] = *reinterpret_cast<const f32x4*>(xtp[m] + kt * 16);
+    }
+  };
+  auto mac = [&](const Frag& f, auto with_t) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[j][s], f.x[m][s], acc[j][m], 0, 0, 0);
+    if constexpr (DUAL && decltype(with_t)::value) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) acT[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[j][s], f.t[m][s], acT[j][m], 0, 0, 0);
+    }
+  };
+  // A ring of RING fragment sets: the loads of block kb + RING - 1 are issued before block kb is multiplied, i.e. RING - 1 blocks
+  // ((RING - 1) x 16 MTW NTW MFMA issue slots) of latency cover for a wave that is often alone on its SIMD (the launch is ~one
+  // workgroup per CU at the pines shape).  Every load of the loop is UNCONDITIONAL (block indices clamped to the last block,
+  // the tangent's to its last block): with the loads under `if (kb + 3 < KB)` the compiler could not count them and waited
+  // with vmcnt(0) in front of the first MFMA of every round -- for the block it had just requested (round 1: 50 % MFMA
+  // occupancy on the 1024^3 layer).  Tangent blocks come first (K blocks [0, KBT)), then the value-only remainder.
+  Frag f[RING];
+  const int kl = a.KB - 1;
+  auto ck = [&](int kb) { return kb < kl ? kb : kl; };
+  const int kt_end = DUAL ? a.KBT : 0;                         // a multiple of RING on the path that uses it
+  if ((DUAL && (a.KBT % RING)) || (a.KB % RING)) {
+    // general case (never taken by the reference's widths): one block at a time, tangent under a uniform branch
+    for (int kb = 0; kb < a.KB; ++kb) {
+      load(f[0], kb, WithT{});
+      if (kb < a.KBT) mac(f[0], WithT{}); else mac(f[0], NoT{});
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < RING - 1; ++j) load(f[j], ck(j), WithT{});
+    WIDE_PIN();
+    int kb = 0;
+    for (; kb < kt_end; kb += RING) {
+#pragma unroll
+      for (int j = 0; j < RING; ++j) { load(f[(j + RING - 1) % RING], ck(kb + j + RING - 1), WithT{}); WIDE_PIN(); mac(f[j], WithT{}); }
+    }
+    for (; kb < a.KB; kb += RING) {
+#pragma unroll
+      for (int j = 0; j < RING; ++j) { load(f[(j + RING - 1) % RING], ck(kb + j + RING - 1), NoT{}); WIDE_PIN(); mac(f[j], NoT{}); }
+    }
+  }
+  gemm_epilogue<MTW, NTW>(a, acc, acT, mt0, nt0, MT, g, c);
+}
+
+// The same GEMM with the activation tile staged through LDS: workgroup tile 64 rows x 64 features, K in steps of 64.
+// Why: the fragment-shaped activation loads of gemm_kernel (16 rows x 64 B per instruction) use half of every 128-byte line
+// they touch -- twice the texture-addresser time for the same bytes -- and four waves each load their own copy.  Here the
+// 256 threads load the [64 rows][64 k] tile ONCE per step in full lines (16 lanes x 16 B per row), park it in registers for
+// one step (2,048 MFMA cycles of latency cover), write it to a [64][72] LDS image (leading dimension = 8 mod 64 dwords:
+// the ds_read_b128 A-fragment reads -- 16 rows x 4 k-groups -- touch all 64 banks once) and every wave reads its fragments
+// from there.  Waves are arranged 1 (rows) x 4 (features): a wave owns one 16-feature tile for all 64 rows, so each packed
+// weight fragment is loaded by exactly one wave (2 x 2 waves loaded every fragment twice); the weights stay on the
+// register ring, three k-blocks ahead.  One barrier per step, placed in front of the step's LAST k-block: by then every
+// wave has written the next tile (at the step's start) and has issued its last fragment read of this one.
+constexpr int GL_LD = 72;
+__device__ __forceinline__ f32x4 wide_bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+#ifdef WIDE_DBG_CLOCK
+__device__ unsigned long long wide_dbg_clk[4];
+#endif
+// WM = 1: four waves, each a 16-feature tile x all 64 rows.  WM = 2: eight waves (two per SIMD), each 16 features x 32 rows:
+// every weight fragment is then loaded by two waves, but a SIMD has a second wave to issue from while the first waits.
+template <bool DUAL, int WM>
+__global__ __launch_bounds__(256 * WM) void gemm_lds_kernel(Gemm a) {
+  constexpr int MTW = 4 / WM, NP = 4 / WM;                     // M tiles per wave; staging passes per thread
+  __shared__ __attribute__((aligned(16))) float Xs[2][64][GL_LD];
+  __shared__ __attribute__((aligned(16))) float Ts[DUAL ? 2 : 1][DUAL ? 64 : 1][DUAL ? GL_LD : 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c = lane & 15;
+  const int wn = wave & 3, wm = wave >> 2;
+  const int MT = a.rows >> 4;
+  // XCD-aware tile order: consecutive workgroup ids go to consecutive XCDs (id % 8), each with its own L2.  Give XCD q the
+  // compact block of tiles (q % QX, q / QX) so that the activation rows and weight columns it streams are shared by its 32 CUs
+  int bx = blockIdx.x, by = blockIdx.y;
+#ifndef WIDE_DBG_NO_REMAP
+  if ((gridDim.x & 7) == 0 && (gridDim.y & 3) == 0) {
+    const int id = blockIdx.y * gridDim.x + blockIdx.x, q = id & 7, j = id >> 3;
+    const int bw = gridDim.x >> 1, bh = gridDim.y >> 2;        // block of tiles per XCD: (gx / 2) x (gy / 4)
+    bx = (q & 1) * bw + j % bw; by = (q >> 1) * bh + j / bw;
+  }
+#endif
+  const int mt0 = by * 4 + wm * MTW, nt = bx * 4 + wn;
+  // Operands through buffer descriptors: per-lane offsets are loop constants, the k position is a SCALAR offset (no vector
+  // address arithmetic between the MFMAs) and reads past the end of a descriptor return zeros (no clamps)
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.W) + (size_t)(nt < a.NT ? nt : a.NT - 1) * a.KB * 256, 0, a.KB * 1024, 0x00020000);
+  const int wvo = lane * 16;
+  // staging role of this thread: rows sr + 16 WM p (p = 0..NP-1), 4 floats at column sc of the step's 64
+  const int sr = tid >> 4, sc = (tid & 15) * 4;
+  const int trows = a.rows - by * 64 < 64 ? a.rows - by * 64 : 64;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X) + (size_t)by * 64 * a.ldx, 0, trows * a.ldx * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? a.XT : a.X) + (size_t)by * 64 * a.ldx, 0, trows * a.ldx * 4, 0x00020000);
+  int xvo[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) xvo[p] = ((sr + 16 * WM * p) * a.ldx + sc) * 4;
+  const int NS = a.KB >> 2, NST = DUAL ? a.KBT >> 2 : 0;       // steps (an even number); steps that carry tangent rows (the first NST)
+  // Prefetch distances: the activation tile TWO steps ahead (two register sets: tile t waits in set t & 1 until it is written
+  // to LDS at the start of step t - 1), the weights SEVEN k-blocks ahead (ring of eight).  One step is 2,048 MFMA cycles
+  // (~0.9 us): the first workgroup of an XCD to touch a line waits for HBM / MALL, not for L2.
+  f32x4 xr[2][NP], tr[2][NP];
+  auto gload = [&](int st, auto setc) {
+    constexpr int S = decltype(setc)::value;
+    const int sx = st < NS ? st : NS - 1;                       // (a row is ldx wide: the next row's data, not zeros, lies past K)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) xr[S][p] = wide_bload(xrs, xvo[p], sx * 256);
+    if constexpr (DUAL) {
+      const int stt = st < NST ? st : NST - 1;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) tr[S][p] = wide_bload(trs, xvo[p], stt * 256);
+    }
+  };
+  auto swrite = [&](int buf, auto setc) {
+    constexpr int S = decltype(setc)::value;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(&Xs[buf][sr + 16 * WM * p][sc]) = xr[S][p];
+    if constexpr (DUAL) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(&Ts[buf][sr + 16 * WM * p][sc]) = tr[S][p];
+    }
+  };
+  struct XF { f32x4 x[MTW], t[MTW]; };
+  auto fread = [&](XF& f, int buf, int kbl) {
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) f.x[m] = *reinterpret_cast<const f32x4*>(&Xs[buf][16 * (wm * MTW + m) + c][16 * kbl + 4 * g]);
+    if constexpr (DUAL) {
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) f.t[m] = *reinterpret_cast<const f32x4*>(&Ts[buf][16 * (wm * MTW + m) + c][16 * kbl + 4 * g]);
+    }
+  };
+  f32x4 acc[1][MTW], acT[1][MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) { acc[0][m] = f32x4{0.f, 0.f, 0.f, 0.f}; acT[0][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  auto mac = [&](const f32x4& w, const XF& f, bool with_t) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], f.x[m][s], acc[0][m], 0, 0, 0);
+    if constexpr (DUAL) {
+      if (with_t) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) acT[0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], f.t[m][s], acT[0][m], 0, 0, 0);
+      }
+    }
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  f32x4 w[8];
+  XF xf[2];
+#ifdef WIDE_DBG_CLOCK
+  const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // request order = the order the loop consumes in (the compiler's counted waits merge the loop entry with the back edge)
+  gload(0, C0{});
+  swrite(0, C0{});
+  gload(1, C1{});
+  gload(2, C0{});
+#pragma unroll
+  for (int j = 0; j < 7; ++j) w[j] = wide_bload(wr, wvo, j * 1024);
+  WIDE_PIN();
+  __syncthreads();
+  fread(xf[0], 0, 0);
+  asm volatile("" ::: "memory");       // (as in WIDE_PIN: keeps this read and the read-ahead of the loop's last block two loads)
+  auto step = [&](int st, auto pc) {
+    constexpr int P = decltype(pc)::value;                     // st & 1: LDS buffer of tile st, register set of tile st + 2
+    const bool tt = DUAL && st < NST;
+#ifndef WIDE_DBG_NO_X
+    swrite(P ^ 1, std::integral_constant<int, P ^ 1>{});       // tile st + 1 (requested two steps ago)
+    gload(st + 3, std::integral_constant<int, P ^ 1>{});
+#endif
+    WIDE_PIN();
+#pragma unroll
+    for (int kbl = 0; kbl < 4; ++kbl) {
+#ifndef WIDE_DBG_NO_BARRIER
+      if (kbl == 3) __syncthreads();
+#endif
+      // One k-block: MTW MFMAs per k-sub-step s, and ONE memory instruction after each group -- the weight request after the
+      // first, one fragment read of the NEXT block after each.  Issued in a cluster at the block boundary they cost the matrix
+      // pipe ~120 cycles per block (a wave issues in order and the pipe holds one MFMA: five memory instructions between two
+      // MFMAs drain it); spread out, each one issues in the shadow of the MFMA before it.
+      const f32x4& wk = w[4 * P + kbl];
+      const XF& fc = xf[kbl & 1];
+      XF& fn = xf[(kbl + 1) & 1];
+      const int nbuf = kbl < 3 ? P : P ^ 1, nk = (kbl + 1) & 3;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[s4], fc.x[m][s4], acc[0][m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef WIDE_DBG_NO_W
+        if (s4 == 0) w[(4 * P + kbl + 7) & 7] = wide_bload(wr, wvo, (4 * st + kbl + 7) * 1024);
+#endif
+#ifndef WIDE_DBG_NO_FREAD
+        if (s4 < MTW) fn.x[s4] = *reinterpret_cast<const f32x4*>(&Xs[nbuf][16 * (wm * MTW + s4) + c][16 * nk + 4 * g]);
+#endif
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (DUAL) {
+        if (tt) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) acT[0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[s4], fc.t[m][s4], acT[0][m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s4 < MTW) fn.t[s4] = *reinterpret_cast<const f32x4*>(&Ts[nbuf][16 * (wm * MTW + s4) + c][16 * nk + 4 * g]);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+  };
+  for (int st = 0; st < NS; st += 2) { step(st, C0{}); step(st + 1, C1{}); }
+#ifdef WIDE_DBG_CLOCK
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    wide_dbg_clk[0] = __builtin_readcyclecounter() - dbg_c0; wide_dbg_clk[1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+  }
+#endif
+  gemm_epilogue<MTW, 1>(a, acc, acT, mt0, nt, MT, g, c);
+}
+
 static void launch_gemm(const Gemm& a, hipStream_t s) {
   const bool dual = a.XT != nullptr;
   const int MT = a.rows / 16;
@@ -163,8 +369,24 @@ static void launch_gemm(const Gemm& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<4, 2, false>), grid, dim3(256), 0, s, a);
   } else {
     dim3 grid((a.NT + 3) / 4, (MT + 3) / 4);
-    if (dual) hipLaunchKernelGGL((gemm_kernel<2, 2, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<2, 2, false>), grid, dim3(256), 0, s, a);
+    // the LDS-staged kernel needs an even number of whole 64-wide K steps (every width of the reference's pines networks); MFM_WIDE_NOLDS=1
+    // keeps the register-only kernel for A/B measurements
+    static const bool no_lds = getenv("MFM_WIDE_NOLDS") != nullptr;
+    const bool lds = !no_lds && (a.KB & 7) == 0 && (!dual || ((a.KBT & 3) == 0 && a.KBT >= 4));
+    static const bool wm2 = getenv("MFM_WIDE_WM1") == nullptr;    // eight waves (two per SIMD) by default: 37.0 k vs 40.6 k cycles on 1024^3
+    if (lds && wm2) {
+      if (dual) hipLaunchKernelGGL((gemm_lds_kernel<true, 2>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gemm_lds_kernel<false, 2>), grid, dim3(512), 0, s, a);
+    } else if (lds) {
+      if (dual) hipLaunchKernelGGL((gemm_lds_kernel<true, 1>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_lds_kernel<false, 1>), grid, dim3(256), 0, s, a);
+    } else if (dual) {
+      if (a.KB % 8 == 0 && a.KBT % 8 == 0 && getenv("MFM_WIDE_RING8")) hipLaunchKernelGGL((gemm_kernel<2, 2, true, 8>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_kernel<2, 2, true>), grid, dim3(256), 0, s, a);
+    } else {
+      if (a.KB % 8 == 0 && getenv("MFM_WIDE_RING8")) hipLaunchKernelGGL((gemm_kernel<2, 2, false, 8>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_kernel<2, 2, false>), grid, dim3(256), 0, s, a);
+    }
   }
 }
 
@@ -177,23 +399,29 @@ struct WgArgs { WgLayer L[MLP_NLAYER]; const WgJob* jobs; int n_jobs; int rows; 
                 int* bad; };   // non-null: raise *bad when a gradient element is not finite (the optimizer's apply_if_finite check)
 
 __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
   const int job = blockIdx.x * 4 + wave;
   if (job >= a.n_jobs) return;
-  const WgJob J = a.jobs[job];
-  const WgLayer& L = a.L[J.layer];
+  // The job and its layer descriptor are wave-uniform: read them as scalars ONCE.  Indexing the kernel-argument array with a
+  // per-lane value made the compiler re-read `lda` / `ldz` from memory -- and wait with vmcnt(0) -- in front of every operand
+  // load of the loop (round 1: 28 % MFMA occupancy).
+  const int jl = __builtin_amdgcn_readfirstlane(a.jobs[job].layer), jkt = __builtin_amdgcn_readfirstlane(a.jobs[job].kt),
+            jnt = __builtin_amdgcn_readfirstlane(a.jobs[job].nt);
+  struct { int layer, kt, nt; } J = {jl, jkt, jnt};
+  const WgLayer L = a.L[jl];
+  const int lda = L.lda, ldz = L.ldz, rows = a.rows;
   const int ac = 64 * J.kt + 4 * c, zc = 64 * J.nt + 4 * c;
   const bool av = ac < L.Kp, zv = zc < L.Np;
-  const float* ap = L.A + (size_t)g * L.lda + (av ? ac : 0);
-  const float* zp = L.Z + (size_t)g * L.ldz + (zv ? zc : 0);
+  // lanes beyond the padded widths read column 0 (valid memory): what they accumulate lands in rows / columns of the 64 x 64
+  // block that are never stored (an MFMA keeps the M rows and the N columns of its operands apart)
+  const float* ap = L.A + (size_t)g * lda + (av ? ac : 0);
+  const float* zp = L.Z + (size_t)g * ldz + (zv ? zc : 0);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[4][4], bs = zero;
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[s][u] = zero;
-  auto lda_ = [&](int r) { return av ? *reinterpret_cast<const f32x4*>(ap + (size_t)r * L.lda) : zero; };
-  auto ldz_ = [&](int r) { return zv ? *reinterpret_cast<const f32x4*>(zp + (size_t)r * L.ldz) : zero; };
   auto mac = [&](const f32x4& af, const f32x4& zf) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -201,17 +429,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
       for (int u = 0; u < 4; ++u) acc[s][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], zf[u], acc[s][u], 0, 0, 0);
     bs += zf;
   };
-  // rows is a multiple of 16: four steps of 4 chains per iteration, loads of the next iteration issued first
-  f32x4 a0 = lda_(0), a1 = lda_(4), a2 = lda_(8), a3 = lda_(12), z0 = ldz_(0), z1 = ldz_(4), z2 = ldz_(8), z3 = ldz_(12);
-  for (int r = 0; r < a.rows; r += 16) {
-    f32x4 na0 = zero, na1 = zero, na2 = zero, na3 = zero, nz0 = zero, nz1 = zero, nz2 = zero, nz3 = zero;
-    if (r + 16 < a.rows) {
-      na0 = lda_(r + 16); na1 = lda_(r + 20); na2 = lda_(r + 24); na3 = lda_(r + 28);
-      nz0 = ldz_(r + 16); nz1 = ldz_(r + 20); nz2 = ldz_(r + 24); nz3 = ldz_(r + 28);
-    }
-    mac(a0, z0); mac(a1, z1); mac(a2, z2); mac(a3, z3);
-    a0 = na0; a1 = na1; a2 = na2; a3 = na3; z0 = nz0; z1 = nz1; z2 = nz2; z3 = nz3;
+  // rows is a multiple of 16: four steps of 4 chains per 16-row block.  Two operand sets in ping-pong (no register copies
+  // at the end of an iteration: a copy would wait for the request just issued): the block after the one being multiplied is
+  // requested first, unconditionally (the last request re-reads valid rows), so the wait in front of the MFMAs is a counted one
+  struct Set { f32x4 a[4], z[4]; };
+  auto request = [&](Set& q, int r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q.a[i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(r + 4 * i) * lda);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q.z[i] = *reinterpret_cast<const f32x4*>(zp + (size_t)(r + 4 * i) * ldz);
+  };
+  auto macs = [&](const Set& q) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mac(q.a[i], q.z[i]);
+  };
+  Set q0, q1;
+  request(q0, 0);
+  WIDE_PIN();
+  int r = 0;
+  for (; r + 32 <= rows; r += 32) {
+    request(q1, r + 16);
+    WIDE_PIN();                        // see gemm_kernel: keeps the requests one block ahead of their use
+    macs(q0);
+    request(q0, r + 32 < rows ? r + 32 : r + 16);
+    WIDE_PIN();
+    macs(q1);
   }
+  if (r < rows) macs(q0);              // odd number of 16-row blocks
   // acc[s][u][i] = dW[64 kt + 4 (4 g + i) + s][64 nt + 4 c + u]
   float* gw = a.grads + L.m_w;
   const bool vec = (L.N & 3) == 0;
