@@ -21,7 +21,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, float a0, float 
           if (q & 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v0) : "v"(v2)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(v1) : "v"(v3));
         }
 #pragma unroll
-        for (int q = 0; q < NS; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(s0));
+        for (int q = 0; q < NS; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(s0) : : "scc");
       }
   }
   f32x4 r = acc[0];
