@@ -107,7 +107,14 @@ __device__ __forceinline__ void layer_gemm(const float* A, int lda, const float*
   const float* arow = A + r * lda + 4 * g;
   for (int q = 0; wave + NW * q < NT; ++q) {
     const int nt = wave + NW * q;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(Wp_) + (size_t)nt * KB * 64 + lane;
+    // the tile's packed fragments through a buffer descriptor: the per-lane offset is a loop constant and the k-block a SCALAR
+    // offset, so no vector address arithmetic sits between the MFMAs (a vector instruction of the wave's own stream is not
+    // free next to its MFMAs: tools/mb/mfma_coissue.hip); the tile index is wave-uniform (made a scalar here: a descriptor
+    // built from a per-lane value is loaded under a waterfall loop); reads past the tile's last block return zeros
+    const int nt_s = __builtin_amdgcn_readfirstlane(nt), kb_s = __builtin_amdgcn_readfirstlane(KB);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wp_) + (size_t)nt_s * kb_s * 256, 0, kb_s * 1024, 0x00020000);
+    const int wvo = lane * 16;
+    auto wload = [&](int kb) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, wvo, kb * 1024, 0)); };
     const float bv = bias ? bias[nt * 16 + (lane & 15)] : 0.f;   // issued ahead of the K loop: its latency hides there
     f32x4 acc[MT];
 #pragma unroll
@@ -133,25 +140,25 @@ __device__ __forceinline__ void layer_gemm(const float* A, int lda, const float*
     f32x4 ba[4], bb[4];
     if (KG > 0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) ba[u] = wp[(size_t)u * 64];
+      for (int u = 0; u < 4; ++u) ba[u] = wload(u);
     }
     int gi = 0;
     for (; gi + 1 < KG; gi += 2) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) bb[u] = wp[(size_t)(4 * gi + 4 + u) * 64];
+      for (int u = 0; u < 4; ++u) bb[u] = wload(4 * gi + 4 + u);
       __builtin_amdgcn_sched_barrier(0);
       group(ba, 4 * gi);
       __builtin_amdgcn_sched_barrier(0);
       if (gi + 2 < KG) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ba[u] = wp[(size_t)(4 * gi + 8 + u) * 64];
+        for (int u = 0; u < 4; ++u) ba[u] = wload(4 * gi + 8 + u);
       }
       __builtin_amdgcn_sched_barrier(0);
       group(bb, 4 * gi + 4);
     }
     if (gi < KG) group(ba, 4 * gi);
     for (int kb = 4 * KG; kb < KB; ++kb) {          // tail (KB not a multiple of 4: tiny layers only)
-      const f32x4 bf = wp[(size_t)kb * 64];
+      const f32x4 bf = wload(kb);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(arow + m * 16 * lda + kb * 16);
@@ -165,7 +172,7 @@ __device__ __forceinline__ void layer_gemm(const float* A, int lda, const float*
     // vmcnt(0) across the loop back-edge) only ever covers loads issued a whole group (>= 12 MT MFMAs) earlier.
     f32x4 cur[4], nxt[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) cur[u] = wp[(size_t)(u < KB ? u : 0) * 64];
+    for (int u = 0; u < 4; ++u) cur[u] = wload(u);
     for (int kb0 = 0; kb0 < KB; kb0 += 4) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -184,8 +191,7 @@ __device__ __forceinline__ void layer_gemm(const float* A, int lda, const float*
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            const int kn = kb0 + 4 + v;
-            nxt[v] = wp[(size_t)(kn < KB ? kn : 0) * 64];
+            nxt[v] = wload(kb0 + 4 + v);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
