@@ -103,7 +103,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   }
   const NetDev& n = nloc;
   const FmLds L = fm_lds_layout(n, TRAIN);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
   const int bb = blockIdx.x, b0 = bb * 16, nbb = a.B / 16;
   const int d = n.d;
 
@@ -432,7 +432,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_eval64_kernel(FmArgs a
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const NetDev& n = a.net;
   const FmEvalLds L = fm_eval_lds_layout(n);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * 64, d = n.d;
   constexpr int NT_ = MLP_WAVES_FM * 64;
   float* bA = lds + L.a; float* bB = lds + L.b; float* bC = lds + L.c; float* bX = lds + L.x; float* bG = lds + L.g;
@@ -638,7 +638,7 @@ __device__ __forceinline__ int wgrad_z_tile(const WsLayout& w, int layer, int nt
 constexpr int WG_BB = MFM_WG_BB;                           // chain tiles per LDS stage
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   __shared__ f32x4 sh[2][WG_BB][8][64];                   // [stage][chain tile][A0..A3, Z0..Z3][lane]: 32 KB
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
   const int wk = wave >> 1, wn = wave & 1;
   if (a.flag_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.flag_reset = 0;
   const WgradJob J = a.jobs[blockIdx.x];

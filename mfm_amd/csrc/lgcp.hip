@@ -23,7 +23,7 @@ struct LgcpArgs {
 template <int TPW>
 __global__ __launch_bounds__(LGCP_NW * 64) void mala_lgcp_kernel(LgcpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
   const int d = a.T.dim, dp = a.dp, ld = dp + 4, b0 = blockIdx.x * 16;
   float* bU = lds;                                   // [16][ld] proposal positions
   double* red = reinterpret_cast<double*>(lds + 16 * ld);   // [3][LGCP_NW][16]

@@ -877,7 +877,7 @@ __device__ __forceinline__ void fill_probe(OdeTile<TPW, NW>& T, const float* z, 
 template <int TPW, int NW>
 __device__ __forceinline__ void tile_init(OdeTile<TPW, NW>& T, const NetDev* n, float* lds, bool hutch) {
   T.n = n; T.L = ode_lds_layout(*n, NW); T.lds = lds;
-  T.lane = threadIdx.x & 63; T.wave = threadIdx.x >> 6; T.g = T.lane >> 4; T.c = T.lane & 15;
+  T.lane = threadIdx.x & 63; T.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); T.g = T.lane >> 4; T.c = T.lane & 15;
   T.hutch = hutch; T.exact = false; T.sign = 1;
   for (int i = threadIdx.x; i < T.L.total; i += (NW * 64)) lds[i] = 0.f;     // pads, tangent rows of st, scratch
 #pragma unroll

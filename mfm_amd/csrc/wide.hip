@@ -95,7 +95,7 @@ __device__ __forceinline__ void gemm_epilogue(const Gemm& a, f32x4 (&acc)[NTW][M
 
 template <int MTW, int NTW, bool DUAL, int RING = 4>
 __global__ __launch_bounds__(256) void gemm_kernel(Gemm a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
   const int mt0 = (blockIdx.y * 2 + (wave >> 1)) * MTW, nt0 = (blockIdx.x * 2 + (wave & 1)) * NTW;
   const int MT = a.rows >> 4;
   if (mt0 >= MT || nt0 >= a.NT) return;                       // no barriers in this kernel
