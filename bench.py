@@ -181,7 +181,8 @@ def pmc_traffic(kernel_class, workload="phi-four"):
     same command, tools/prof_round.sh): 2 * FETCH_SIZE + WRITE_SIZE, both reported in KB; the factor 2 is the gfx950
     correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section).  None when no summary is present."""
     files = {"phi-four": ("profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"),       # newest committed summary first
-             "gaussian-mixture": ("profiles/r02_gmm_pmc_summary.json",), "pines": ("profiles/r02_pines_pmc_summary.json",)}.get(workload, ())
+             "gaussian-mixture": ("profiles/r02_gmm_pmc_summary.json",), "4-mode": ("profiles/r02_4mode_pmc_summary.json",),
+             "pines": ("profiles/r02_pines_pmc_summary.json",)}.get(workload, ())
     pattern = {"fm_eval": "fm_eval64"}.get(kernel_class, kernel_class)
     if workload == "pines":
         return None, None      # its roofline entry is the whole training step (many launches): per-kernel traffic is in the summary file

@@ -221,7 +221,9 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
                                   "the exact trace needs dim tangent passes per evaluation");
   }
   const int nbb = c.n_chain_local / 16;
-  x->split = nbb < 8 ? nbb : 8;         // chain slices of the weight-gradient GEMM: 8 measured best at 4096 x 256 (wgrad + slab reduction 36.9 us against 41.4 at 16)
+  x->split = nbb < 8 ? nbb : 8;
+  if (const char* e = getenv("MFM_WGRAD_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= nbb) x->split = v; }      // development: A/B
+  // chain slices of the weight-gradient GEMM: 8 measured best at 4096 x 256 (wgrad + slab reduction 36.9 us against 41.4 at 16)
   x->loss_cap = (c.max_eval_samples > c.n_chain_local ? c.max_eval_samples : c.n_chain_local) / 16 + 1;
   // wgrad job table
   std::vector<WgradJob> jobs;
@@ -659,7 +661,6 @@ extern "C" int mfm_debug_replay(mfm_ctx* x, int cap, const float* d_dt, const ui
   if (!x) return fail(MFM_EINVAL, "null ctx");
   if (!d_dt) { memset(&x->replay, 0, sizeof x->replay); return MFM_OK; }          // disarm
   if (!d_acc || !d_ratio || !d_dt_own || cap < 2) return fail(MFM_EINVAL, "mfm_debug_replay needs all four arrays and cap >= 2");
-  if (x->wide) return fail(MFM_EUNSUPPORTED, "the wide kernel family (host-driven Dopri5) has no replay instrumentation");
   x->replay.dt = d_dt; x->replay.acc = d_acc; x->replay.ratio = d_ratio; x->replay.dt_own = d_dt_own; x->replay.cap = cap; x->replay.n = 0; x->replay.diag = d_diag;
   return MFM_OK;
 }
@@ -695,7 +696,8 @@ extern "C" int mfm_ode_transform(mfm_ctx* x, int direction, int per_chain, const
   a.rp = x->replay; a.rp.n = n; memset(&x->replay, 0, sizeof x->replay);      // one-shot
   if (x->wide) {
     launch_probe(per_chain ? 0 : 1, d_keys, a.key, 0, 0, 0, n, x->net.d, const_cast<float*>(a.z1), x->stream);
-    const int rcw = wide::transform(x->wide, x->net, direction, a.rtol, a.atol, a.max_attempts, a.z1, d_in, n, d_out, d_ldj, d_nsteps, x->stream);
+    wide::WReplay wr{a.rp.dt, a.rp.acc, a.rp.ratio, a.rp.dt_own, a.rp.cap, a.rp.n, 0, 0, nullptr};
+    const int rcw = wide::transform(x->wide, x->net, direction, a.rtol, a.atol, a.max_attempts, a.z1, d_in, n, d_out, d_ldj, d_nsteps, x->stream, wr);
     if (rcw) return fail(rcw, "wide ODE transform failed: %s", hipGetErrorString(hipGetLastError()));
     LAUNCHCHK();
     tally_solves(x, d_nsteps, n, 1);
@@ -750,6 +752,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
       c.mode = mode; c.key = f.key; c.n_total = f.n_total; c.chain_offset = f.chain_offset; c.beta = beta; c.rows = a.n; c.ref_std = f.ref_std;
       c.rtol = a.rtol; c.atol = a.atol; c.max_attempts = a.max_attempts; c.z_inv = a.z1; c.z_fwd = a.z2; c.zgen = a.zgen;
       c.pos = d_pos; c.logp = d_logp; c.grad = d_grad; c.acc_prob = d_acc; c.accepted = d_isacc; c.proposed = d_prop; c.nsteps = d_nsteps;
+      c.rp = wide::WReplay{a.rp.dt, a.rp.acc, a.rp.ratio, a.rp.dt_own, a.rp.cap, a.rp.n, 0, 0, a.rp.diag};
       const int rcw = wide::flow_step(x->wide, x->net, c, x->stream);
       if (rcw) return fail(rcw, "wide flow step failed: %s", hipGetErrorString(hipGetLastError()));
     } else {

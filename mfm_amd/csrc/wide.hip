@@ -641,6 +641,14 @@ __device__ static const float W_M[7] = {(float)(6025192743.0 / 30085553152.0 / 2
                                         (float)(-2691868925.0 / 45128329728.0 / 2), (float)(187940372067.0 / 1594534317056.0 / 2),
                                         (float)(-1776094331.0 / 19743644256.0 / 2), (float)(11237099.0 / 235043384.0 / 2)};
 
+// Parity instrumentation (mfm_debug_replay): the solve runs on a PRESCRIBED step sequence and records its own controller's
+// values; same meaning as `Replay` in ode.hip (dt == nullptr: off, production).
+struct WReplay {
+  const float* dt; const uint8_t* acc; float* ratio; float* dt_own; int cap, n, solve, row0;
+  double* diag;             // flow step only, may be null: [n][4] as in ode.hip
+  __device__ __forceinline__ size_t at(int row, int j) const { return ((size_t)solve * n + row0 + row) * cap + j; }
+};
+
 struct OdeBuf {
   int rows, d, dp, F, F2p, sign;
   float rtol, atol; int max_attempts;
@@ -653,6 +661,7 @@ struct OdeBuf {
   const float* fourier;
   const float* out; const float* outT; const float* gate; const float* gc; const float* hz;   // results of the evaluation
   int* n_active;
+  WReplay rp;
 };
 
 // stage input of phase p: X = y + h sum_j TAB[p][j] k_j, Fourier features of the stage time (:70-71, :229)
@@ -732,7 +741,8 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
       const float a2 = (dl - a.rs.kl[b]) / atol;
       const float d2 = sqrtf(p2 + a2 * a2) / h0;
       const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
-      const float dt = fminf(100.f * h0, h1);
+      float dt = fminf(100.f * h0, h1);
+      if (a.rp.dt) { const size_t o = a.rp.at(b, 0); a.rp.dt_own[o] = dt; dt = a.rp.dt[o]; }
       a.rs.dt[b] = dt;
       if (dt > 0.f) atomicAdd(a.n_active, 1);
     }
@@ -766,10 +776,17 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
     const float tol = atol + rtol * fmaxf(fabsf(ell0), fabsf(l1));
     const float rr = el / tol;
     const float ratio = sqrtf((e2 + rr * rr) / (float)(a.d + 1));
-    const bool acc = active && ratio <= 1.f;
+    bool acc = active && ratio <= 1.f;
     const float dfac = ratio < 1.f ? 1.f : 0.2f;
     const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
-    const float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+    float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+    if (a.rp.dt && active) {               // every lane of the wavefront takes the same (uniform) decision
+      const bool in = na < a.rp.cap, nx = na + 1 < a.rp.cap;
+      const size_t o = a.rp.at(b, in ? na : 0);
+      if (lane == 0 && in) { a.rp.ratio[o] = ratio; if (nx) a.rp.dt_own[o + 1] = ndt; }
+      acc = in && a.rp.acc[o] != 0;
+      ndt = nx ? a.rp.dt[o + 1] : 0.f;
+    }
     float t_n = t0, ell_n = ell0, kl0_n = kl[0];
     int dn_n = dn;
     if (acc) {
@@ -862,6 +879,7 @@ struct FlowGlue {
   float* vol0; float* lqref; int* natt_tot; const int* natt;
   const float* KV;           // LGCP: K^-1 (x' - mu)
   float* pos; double* logp; float* grad; float* acc_prob; uint8_t* accepted; float* proposed; int* nsteps;
+  double* diag;              // replay instrumentation (may be null)
 };
 // after the inverse solve: keep vol0, build the latent proposal (:268 random walk / :249 independent)
 __global__ __launch_bounds__(256) void flow_propose_kernel(FlowGlue a) {
@@ -934,6 +952,7 @@ __global__ __launch_bounds__(256) void flow_accept_kernel(FlowGlue a) {
     if (a.acc_prob) a.acc_prob[b] = (float)ap;
     if (a.accepted) a.accepted[b] = acc ? 1 : 0;
     if (a.nsteps) a.nsteps[b] = a.natt_tot[b] + a.natt[b];
+    if (a.diag) { double* o = a.diag + 4 * (size_t)b; o[0] = a.vol0[b]; o[1] = a.ell[b]; o[2] = lpn; o[3] = la; }
   }
 }
 
@@ -1224,7 +1243,7 @@ static void field_eval(Ctx* w, const NetDev& n, const float* X, bool tangent, bo
   x_branch(w, n, X, tangent, rows, s);
 }
 
-struct SolveArgs { int sign; float rtol, atol; int max_attempts; int rows; };
+struct SolveArgs { int sign; float rtol, atol; int max_attempts; int rows; WReplay rp; };
 
 // Integrate rows of w->Y (padded [rows][dp]) from t = 0 to 1 with the probe in w->zp; results: w->Y, w->rs.ell, w->rs.natt.
 // Synchronises the stream once per attempted step (4-byte read-back of the number of rows still integrating).
@@ -1234,6 +1253,7 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
   o.rows = rows; o.d = n.d; o.dp = n.dp; o.F = n.F; o.F2p = n.F2p; o.sign = c.sign; o.rtol = c.rtol; o.atol = c.atol; o.max_attempts = c.max_attempts;
   o.rs = w->rs; o.Y = w->Y; o.K = w->K; o.X = xstage; o.Z = w->zp; o.ffat = w->ffat; o.fourier = n.fourier;
   o.out = w->out; o.outT = w->outT; o.gate = w->gate; o.gc = w->gc; o.hz = w->hz; o.n_active = w->n_active;
+  o.rp = c.rp;
   hipLaunchKernelGGL(ode_init_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, w->rs, rows);
   if (hipMemsetAsync(w->K, 0, (size_t)7 * rows * n.dp * sizeof(float), s) != hipSuccess) return -4;
   probe_setup(w, n, rows, s);
@@ -1274,12 +1294,13 @@ static void unpad_rows(const float* src, int n, int d, int dp, float* dst, hipSt
 
 // transform_and_logdet / inverse_and_logdet (:206-242) on n samples, R rows per pass.  z: Hutchinson probes [n][d].
 static int transform(Ctx* w, const NetDev& n, int direction, float rtol, float atol, int max_attempts, const float* z, const float* in,
-                     int cnt, float* out, float* ldj, int* nsteps, hipStream_t s) {
+                     int cnt, float* out, float* ldj, int* nsteps, hipStream_t s, WReplay rp = WReplay{}) {
   for (int r0 = 0; r0 < cnt; r0 += w->R) {
     const int rows = cnt - r0 < w->R ? cnt - r0 : w->R;
     pad_rows(in + (size_t)r0 * n.d, rows, n.d, n.dp, w->Y, s);
     pad_rows(z + (size_t)r0 * n.d, rows, n.d, n.dp, w->zp, s);
-    SolveArgs c{direction, rtol, atol, max_attempts, rows};
+    rp.solve = 0; rp.row0 = r0;
+    SolveArgs c{direction, rtol, atol, max_attempts, rows, rp};
     const int rc = solve(w, n, c, w->cond, s);
     if (rc) return rc;
     unpad_rows(w->Y, rows, n.d, n.dp, out + (size_t)r0 * n.d, s);
@@ -1294,6 +1315,7 @@ struct FlowCall {
   float rtol, atol; int max_attempts;
   const float *z_inv, *z_fwd, *zgen;          // [rows][d]: key_hutch2, key_hutch1, key_gen draws (:265 / :247)
   float* pos; double* logp; float* grad; float* acc_prob; uint8_t* accepted; float* proposed; int* nsteps;
+  WReplay rp;
 };
 static int flow_step(Ctx* w, const NetDev& n, const FlowCall& c, hipStream_t s) {
   const int rows = c.rows;
@@ -1306,13 +1328,15 @@ static int flow_step(Ctx* w, const NetDev& n, const FlowCall& c, hipStream_t s) 
   // inverse solve from the current position (:267 / :251)
   pad_rows(c.pos, rows, n.d, n.dp, w->Y, s);
   pad_rows(c.z_inv, rows, n.d, n.dp, w->zp, s);
-  SolveArgs sa{-1, c.rtol, c.atol, c.max_attempts, rows};
+  SolveArgs sa{-1, c.rtol, c.atol, c.max_attempts, rows, c.rp};
+  sa.rp.solve = 0; sa.rp.row0 = 0;
+  f.diag = c.rp.diag;
   int rc = solve(w, n, sa, w->cond, s);
   if (rc) return rc;
   hipLaunchKernelGGL(flow_propose_kernel, dim3(grid4(rows)), dim3(256), 0, s, f);
   // forward solve of the proposal (:269 / :250)
   pad_rows(c.z_fwd, rows, n.d, n.dp, w->zp, s);
-  sa.sign = 1;
+  sa.sign = 1; sa.rp.solve = 1;
   rc = solve(w, n, sa, w->cond, s);
   if (rc) return rc;
   if (n.T.kind == MFM_TARGET_LGCP) launch_gemm(kinv(n, w->Y, w->kv, rows, true), s);
