@@ -226,8 +226,8 @@ int mfm_reset_counters(mfm_ctx* ctx);
  * array is at ((s * n + r) * cap + j), n = samples of the armed call; a zero d_dt entry ends the solve.  Lets two
  * implementations be compared stage for stage on the same step sequence (tests/test_gpu_replay.py); no counterpart in the
  * reference.  d_diag (may be NULL; flow step only): float64 [n][4] = {inverse log-det, forward log-det, tempered log-density
- * at the proposal, log acceptance ratio}, the terms of exe_flow_matching.py:271-274.  d_dt == NULL disarms.  Fused kernel
- * family only (EUNSUPPORTED on the wide family). */
+ * at the proposal, log acceptance ratio}, the terms of exe_flow_matching.py:271-274.  d_dt == NULL disarms.  Both kernel
+ * families (the wide family's host-driven solver takes the same hooks in its row kernels). */
 int mfm_debug_replay(mfm_ctx* ctx, int cap, const float* d_dt, const uint8_t* d_acc, float* d_ratio, float* d_dt_own,
                      double* d_diag);
 

@@ -6,8 +6,9 @@ on the outputs, 5 % on the Hutchinson log-det, |d log alpha| < 0.5).  Here both 
 accept decisions (``mfm_debug_replay`` <-> ``oracle.ode.odeint(replay=...)``): the oracle first runs with its own controller,
 its step sequence is rounded to float32 and then replayed by the oracle (float64 arithmetic) and by the HIP kernels (float32
 arithmetic).  What is compared is the arithmetic itself -- six stage evaluations per attempt, the 5th-order update, the error
-norm, the 4th-order interpolant at t = 1, the log-det -- for the generic solver tile, the shape-specialised solver (``solve``)
-and the flow-step kernel with per-row solve phases and tail compaction (``solve2``), plus the controller's own outputs (error
+norm, the 4th-order interpolant at t = 1, the log-det -- for the generic solver tile, the shape-specialised solver (``solve``),
+the flow-step kernel with per-row solve phases and tail compaction (``solve2``) and the wide family's host-driven solver
+(per-layer GEMM launches + row kernels, wide.hip), plus the controller's own outputs (error
 ratio of every attempt, the step it would have chosen next), attempt by attempt.
 
 Two regimes (numbers: tools/replay_stats*.py on MI355X, profiles/r02_replay_stats.txt):
@@ -77,15 +78,24 @@ def _tamed(model, out_scale=4.0, seed=9):
     return p
 
 
-@pytest.mark.parametrize("d,hidden,F", [(256, 128, 128), (128, 128, 128), (64, 32, 16)])   # shape-specialised solver x2, generic tile
+def _family_kw(fam):
+    from mfm_amd import _lib
+    return dict(family=_lib.FAMILY_WIDE) if fam == "wide" else {}
+
+
+# shape-specialised solver x2, generic tile, and the wide family's host-driven solver (per-layer GEMMs, row kernels) on two shapes
+SHAPES = [(256, 128, 128, None), (128, 128, 128, None), (64, 32, 16, None), (256, 128, 128, "wide"), (64, 48, 16, "wide")]
+
+
+@pytest.mark.parametrize("d,hidden,F,fam", SHAPES)
 @pytest.mark.parametrize("direction", [1, -1])
-def test_transform_on_prescribed_steps_matches_oracle(d, hidden, F, direction):
+def test_transform_on_prescribed_steps_matches_oracle(d, hidden, F, fam, direction):
     import torch
     from tests import gpu_util as gu
     B = 32
     args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=hidden, F=F)
     params = _tamed(model)
-    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, **_family_kw(fam))
     x64 = dist.init_params.astype(np.float32).astype(np.float64)
     keys = prng.split(prng.PRNGKey(21), B)
     fn = ode.transform_and_logdet if direction > 0 else ode.inverse_and_logdet
@@ -112,7 +122,7 @@ def test_transform_on_prescribed_steps_matches_oracle(d, hidden, F, direction):
     assert np.quantile(el, 0.9) < 2e-5 * ls and el.max() < 2e-3 * ls, (np.quantile(el, 0.9), el.max(), ls)
     assert abs((l - l_o).mean()) < 1e-4 * ls                         # no systematic log-det bias
     mr, md = _check_controller_tight(f"d={d} dir={direction}", st_o, ratio.cpu().numpy(), own.cpu().numpy(), n)
-    print(f"replay transform d={d} dir={direction}: attempts {n.mean():.0f}, |dy| {ey.max():.2e}, |dl| {el.max():.2e} (|l| {ls:.1f}), "
+    print(f"replay transform d={d} {fam or 'fused'} dir={direction}: attempts {n.mean():.0f}, |dy| {ey.max():.2e}, |dl| {el.max():.2e} (|l| {ls:.1f}), "
           f"median rel diff: error ratio {mr:.1e}, chosen step {md:.1e}")
     # a replay call is one-shot: the next transform integrates with its own controller again
     ctx.ode_transform(direction, _dev(x64.astype(np.float32)), out, ldj, keys=d_keys, nsteps=ns)
@@ -153,15 +163,15 @@ def _flow_replay_raw(ctx, model, params, args, dist, beta, x32, key, yardstick=F
                 own=own.cpu().numpy(), pos=pos.cpu().numpy(), logp=logp.cpu().numpy())
 
 
-@pytest.mark.parametrize("d,hidden,F", [(256, 128, 128), (128, 128, 128), (64, 32, 16)])      # shape-specialised kernel x2, generic tile
-def test_flow_step_on_prescribed_steps_matches_oracle(d, hidden, F):
+@pytest.mark.parametrize("d,hidden,F,fam", SHAPES)
+def test_flow_step_on_prescribed_steps_matches_oracle(d, hidden, F, fam):
     """Well-conditioned field: inverse solve -> latent proposal -> forward solve -> target -> log acceptance ratio, per chain, on
     the oracle's step sequences.  d = 256 is the shape-specialised kernel (per-row solve phases, tail compaction)."""
     from tests import gpu_util as gu
     B = 32
     args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=hidden, F=F)
     params = _tamed(model, out_scale=2.0)
-    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, **_family_kw(fam))
     r = _flow_replay_raw(ctx, model, params, args, dist, 0.8, dist.init_params.astype(np.float32), prng.PRNGKey(31))
     so, dg, info_o = r["so"], r["diag"], r["info_o"]
     np.testing.assert_array_equal(r["n_g"], r["n_o"])                         # attempt counts of both solves: exact
@@ -171,7 +181,7 @@ def test_flow_step_on_prescribed_steps_matches_oracle(d, hidden, F):
     e_v0, e_vp, e_la = np.abs(dg[:, 0] - so["vol0"]), np.abs(dg[:, 1] - so["volp"]), np.abs(dg[:, 3] - so["log_alpha"])
     mi = _check_controller_tight("inverse", so["inv"], r["ratio"][0], r["own"][0], so["n_att_inv"])
     mf = _check_controller_tight("forward", so["fwd"], r["ratio"][1], r["own"][1], so["n_att_fwd"])
-    print(f"replay flow step d={d}: attempts {r['n_o'].mean():.0f} (max {r['n_o'].max()}), |dx'| {e_p:.2e}, |dvol0| {e_v0.max():.2e}, |dvolp| {e_vp.max():.2e} "
+    print(f"replay flow step d={d} {fam or 'fused'}: attempts {r['n_o'].mean():.0f} (max {r['n_o'].max()}), |dx'| {e_p:.2e}, |dvol0| {e_v0.max():.2e}, |dvolp| {e_vp.max():.2e} "
           f"(scale {vs:.1f}), |d log alpha| med {np.median(e_la):.2e} max {e_la.max():.2e}, controller medians {mi} {mf}")
     assert e_p < 3e-5 * max(1.0, np.abs(info_o.proposed_position).max())     # measured 2.6e-6
     for e in (e_v0, e_vp):
