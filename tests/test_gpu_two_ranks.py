@@ -69,3 +69,43 @@ def test_two_ranks_reproduce_single_process(tmp_path):
     # against the single-process run: the same draws through parameters that differ by float32 summation order
     assert np.abs(z[0]["flow"] - fin1["flow_samples"]).max() < 2e-2
     np.testing.assert_allclose(z[0]["res"][:3], res[:3], rtol=5e-2, atol=1e-3)          # logpdf, KSD U / V of the flow samples
+
+
+def _rccl_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as td
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MFM_COLLECTIVES_AT_WORLD1="1")
+    torch.cuda.set_device(0)
+    td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from mfm_amd import distributions as D, exe_flow_matching as E
+    res, res_, ex = E.run(D.PhiFour(64), _args(64), None, log_every=3, return_extras=True)
+    eng = ex["engine"]
+    assert eng._split_calls                                   # the multi-rank call sequence (deferred AdamW behind the async all-reduce)
+    np.savez(out % rank, metrics=ex["metrics"], pos=ex["states"].position.cpu().numpy(), params=eng.ctx.get_params(),
+             opt=np.array([eng.ctx.opt_state()[k] for k in ("step", "count")]), res=res,
+             idx=ex["final"]["idx"].cpu().numpy(), flow=ex["flow_samples"].cpu().numpy())
+    eng.close()
+    td.destroy_process_group()
+
+
+def test_rccl_call_pattern_on_a_one_rank_communicator(tmp_path):
+    """RCCL refuses two ranks on one device, so what a one-GPU box can check of the backend the 8-GPU runs use is the CALL
+    PATTERN: the multi-rank sequence (separate MALA / loss-gradient calls, the gradient all-reduce issued asynchronously on RCCL's
+    stream, AdamW deferred behind it, all-gathers of the final evaluation) on a one-rank `nccl` communicator.  A sum over one
+    rank is the identity, so the run must reproduce the single-call run bit for bit."""
+    import torch.multiprocessing as mp
+    from mfm_amd import distributions as D, exe_flow_matching as E
+    out = str(tmp_path / "n%d.npz")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    res, res_, ex = E.run(D.PhiFour(64), _args(64), None, log_every=1000, return_extras=True)
+    z = np.load(out % 0)
+    np.testing.assert_array_equal(z["params"], ex["engine"].ctx.get_params())
+    np.testing.assert_array_equal(z["pos"], ex["states"].position.cpu().numpy())
+    np.testing.assert_array_equal(z["metrics"][:, :3], ex["metrics"][:, :3])
+    np.testing.assert_array_equal(z["idx"], ex["final"]["idx"].cpu().numpy())
+    np.testing.assert_array_equal(z["flow"], ex["flow_samples"].cpu().numpy())
+    np.testing.assert_array_equal(z["res"][:4], res[:4])
+    opt = ex["engine"].ctx.opt_state()
+    assert tuple(z["opt"]) == (opt["step"], opt["count"])
+    ex["engine"].close()
