@@ -419,6 +419,8 @@ def main():
                   "iteration_ms_excluding_flow_kernel": round(t_rest, 5), "flow_step_avg_ms": round(flow_ms["ms"] / flow_ms["launches"], 4)}
         par = ("single GPU" + (f" (REHEARSAL: the multi-rank call sequence with its collectives on a one-rank '{backend}' communicator)" if td is not None else "")) if world == 1 else (f"chains sharded x{world}, one gradient all-reduce(SUM) per iteration over torch.distributed backend "
                                                f"'{backend}'" + (" (RCCL over xGMI)" if backend == "nccl" else " (rehearsal backend, NOT RCCL)"))
+        if getattr(eng, "rccl_in_lib", False):
+            par += "; gradient all-reduce inside the library on a context-owned RCCL communicator (mfm_comm_init, MFM_RCCL_IN_LIB=1)"
         out = {
             "metric": f"MFM train-steps/s x chains ({desc[0]})", "value": round(value, 1),
             "unit": "chain-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

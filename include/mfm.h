@@ -123,6 +123,26 @@ int mfm_fm_loss(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const float* d_sampl
  * buffer's contents in between (its own all-reduce, accumulation, clipping) must pass the result through a DIFFERENT buffer
  * (or call on a multi-rank context): any other pointer is checked afresh by the optimizer's own check kernel. */
 int mfm_adamw_step(mfm_ctx* ctx, const float* d_grads);
+
+/* ---- context-owned RCCL communicator for the gradient all-reduce ------------------------------
+ * The reference has no distributed code: its loss sums over ALL chains (exe_flow_matching.py:178) inside one process.  With
+ * the chains sharded over ranks that sum becomes ONE all-reduce(SUM) of the flow-matching gradient per train_step (:362-368),
+ * over RCCL / xGMI.  A host without a collective layer of its own hands the context a communicator:
+ *   rank 0: mfm_comm_unique_id(id) and ships the 128 bytes to the other ranks out of band (a file, a socket, MPI, ...);
+ *   every rank, with its GPU current: mfm_comm_init(ctx, nranks, rank, id)  -- collective (ncclCommInitRank);
+ *   per iteration: mfm_fm_loss_grad(...); mfm_grad_allreduce_begin(ctx, d_grads)  -- asynchronous, on the context's own
+ *     communication stream, ordered after the work queued on the context's stream; the caller may queue the next MALA step
+ *     (which touches neither gradient nor parameters) before mfm_adamw_step(ctx, d_grads), which waits for the all-reduce.
+ *   mfm_adamw_step on a context with a communicator and no all-reduce in flight reduces first (synchronous form).
+ * With more than one rank the apply_if_finite decision is taken on the REDUCED gradient, so every rank decides alike.
+ * RCCL is resolved at run time (dlopen of librccl.so.1, preferring a copy the process already loaded): the library has no
+ * link-time dependency on it and a single-GPU host needs none.  mfm_destroy destroys the communicator.
+ * (The Python host, mfm_amd/engine.py, uses torch.distributed's RCCL backend by default and this path with MFM_RCCL_IN_LIB=1.) */
+#define MFM_COMM_ID_BYTES 128
+int mfm_comm_unique_id(uint8_t out[MFM_COMM_ID_BYTES]);
+int mfm_comm_init(mfm_ctx* ctx, int nranks, int rank, const uint8_t id[MFM_COMM_ID_BYTES]);
+int mfm_comm_destroy(mfm_ctx* ctx);
+int mfm_grad_allreduce_begin(mfm_ctx* ctx, float* d_grads);
 /* host copies of {step, count, notfinite_count, last_applied} and the learning rate logged at :367 */
 int mfm_opt_state(mfm_ctx* ctx, int32_t h_out[4], float* h_last_lr);
 

@@ -63,6 +63,10 @@ _SIGS = {
     "mfm_fm_loss_grad": (C.c_int, [_P, _U32, _U32, _P, _P, _P]),
     "mfm_fm_loss": (C.c_int, [_P, _U32, _U32, _P, C.c_int, C.c_int, C.c_int, _P]),
     "mfm_adamw_step": (C.c_int, [_P, _P]),
+    "mfm_comm_unique_id": (C.c_int, [_P]),
+    "mfm_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "mfm_comm_destroy": (C.c_int, [_P]),
+    "mfm_grad_allreduce_begin": (C.c_int, [_P, _P]),
     "mfm_opt_state": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "mfm_vf_apply": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
     "mfm_ode_transform": (C.c_int, [_P, C.c_int, C.c_int, _P, _U32, _U32, _P, C.c_int, _P, _P, _P]),
@@ -266,6 +270,26 @@ class Context:
     def adamw_step(self, grads):
         self._p()
         _chk(self.lib.mfm_adamw_step(self.h, _ptr(grads, F32)))
+
+    # ---- context-owned RCCL communicator (include/mfm.h: mfm_comm_*) ---------------------------------------------
+    def comm_unique_id(self):
+        """128 bytes from ncclGetUniqueId (rank 0; ship them to the other ranks out of band)."""
+        buf = (C.c_uint8 * 128)()
+        _chk(self.lib.mfm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _chk(self.lib.mfm_comm_init(self.h, int(nranks), int(rank), buf))
+        self.has_comm = True
+
+    def comm_destroy(self):
+        _chk(self.lib.mfm_comm_destroy(self.h))
+        self.has_comm = False
+
+    def grad_allreduce_begin(self, grads):
+        """Asynchronous SUM all-reduce of the gradient on the context's communication stream; the next adamw_step(grads) waits."""
+        _chk(self.lib.mfm_grad_allreduce_begin(self.h, _ptr(grads, F32)))
 
     def opt_state(self):
         self._p()

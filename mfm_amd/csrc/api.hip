@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <dlfcn.h>
+#include <rccl/rccl.h>     // types and enums only: the library is resolved at run time (rccl_api), never linked
 
 #include "mala.hip"
 #include "lgcp.hip"
@@ -77,6 +79,10 @@ struct mfm_ctx {
   int* att_buf; size_t att_cap;   // per-sample attempt counts of the last solve when the caller passed no d_nsteps
   double* beta_out;
   wide::Ctx* wide;             // non-null: the wide kernel family serves the network kernels (wide.hip)
+  // context-owned RCCL communicator for the gradient all-reduce (mfm_comm_init; null: the caller reduces the gradient itself)
+  ncclComm_t comm = nullptr; int comm_nranks = 0;
+  hipStream_t comm_stream = nullptr; hipEvent_t ev_grads = nullptr, ev_comm = nullptr;
+  const float* comm_pending = nullptr;   // gradient buffer whose all-reduce is in flight on comm_stream
 };
 
 struct ProfScope {
@@ -263,6 +269,7 @@ extern "C" int mfm_destroy(mfm_ctx* x) {
                 x->jobs, x->opt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->beta_out,
                 x->d_att, x->att_buf};
   for (void* p : ps) if (p) hipFree(p);
+  (void)mfm_comm_destroy(x);
   ode_ws_free(x->ode);
   wide::destroy(x->wide);
   if (x->noise) {
@@ -567,6 +574,93 @@ extern "C" int mfm_fm_loss(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_
   return fm_common(x, k0, k1, d_samples, n, n_total, offset, false, d_loss);
 }
 
+// ---- RCCL, resolved at run time ------------------------------------------------------------------------------------------
+// The library carries no link-time dependency on RCCL (a host that never calls mfm_comm_* needs none): the first call looks for
+// a copy the process has already loaded (PyTorch ships one under the same soname), then for the system's.
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*);
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+  const char* (*GetErrorString)(ncclResult_t);
+};
+static RcclApi* rccl_api() {
+  static RcclApi api; static int state = 0;
+  if (state == 0) {
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    state = -1;
+    if (h) {
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+      api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+      if (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString) state = 1;
+    }
+  }
+  return state == 1 ? &api : nullptr;
+}
+#define RCCLCHK(call) do { const ncclResult_t r_ = (call); if (r_ != ncclSuccess) return fail(MFM_EHIP, "RCCL: %s", R->GetErrorString(r_)); } while (0)
+
+extern "C" int mfm_comm_unique_id(uint8_t out[MFM_COMM_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == MFM_COMM_ID_BYTES, "ncclUniqueId size");
+  RcclApi* R = rccl_api();
+  if (!R) return fail(MFM_EUNSUPPORTED, "librccl.so.1 cannot be loaded: %s", dlerror());
+  if (!out) return fail(MFM_EINVAL, "null argument");
+  ncclUniqueId id;
+  RCCLCHK(R->GetUniqueId(&id));
+  memcpy(out, &id, sizeof id);
+  return MFM_OK;
+}
+
+extern "C" int mfm_comm_destroy(mfm_ctx* x) {
+  if (!x) return fail(MFM_EINVAL, "null ctx");
+  if (x->comm) {
+    RcclApi* R = rccl_api();
+    (void)hipStreamSynchronize(x->comm_stream);
+    if (R) (void)R->CommDestroy(x->comm);
+    (void)hipEventDestroy(x->ev_grads); (void)hipEventDestroy(x->ev_comm); (void)hipStreamDestroy(x->comm_stream);
+    x->comm = nullptr; x->comm_stream = nullptr; x->ev_grads = x->ev_comm = nullptr; x->comm_pending = nullptr; x->comm_nranks = 0;
+  }
+  return MFM_OK;
+}
+
+extern "C" int mfm_comm_init(mfm_ctx* x, int nranks, int rank, const uint8_t id_bytes[MFM_COMM_ID_BYTES]) {
+  if (!x || !id_bytes) return fail(MFM_EINVAL, "null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(MFM_EINVAL, "bad rank %d of %d", rank, nranks);
+  if (x->comm) return fail(MFM_EINVAL, "the context already owns a communicator (mfm_comm_destroy first)");
+  if ((long long)x->cfg.n_chain_local * nranks != (long long)x->cfg.n_chain_total)
+    return fail(MFM_EINVAL, "n_chain_total (%d) is not nranks (%d) x n_chain_local (%d)", x->cfg.n_chain_total, nranks, x->cfg.n_chain_local);
+  RcclApi* R = rccl_api();
+  if (!R) return fail(MFM_EUNSUPPORTED, "librccl.so.1 cannot be loaded: %s", dlerror());
+  ncclUniqueId id; memcpy(&id, id_bytes, sizeof id);
+  HIPCHK(hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&x->ev_grads, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&x->ev_comm, hipEventDisableTiming));
+  RCCLCHK(R->CommInitRank(&x->comm, nranks, id, rank));
+  x->comm_nranks = nranks;
+  return MFM_OK;
+}
+
+// Starts the SUM all-reduce of the flow-matching gradient over the context's communicator on the context's communication
+// stream, ordered after everything queued on the context's stream so far; returns at once.  Work the caller queues next that
+// touches neither the gradient nor the parameters (the MALA step of the following iteration) overlaps it; the next
+// mfm_adamw_step on the same buffer waits for it.
+extern "C" int mfm_grad_allreduce_begin(mfm_ctx* x, float* d_grads) {
+  if (!x || !d_grads) return fail(MFM_EINVAL, "null argument");
+  if (!x->comm) return fail(MFM_EINVAL, "no communicator (mfm_comm_init)");
+  if (x->comm_pending) return fail(MFM_EINVAL, "an all-reduce is already in flight: apply it with mfm_adamw_step first");
+  RcclApi* R = rccl_api();
+  HIPCHK(hipEventRecord(x->ev_grads, x->stream));
+  HIPCHK(hipStreamWaitEvent(x->comm_stream, x->ev_grads, 0));
+  RCCLCHK(R->AllReduce(d_grads, d_grads, (size_t)x->net.n_params, ncclFloat32, ncclSum, x->comm, x->comm_stream));
+  HIPCHK(hipEventRecord(x->ev_comm, x->comm_stream));
+  x->comm_pending = d_grads;
+  return MFM_OK;
+}
+
 extern "C" int mfm_adamw_step(mfm_ctx* x, const float* d_grads) {
   if (!x || !d_grads) return fail(MFM_EINVAL, "null argument");
   const mfm_config& c = x->cfg;
@@ -579,6 +673,18 @@ extern "C" int mfm_adamw_step(mfm_ctx* x, const float* d_grads) {
   a.max_err = 10;
   a.inline_decide = (x->checked_grads == d_grads) ? 1 : 0;
   x->checked_grads = nullptr;
+  if (x->comm) {
+    // the gradient every rank applies is the SUM over the communicator (exe_flow_matching.py:178 sums over ALL chains): started
+    // earlier by mfm_grad_allreduce_begin, or here
+    if (x->comm_pending != d_grads) {
+      if (x->comm_pending) return fail(MFM_EINVAL, "an all-reduce of another buffer is in flight");
+      const int rc = mfm_grad_allreduce_begin(x, const_cast<float*>(d_grads));
+      if (rc) return rc;
+    }
+    HIPCHK(hipStreamWaitEvent(x->stream, x->ev_comm, 0));
+    x->comm_pending = nullptr;
+    if (x->comm_nranks > 1) a.inline_decide = 0;      // the finite check must see the reduced gradient
+  }
   ProfScope ps_(x, PROF_ADAM);
   launch_adamw(a, x->stream);
   LAUNCHCHK();

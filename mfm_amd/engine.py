@@ -77,8 +77,9 @@ class DeferredAllReduce:
     step (which needs neither the parameters nor the gradient buffer) overlaps the collective; a flow step or the next
     loss/gradient evaluation waits for it.  Without a process group ``submit`` applies immediately."""
 
-    def __init__(self, apply):
+    def __init__(self, apply, begin_in_lib=None):
         self.apply = apply
+        self.begin_in_lib = begin_in_lib     # context-owned communicator (MFM_RCCL_IN_LIB=1): the library starts and awaits the all-reduce
         self.work = None
         self.armed = False
 
@@ -88,7 +89,12 @@ class DeferredAllReduce:
             self.apply()
             return
         self.flush()
-        self.work = [td.all_reduce(t, op=td.ReduceOp.SUM, async_op=True) for t in tensors]
+        if self.begin_in_lib is not None:
+            for t in tensors:
+                self.begin_in_lib(t)         # mfm_grad_allreduce_begin: asynchronous, on the context's communication stream
+            self.work = []
+        else:
+            self.work = [td.all_reduce(t, op=td.ReduceOp.SUM, async_op=True) for t in tensors]
         self.armed = True
 
     def flush(self):
@@ -98,7 +104,7 @@ class DeferredAllReduce:
         for w in self.work:
             w.wait()
         self.work = None
-        self.apply()
+        self.apply()                         # (in-library form: mfm_adamw_step waits for the all-reduce itself)
 
 
 class Engine:
@@ -148,7 +154,16 @@ class Engine:
         self.loss = torch.zeros(1, device=dev, dtype=torch.float64)
         import os
         self._split_calls = bool(os.environ.get("MFM_SPLIT_CALLS")) or _collective(td)   # development: the multi-rank call sequence on one rank
-        self._deferred = DeferredAllReduce(lambda: self.ctx.adamw_step(self.grads))
+        begin = None
+        if os.environ.get("MFM_RCCL_IN_LIB") and _collective(td):
+            # the gradient all-reduce inside the library, on a communicator the context owns (include/mfm.h: mfm_comm_*); the
+            # 128-byte id travels over the process group that is already up (control plane only)
+            ids = [self.ctx.comm_unique_id() if self.rank == 0 else None]
+            td.broadcast_object_list(ids, src=0)
+            self.ctx.comm_init(self.world, self.rank, ids[0])
+            begin = self.ctx.grad_allreduce_begin
+        self.rccl_in_lib = begin is not None
+        self._deferred = DeferredAllReduce(lambda: self.ctx.adamw_step(self.grads), begin)
         self.ctx.before_params = self._deferred.flush
 
     # ---- helpers --------------------------------------------------------------------------------------------

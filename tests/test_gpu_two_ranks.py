@@ -71,16 +71,19 @@ def test_two_ranks_reproduce_single_process(tmp_path):
     np.testing.assert_allclose(z[0]["res"][:3], res[:3], rtol=5e-2, atol=1e-3)          # logpdf, KSD U / V of the flow samples
 
 
-def _rccl_worker(rank, world, port, out):
+def _rccl_worker(rank, world, port, out, in_lib):
     import torch
     import torch.distributed as td
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MFM_COLLECTIVES_AT_WORLD1="1")
+    if in_lib:
+        os.environ["MFM_RCCL_IN_LIB"] = "1"
     torch.cuda.set_device(0)
     td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     from mfm_amd import distributions as D, exe_flow_matching as E
     res, res_, ex = E.run(D.PhiFour(64), _args(64), None, log_every=3, return_extras=True)
     eng = ex["engine"]
     assert eng._split_calls                                   # the multi-rank call sequence (deferred AdamW behind the async all-reduce)
+    assert eng.rccl_in_lib == bool(in_lib)                    # ... through torch.distributed's RCCL backend, or the context's own communicator
     np.savez(out % rank, metrics=ex["metrics"], pos=ex["states"].position.cpu().numpy(), params=eng.ctx.get_params(),
              opt=np.array([eng.ctx.opt_state()[k] for k in ("step", "count")]), res=res,
              idx=ex["final"]["idx"].cpu().numpy(), flow=ex["flow_samples"].cpu().numpy())
@@ -88,16 +91,19 @@ def _rccl_worker(rank, world, port, out):
     td.destroy_process_group()
 
 
-def test_rccl_call_pattern_on_a_one_rank_communicator(tmp_path):
+@pytest.mark.parametrize("in_lib", [0, 1])
+def test_rccl_call_pattern_on_a_one_rank_communicator(tmp_path, in_lib):
     """RCCL refuses two ranks on one device, so what a one-GPU box can check of the backend the 8-GPU runs use is the CALL
     PATTERN: the multi-rank sequence (separate MALA / loss-gradient calls, the gradient all-reduce issued asynchronously on RCCL's
     stream, AdamW deferred behind it, all-gathers of the final evaluation) on a one-rank `nccl` communicator.  A sum over one
-    rank is the identity, so the run must reproduce the single-call run bit for bit."""
+    rank is the identity, so the run must reproduce the single-call run bit for bit.  in_lib = 1: the all-reduce inside the
+    library on a communicator the context owns (mfm_comm_init / mfm_grad_allreduce_begin, ncclAllReduce on the context's
+    communication stream) instead of torch.distributed's."""
     import torch.multiprocessing as mp
     from mfm_amd import distributions as D, exe_flow_matching as E
     out = str(tmp_path / "n%d.npz")
     port = 31500 + os.getpid() % 2000
-    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(1, port + in_lib, out, in_lib), nprocs=1, join=True)
     res, res_, ex = E.run(D.PhiFour(64), _args(64), None, log_every=1000, return_extras=True)
     z = np.load(out % 0)
     np.testing.assert_array_equal(z["params"], ex["engine"].ctx.get_params())
