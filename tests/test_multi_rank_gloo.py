@@ -49,6 +49,19 @@ def _worker(rank, world, port, out):
     d.submit(buf2)                                              # ... but a submit while armed flushes the first one
     d.flush()
     assert len(applied) == 3
+    # the in-library form (context-owned communicator, MFM_RCCL_IN_LIB=1): submit() starts the reduction through the library's
+    # begin call and issues no torch collective; the optimizer step (which awaits the reduction inside the library) runs at flush
+    order = []
+    buf3 = torch.full((3,), float(rank + 1), dtype=torch.float64)
+
+    def begin(t):                                              # stands in for mfm_grad_allreduce_begin
+        order.append("begin"); td.all_reduce(t, op=td.ReduceOp.SUM)
+
+    d2 = engine.DeferredAllReduce(lambda: order.append(("apply", buf3.clone())), begin)
+    d2.submit(buf3)
+    assert order == ["begin"] and d2.armed and d2.work == []
+    d2.flush(); d2.flush()
+    assert len(order) == 2 and order[1][0] == "apply" and torch.equal(order[1][1], torch.full((3,), 3.0, dtype=torch.float64))
     if rank == 0:
         np.savez(out, g=g.numpy(), l=l.numpy(), pos=st.position, beta=beta, m=m.item(), s=s.item(), ll=ll.numpy())
     td.destroy_process_group()
