@@ -519,12 +519,16 @@ struct FTile {
         }
       }
     };
-    if (wave < NW / 2) target_terms();
+#ifndef MFM_TT_MODE
+#define MFM_TT_MODE 0        // 0: waves 0-3 before their x1 job, waves 4-7 after theirs (stagger); 1: every wave before; 2: every wave after
+                             // (same-trajectory A/B, tools/flow_ab.py, round 2: 52.75 / 52.95 / 53.03 ms)
+#endif
+    if (MFM_TT_MODE == 1 || (MFM_TT_MODE == 0 && wave < NW / 2)) target_terms();
     {   // x1: value rows; tangent rows = relu' * (z W_x1)
       f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
       run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(at(o_xa + xsel, 0), wr, W(S::W2, wave, D / 16), W(S::W3, wave, 8), lane, P, Q, acc);
       FSEC(8);
-      if (wave >= NW / 2) target_terms();
+      if (MFM_TT_MODE == 2 || (MFM_TT_MODE == 0 && wave >= NW / 2)) target_terms();
       const float b = bias(S::B2);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
