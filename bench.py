@@ -300,9 +300,9 @@ def main():
     untimed = prep + a.warmup
     count0 = (-(untimed + 1)) % (wl_K + 1)
     total = untimed + a.steps
-    keys = np.empty((total + EXTRA, 2, 2), dtype=np.uint32)  # key plumbing of :433, precomputed off the clock
+    keys = np.empty((total + EXTRA + 1 + wl_K, 2, 2), dtype=np.uint32)  # key plumbing of :433, precomputed off the clock
     ks = key_sample
-    for i in range(total + EXTRA):
+    for i in range(total + EXTRA + 1 + wl_K):
         ks, k_gn, k_step = jr.split(ks, 3)
         keys[i, 0], keys[i, 1] = k_gn, k_step
     natt_sum = torch.zeros(1, device=eng.dev, dtype=torch.float64)
@@ -356,8 +356,16 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
-    ctx.profile(True)                                        # instrumented pass (not part of `value`): every class
-    for extra in range(EXTRA):                               # MALA + training iterations only (a flow count is skipped)
+    # instrumented pass (not part of `value`): every class, on MALA + training iterations in the state the timed ones run in --
+    # after an (uninstrumented) flow step whose tail has produced their draws; without it a timed region that ends with its
+    # cycle leaves these iterations drawing in line (mala_step 38 us instead of 10, the training kernel 65 instead of 43)
+    ctx.profile(False)
+    natt_timed, nflow_timed = natt_sum.clone(), n_flow[0]    # the tallies of the timed region: the flow step below is not part of it
+    count += (wl_K + 1) - count % (wl_K + 1)
+    step(total, count)
+    natt_sum.copy_(natt_timed); n_flow[0] = nflow_timed
+    ctx.profile(True)
+    for extra in range(1, EXTRA + 1):                        # MALA + training iterations only (a flow count is skipped)
         count += 2 if (count + 1) % (wl_K + 1) == 0 else 1
         step(total + extra, count)
     fence()
