@@ -51,18 +51,26 @@ def rwmh_step(keys, prev, value_and_grad, model, params, args, stats=None, repla
     return _accept(kk[:, 1], a, prev, (xp, lpn, gn))                                               # :275-278
 
 
-def imh_step(keys, prev, value_and_grad, model, params, args, stats=None):
-    """``exe_flow_matching.py:246-260``."""
+def imh_step(keys, prev, value_and_grad, model, params, args, stats=None, replay=None):
+    """``exe_flow_matching.py:246-260``.  ``stats`` / ``replay`` as in ``rwmh_step`` (parity instrumentation)."""
     B, d = prev.position.shape
     ref = IndepGaussian(d, var=REF_VARS[getattr(args, "ref_dist", "stdgauss")])
     kk = prng.split_rows(keys, 4)                      # :247
     o = dict(hutch=args.hutchs, rtol=args.rtol, atol=args.atol, mxstep=args.mxstep, n_ts=args.n_ts)
+    st_inv = {} if stats is not None else None
+    st_fwd = {} if stats is not None else None
+    rp = replay or {}
     up = ref.sample_model_rows(kk[:, 0])                                                           # :249
-    xp, volp = ode.transform_and_logdet(model, params, kk[:, 2], up, **o)                          # :250
-    u0, vol0 = ode.inverse_and_logdet(model, params, kk[:, 3], prev.position, **o)                 # :251
+    xp, volp = ode.transform_and_logdet(model, params, kk[:, 2], up, stats=st_fwd, replay=rp.get("fwd"), **o)            # :250
+    u0, vol0 = ode.inverse_and_logdet(model, params, kk[:, 3], prev.position, stats=st_inv, replay=rp.get("inv"), **o)   # :251
     lpn, gn = value_and_grad(xp)                                                                    # :252
+    la = lpn - ref.logprob(up) - volp + ref.logprob(u0) - vol0 - prev.logdensity                  # :253-256
     with np.errstate(over="ignore", invalid="ignore"):
-        a = np.exp(lpn - ref.logprob(up) - volp + ref.logprob(u0) - vol0 - prev.logdensity)        # :253-256
+        a = np.exp(la)
+    if stats is not None:
+        stats["n_att_inv"], stats["n_att_fwd"] = st_inv["n_attempted"], st_fwd["n_attempted"]
+        stats["u0"], stats["vol0"], stats["up"], stats["volp"] = u0, vol0, up, volp
+        stats["inv"], stats["fwd"], stats["log_alpha"] = st_inv, st_fwd, la
     return _accept(kk[:, 1], a, prev, (xp, lpn, gn))
 
 

@@ -131,10 +131,11 @@ def test_transform_on_prescribed_steps_matches_oracle(d, hidden, F, fam, directi
     ctx.close()
 
 
-def _flow_replay_raw(ctx, model, params, args, dist, beta, x32, key, yardstick=False):
+def _flow_replay_raw(ctx, model, params, args, dist, beta, x32, key, yardstick=False, imh=False):
     """One flow-MH step of the kernel and of the oracle on the oracle's (float32-rounded) step sequences."""
     import torch
     from mfm_amd import _lib
+    step_o = flow.imh_step if imh else flow.rwmh_step
     B, d = x32.shape
     vg = targets.Tempered(dist, beta).value_and_grad
     pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
@@ -142,11 +143,11 @@ def _flow_replay_raw(ctx, model, params, args, dist, beta, x32, key, yardstick=F
     st0 = mala.MALAState(x32.astype(np.float64), logp.cpu().numpy(), grad.cpu().numpy().astype(np.float64))
     keys = prng.split(key, B)
     nat = {}
-    flow.rwmh_step(keys, st0, vg, model, params, args, nat)                          # natural run: records both step sequences
+    step_o(keys, st0, vg, model, params, args, nat)                                   # natural run: records both step sequences
     dt, acc = _replay_arrays([nat["inv"], nat["fwd"]])
     rp = dict(inv=dict(dt=dt[0].astype(np.float64), acc=acc[0]), fwd=dict(dt=dt[1].astype(np.float64), acc=acc[1]))
     so = {}
-    new_o, info_o = flow.rwmh_step(keys, st0, vg, model, params, args, so, replay=rp)
+    new_o, info_o = step_o(keys, st0, vg, model, params, args, so, replay=rp)
     s32 = None
     if yardstick:                                                                    # the oracle at float32-rounded stage inputs
         s32 = {}
@@ -157,7 +158,7 @@ def _flow_replay_raw(ctx, model, params, args, dist, beta, x32, key, yardstick=F
     ctx.debug_replay(d_dt, d_acc, ratio, own, diag)
     a = torch.empty(B, device="cuda"); isacc = torch.empty(B, dtype=torch.uint8, device="cuda")
     prop = torch.empty(B, d, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
-    ctx.flow_step(_lib.FLOW_RWMH, key, beta, pos, logp, grad, a, isacc, prop, ns)
+    ctx.flow_step(_lib.FLOW_IMH if imh else _lib.FLOW_RWMH, key, beta, pos, logp, grad, a, isacc, prop, ns)
     return dict(so=so, s32=s32, nat=nat, new_o=new_o, info_o=info_o, n_o=so["n_att_inv"] + so["n_att_fwd"], n_g=ns.cpu().numpy(),
                 diag=diag.cpu().numpy(), prop=prop.cpu().numpy(), isacc=isacc.cpu().numpy().astype(bool), ratio=ratio.cpu().numpy(),
                 own=own.cpu().numpy(), pos=pos.cpu().numpy(), logp=logp.cpu().numpy())
@@ -191,6 +192,41 @@ def test_flow_step_on_prescribed_steps_matches_oracle(d, hidden, F, fam):
     sure = np.abs(so["log_alpha"] - np.log(np.maximum(prng.uniform_rows(prng.split_rows(prng.split(prng.PRNGKey(31), B), 4)[:, 1]), 1e-300))) > 0.1
     np.testing.assert_array_equal(r["isacc"][sure], info_o.is_accepted[sure])
     same = r["isacc"] == info_o.is_accepted
+    np.testing.assert_allclose(r["pos"][same], r["new_o"].position[same], atol=3e-5 * max(1.0, np.abs(r["new_o"].position).max()))
+    ctx.close()
+
+
+@pytest.mark.parametrize("d,hidden,F,fam", [(256, 128, 128, None), (64, 32, 16, None), (256, 128, 128, "wide")])
+def test_independent_mh_flow_step_on_prescribed_steps_matches_oracle(d, hidden, F, fam):
+    """The independent-MH form (exe_flow_matching.py:246-260: proposal from the reference distribution, its density ratio in
+    log alpha) on prescribed steps: shape-specialised kernel, generic tile, wide family."""
+    from tests import gpu_util as gu
+    B = 32
+    args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=hidden, F=F)
+    params = _tamed(model, out_scale=2.0)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, **_family_kw(fam))
+    r = _flow_replay_raw(ctx, model, params, args, dist, 0.8, dist.init_params.astype(np.float32), prng.PRNGKey(37), imh=True)
+    so, dg, info_o = r["so"], r["diag"], r["info_o"]
+    np.testing.assert_array_equal(r["n_g"], r["n_o"])
+    e_p = np.abs(r["prop"] - info_o.proposed_position).max()
+    vs = max(1.0, np.abs(so["vol0"]).max(), np.abs(so["volp"]).max())
+    e_v0, e_vp, e_la = np.abs(dg[:, 0] - so["vol0"]), np.abs(dg[:, 1] - so["volp"]), np.abs(dg[:, 3] - so["log_alpha"])
+    print(f"replay IMH flow step d={d} {fam or 'fused'}: attempts {r['n_o'].mean():.0f}, |dx'| {e_p:.2e}, |dvol0| {e_v0.max():.2e}, |dvolp| {e_vp.max():.2e} "
+          f"(scale {vs:.1f}), |d log alpha| med {np.median(e_la):.2e} max {e_la.max():.2e}")
+    assert e_p < 3e-5 * max(1.0, np.abs(info_o.proposed_position).max())
+    for e in (e_v0, e_vp):
+        assert np.quantile(e, 0.9) < 2e-5 * vs and e.max() < 2e-3 * vs, (np.quantile(e, 0.9), e.max(), vs)
+    # log alpha = log pi(x') - ref.logprob(u') - volp + ref.logprob(u0) - vol0 - log pi(x): its float32 error is dominated by
+    # log pi at an x' that is the flow of a FRESH reference draw, |grad log pi(x')| |dx'| (first order, per chain), plus the
+    # log-dets and |u0| |du0| of the reference density
+    vg = targets.Tempered(dist, 0.8).value_and_grad
+    gn = vg(info_o.proposed_position.astype(np.float64))[1]
+    dxp = np.linalg.norm(r["prop"] - info_o.proposed_position, axis=1)
+    bound = 2.0 * np.linalg.norm(gn, axis=1) * dxp + 1e-4 * vs + 1e-3
+    assert (e_la <= bound).all(), (e_la / bound).max()
+    assert np.median(e_la) < 2e-2, np.median(e_la)
+    same = r["isacc"] == info_o.is_accepted
+    assert same.mean() > 0.9
     np.testing.assert_allclose(r["pos"][same], r["new_o"].position[same], atol=3e-5 * max(1.0, np.abs(r["new_o"].position).max()))
     ctx.close()
 
