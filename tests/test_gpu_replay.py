@@ -71,10 +71,10 @@ def _check_controller_tight(tag, st_o, ratio_g, own_g, natt):
     return float(np.median(rr)), float(np.median(dd))
 
 
-def _tamed(model, out_scale=4.0, seed=9):
+def _tamed(model, out_scale=4.0, seed=9, gate=1e-3):
     from tests import gpu_util as gu
     p = gu.rand_params(model, seed=seed, out_scale=out_scale)
-    p[4]["kernel"] *= 1e-3; p[4]["bias"] *= 1e-3
+    p[4]["kernel"] *= gate; p[4]["bias"] *= gate
     return p
 
 
@@ -228,6 +228,43 @@ def test_independent_mh_flow_step_on_prescribed_steps_matches_oracle(d, hidden, 
     same = r["isacc"] == info_o.is_accepted
     assert same.mean() > 0.9
     np.testing.assert_allclose(r["pos"][same], r["new_o"].position[same], atol=3e-5 * max(1.0, np.abs(r["new_o"].position).max()))
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", ["lgcp-fused", "lgcp-wide", "tanh", "elu"])
+def test_flow_step_on_prescribed_steps_other_targets_and_activations(case):
+    """The same step-for-step comparison for the log-Gaussian Cox target (its K^-1 products: tile GEMM in the fused family, the
+    wide family's GEMM) and for smooth activations on the generic solver tile (no ReLU kinks: no isolated mask events)."""
+    from tests import gpu_util as gu
+    B = 32
+    if case.startswith("lgcp"):
+        args, dist, k, model, state = gu.lgcp_setup(n=8, B=B, hidden=32, F=16)
+        fam = "wide" if case.endswith("wide") else None
+    else:
+        args, dist, k, model, state = gu.phi4_setup(d=64, B=B, hidden=32, F=16, non_linearity=case)
+        fam = None
+    d = args.dim
+    # the Cox target's gradient carries exp(x): a gentler field, as in tests/test_gpu_wide.py
+    params = _tamed(model, out_scale=0.3, gate=0.05) if case.startswith("lgcp") else _tamed(model, out_scale=2.0)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, **_family_kw(fam))
+    r = _flow_replay_raw(ctx, model, params, args, dist, 0.8, dist.init_params.astype(np.float32), prng.PRNGKey(41))
+    so, dg, info_o = r["so"], r["diag"], r["info_o"]
+    np.testing.assert_array_equal(r["n_g"], r["n_o"])
+    assert r["n_o"].mean() > 15
+    e_p = np.abs(r["prop"] - info_o.proposed_position).max()
+    vs = max(1.0, np.abs(so["vol0"]).max(), np.abs(so["volp"]).max())
+    e_v0, e_vp, e_la = np.abs(dg[:, 0] - so["vol0"]), np.abs(dg[:, 1] - so["volp"]), np.abs(dg[:, 3] - so["log_alpha"])
+    print(f"replay flow step {case}: attempts {r['n_o'].mean():.0f}, |dx'| {e_p:.2e}, |dvol0| {e_v0.max():.2e}, |dvolp| {e_vp.max():.2e} (scale {vs:.1f}), "
+          f"|d log alpha| med {np.median(e_la):.2e} max {e_la.max():.2e}")
+    assert e_p < 3e-5 * max(1.0, np.abs(info_o.proposed_position).max())
+    for e in (e_v0, e_vp):
+        assert np.quantile(e, 0.9) < 2e-5 * vs and e.max() < 2e-3 * vs, (np.quantile(e, 0.9), e.max(), vs)
+    vg = targets.Tempered(dist, 0.8).value_and_grad
+    gn = vg(info_o.proposed_position.astype(np.float64))[1]
+    bound = 2.0 * np.linalg.norm(gn, axis=1) * np.linalg.norm(r["prop"] - info_o.proposed_position, axis=1) + 1e-4 * vs + 1e-3
+    assert (e_la <= bound).all(), (e_la / bound).max()
+    same = r["isacc"] == info_o.is_accepted
+    assert same.mean() > 0.9
     ctx.close()
 
 
