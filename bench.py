@@ -217,15 +217,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if launched and world != a.gpus:
+        # already under a launcher with another world size (e.g. --nproc-per-node 4 with --gpus 8): every rank spawning its own
+        # nested N-rank job would oversubscribe the GPUs -- a clean error instead
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if a.gpus > 1 and not launched:
         # launched bare (`python bench.py --gpus N`): start one rank per GPU as a CHILD torch.distributed.run job -- before this
         # process has touched the GPU (nothing above imports torch), never by re-exec -- relay its output and exit with its code
-        import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # --standalone lets the launcher's own rendezvous pick (and hold) a free port: probing one here and closing the socket
+        # before the child binds it would be a race
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={a.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         sys.exit(subprocess.run(cmd, env=env).returncode)
     import numpy as np

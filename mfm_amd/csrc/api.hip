@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 #include <dlfcn.h>
+#include <mutex>
 #include <rccl/rccl.h>     // types and enums only: the library is resolved at run time (rccl_api), never linked
 
 #include "mala.hip"
@@ -584,30 +585,32 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
   const char* (*GetErrorString)(ncclResult_t);
 };
+static const char* g_rccl_why = "";
 static RcclApi* rccl_api() {
-  static RcclApi api; static int state = 0;
-  if (state == 0) {
+  // resolved once, whichever thread comes first (std::call_once); the reason of a failed load is kept for the error text
+  static RcclApi api; static bool ok = false; static std::once_flag once; static char why[256] = "";
+  std::call_once(once, [] {
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    state = -1;
-    if (h) {
-      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
-      api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
-      api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
-      api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
-      api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
-      if (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString) state = 1;
-    }
-  }
-  return state == 1 ? &api : nullptr;
+    if (!h) { const char* e = dlerror(); snprintf(why, sizeof why, "%s", e ? e : "dlopen failed"); return; }
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+    ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString;
+    if (!ok) snprintf(why, sizeof why, "librccl.so.1 lacks an expected symbol");
+  });
+  g_rccl_why = why;
+  return ok ? &api : nullptr;
 }
 #define RCCLCHK(call) do { const ncclResult_t r_ = (call); if (r_ != ncclSuccess) return fail(MFM_EHIP, "RCCL: %s", R->GetErrorString(r_)); } while (0)
 
 extern "C" int mfm_comm_unique_id(uint8_t out[MFM_COMM_ID_BYTES]) {
   static_assert(sizeof(ncclUniqueId) == MFM_COMM_ID_BYTES, "ncclUniqueId size");
   RcclApi* R = rccl_api();
-  if (!R) return fail(MFM_EUNSUPPORTED, "librccl.so.1 cannot be loaded: %s", dlerror());
+  if (!R) return fail(MFM_EUNSUPPORTED, "librccl.so.1 cannot be loaded: %s", g_rccl_why);
   if (!out) return fail(MFM_EINVAL, "null argument");
   ncclUniqueId id;
   RCCLCHK(R->GetUniqueId(&id));
@@ -617,13 +620,13 @@ extern "C" int mfm_comm_unique_id(uint8_t out[MFM_COMM_ID_BYTES]) {
 
 extern "C" int mfm_comm_destroy(mfm_ctx* x) {
   if (!x) return fail(MFM_EINVAL, "null ctx");
-  if (x->comm) {
-    RcclApi* R = rccl_api();
-    (void)hipStreamSynchronize(x->comm_stream);
-    if (R) (void)R->CommDestroy(x->comm);
-    (void)hipEventDestroy(x->ev_grads); (void)hipEventDestroy(x->ev_comm); (void)hipStreamDestroy(x->comm_stream);
-    x->comm = nullptr; x->comm_stream = nullptr; x->ev_grads = x->ev_comm = nullptr; x->comm_pending = nullptr; x->comm_nranks = 0;
-  }
+  // keyed on what exists, not on the communicator: a mfm_comm_init that failed half-way leaves a stream / events behind
+  if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
+  if (x->comm) { RcclApi* R = rccl_api(); if (R) (void)R->CommDestroy(x->comm); }
+  if (x->ev_grads) (void)hipEventDestroy(x->ev_grads);
+  if (x->ev_comm) (void)hipEventDestroy(x->ev_comm);
+  if (x->comm_stream) (void)hipStreamDestroy(x->comm_stream);
+  x->comm = nullptr; x->comm_stream = nullptr; x->ev_grads = x->ev_comm = nullptr; x->comm_pending = nullptr; x->comm_nranks = 0;
   return MFM_OK;
 }
 
@@ -634,12 +637,18 @@ extern "C" int mfm_comm_init(mfm_ctx* x, int nranks, int rank, const uint8_t id_
   if ((long long)x->cfg.n_chain_local * nranks != (long long)x->cfg.n_chain_total)
     return fail(MFM_EINVAL, "n_chain_total (%d) is not nranks (%d) x n_chain_local (%d)", x->cfg.n_chain_total, nranks, x->cfg.n_chain_local);
   RcclApi* R = rccl_api();
-  if (!R) return fail(MFM_EUNSUPPORTED, "librccl.so.1 cannot be loaded: %s", dlerror());
+  if (!R) return fail(MFM_EUNSUPPORTED, "librccl.so.1 cannot be loaded: %s", g_rccl_why);
   ncclUniqueId id; memcpy(&id, id_bytes, sizeof id);
-  HIPCHK(hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&x->ev_grads, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&x->ev_comm, hipEventDisableTiming));
-  RCCLCHK(R->CommInitRank(&x->comm, nranks, id, rank));
+  int rc = MFM_OK;
+  if (hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&x->ev_grads, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&x->ev_comm, hipEventDisableTiming) != hipSuccess)
+    rc = fail(MFM_EHIP, "communication stream / events: %s", hipGetErrorString(hipGetLastError()));
+  if (rc == MFM_OK) {
+    const ncclResult_t r = R->CommInitRank(&x->comm, nranks, id, rank);
+    if (r != ncclSuccess) { x->comm = nullptr; rc = fail(MFM_EHIP, "RCCL: %s", R->GetErrorString(r)); }
+  }
+  if (rc != MFM_OK) { (void)mfm_comm_destroy(x); return rc; }      // nothing of a failed init survives: a retry starts clean
   x->comm_nranks = nranks;
   return MFM_OK;
 }

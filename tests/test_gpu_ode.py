@@ -50,8 +50,14 @@ def test_ode_transform_and_inverse_match_oracle(d, hidden, F):
         # own controllers: a float32 and a float64 error norm round differently near ratio = 1 and at ReLU kinks, so individual
         # accept / reject decisions flip (the step-for-step comparison on ONE step sequence is tests/test_gpu_replay.py);
         # the attempt statistics agree
-        dn = np.abs(n - st["n_attempted"])
-        assert (dn == 0).mean() >= 0.3 and np.median(dn) <= 2 and abs(n.mean() - st["n_attempted"].mean()) < 0.1 * st["n_attempted"].mean(), (n, st["n_attempted"])
+        # (the exact-match share alone was >= 0.5 until cec7b18 changed float associations in the shape-specialised solver --
+        # out-layer tangent pull-back, 4-row tail path, DPP sums -- and a few more borderline decisions flipped.
+        # What a drifting controller would show is a BIAS or a wide spread of dn, so those are bounded instead.)
+        sd = n.astype(np.int64) - st["n_attempted"]
+        dn = np.abs(sd)
+        print(f"natural controllers d={d}: exact attempt counts {(dn == 0).mean():.2f}, |dn| <= 2 {(dn <= 2).mean():.2f}, mean signed dn {sd.mean():+.2f}")
+        assert (dn == 0).mean() >= 0.3 and (dn <= 2).mean() >= 0.9 and abs(sd.mean()) < 0.5, ((dn == 0).mean(), (dn <= 2).mean(), sd.mean())
+        assert abs(n.mean() - st["n_attempted"].mean()) < 0.1 * st["n_attempted"].mean(), (n, st["n_attempted"])
     # shared key (final sampling, exe_flow_matching.py:455)
     y_o, l_o = ode.transform_and_logdet(model, params, prng.PRNGKey(4), x32.astype(np.float64), True, args.rtol, args.atol, args.mxstep)
     out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda")

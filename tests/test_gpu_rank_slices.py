@@ -1,0 +1,150 @@
+"""Rank slices of the 8-GPU configurations on ONE GPU (BASELINE configs[3]: phi-four d = 256, 32,768 chains = 8 x 4,096;
+configs[4]: pines d = 1024, 8,192 chains = 8 x 1,024, wide kernel family).
+
+A rank's context is built exactly as the 8-GPU run builds it (`n_chain_total` = the global count, `chain_offset` = rank x
+per-GPU chains) for rank 0 AND rank 7, i.e. global chain ids up to 32,767 / 8,191 in every per-chain key split and
+counter-indexed draw (exe_flow_matching.py:303 `split(rng_key, B)`, :153-155,166).  The oracle is called with the same
+`n_total`, `start` (oracle/fm.py, oracle/flow.py, prng.split_at): the MALA step and the flow-matching loss / gradient on the
+rank's WHOLE slice, one flow-MH step on its first and last 64 chains on a prescribed step sequence."""
+import numpy as np
+import pytest
+
+from oracle import flow, fm, mala, prng, targets
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "phi4-32768": dict(n_total=32768, n_local=4096),
+    "pines-8192": dict(n_total=8192, n_local=1024),
+}
+
+
+def _dev(x, dtype=None):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda()
+
+
+def _setup(case, rank):
+    from tests import gpu_util as gu
+    c = CASES[case]
+    off = rank * c["n_local"]
+    if case.startswith("phi4"):
+        args, dist, k, model, state = gu.phi4_setup(d=256, B=16)
+        params = gu.rand_params(model, seed=9, out_scale=2.0)
+        params[4]["kernel"] *= 1e-3; params[4]["bias"] *= 1e-3
+    else:
+        args, dist, k, model, state = gu.lgcp_setup(n=32, B=16, hidden=1024, F=128)
+        params = gu.rand_params(model, seed=2, out_scale=0.2)
+        params[4]["kernel"] *= 0.02; params[4]["bias"] *= 0.02
+    args.num_chain = c["n_total"]
+    x = dist.initialize_model(k["dist"], c["n_total"], start=off, count=c["n_local"])       # the rank's rows of the global init
+    x32 = x.astype(np.float32)
+    ctx = gu.make_ctx(dist, args, n_local=c["n_local"], n_total=c["n_total"], offset=off, fourier=model.f, params=params)
+    return gu, args, dist, model, params, x32, ctx, off, c
+
+
+@pytest.mark.parametrize("rank", [0, 7])
+@pytest.mark.parametrize("case", list(CASES))
+def test_rank_slice_mala_and_fm_match_oracle(case, rank):
+    import torch
+    gu, args, dist, model, params, x32, ctx, off, c = _setup(case, rank)
+    n, d = x32.shape
+    ids = np.arange(off, off + n)
+    beta = 0.8
+    vg = targets.Tempered(dist, beta).value_and_grad
+    pos = _dev(x32); logp = torch.empty(n, dtype=torch.float64, device="cuda"); grad = torch.empty(n, d, device="cuda")
+    ctx.mala_init(pos, beta, logp, grad)
+    st = mala.init(x32.astype(np.float64), vg)
+    np.testing.assert_allclose(logp.cpu().numpy(), st.logdensity, rtol=2e-6)
+    # ---- MALA step (mala.py:86-118) on the whole slice: chain b draws with split(key, n_total)[offset + b] ----
+    key = prng.PRNGKey(5 + rank)
+    st_in = mala.MALAState(x32.astype(np.float64), logp.cpu().numpy(), grad.cpu().numpy().astype(np.float64))
+    new, info, u = mala.kernel(prng.split_at(key, c["n_total"], ids), st_in, vg, args.step_size)
+    acc = torch.empty(n, device="cuda"); isacc = torch.empty(n, dtype=torch.uint8, device="cuda"); prop = torch.empty(n, d, device="cuda")
+    p2, l2, g2 = pos.clone(), logp.clone(), grad.clone()
+    ctx.mala_step(key, beta, args.step_size, p2, l2, g2, acc, isacc, prop)
+    np.testing.assert_allclose(prop.cpu().numpy(), info.proposed_position, rtol=1e-6, atol=2e-6)
+    np.testing.assert_allclose(acc.cpu().numpy(), info.acceptance_rate, atol=5e-3)
+    decided = np.abs(u - info.acceptance_rate) > 1e-2
+    np.testing.assert_array_equal(isacc.cpu().numpy()[decided].astype(bool), info.is_accepted[decided])
+    # ---- flow-matching loss / gradient (exe_flow_matching.py:151-178): draws indexed by GLOBAL chain id ----
+    kf = prng.PRNGKey(60 + rank)
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctx.n_params, device="cuda")
+    ctx.fm_loss_grad(kf, pos, loss, grads)
+    lo, go = fm.loss_and_grad(model, params, kf, x32.astype(np.float64), args.sigma, n_total=c["n_total"], start=off)
+    assert abs(loss.item() - lo) < 2e-5 * abs(lo), (loss.item(), lo)
+    gflat = gu.flat_params(go).astype(np.float64)
+    ge = grads.cpu().numpy().astype(np.float64) - gflat
+    # every tensor within 2e-6 .. 1e-4 of its maximum (tools/dbg/rank_slice_grad.py) EXCEPT where one of the ~1e7 ReLU
+    # pre-activations of the slice lies within float32 rounding of zero: its mask differs from the float64 oracle's and ONE
+    # chain's contribution to the tensors below that unit flips (measured on pines rank 7: 7e-4 of the maximum in the ReLU
+    # layers, 1e-6 in the two linear ones).  Hence a bound on the maximum that admits one such event and one in norm (measured 4e-5 with the event, 1e-6 without).
+    assert np.abs(ge).max() < 2e-3 * np.abs(gflat).max(), np.abs(ge).max() / np.abs(gflat).max()
+    assert np.linalg.norm(ge) < 2e-4 * np.linalg.norm(gflat), np.linalg.norm(ge) / np.linalg.norm(gflat)
+    # the same key on the OTHER end of the chain axis gives different draws (the offset is not ignored)
+    if rank == 7:
+        lo0, _ = fm.loss_and_grad(model, params, kf, x32.astype(np.float64), args.sigma, n_total=c["n_total"], start=0, need_grad=False)
+        assert abs(lo0 - lo) > 1e-6 * abs(lo)
+    ctx.close()
+
+
+@pytest.mark.parametrize("rank", [0, 7])
+@pytest.mark.parametrize("case", list(CASES))
+def test_rank_slice_flow_step_matches_oracle_on_prescribed_steps(case, rank):
+    """First and last 64 chains of the rank against the oracle, step for step.  The kernel integrates the rank's whole slice:
+    every other chain replays the step sequence of one of the 128 checked ones (a prescribed sequence ends by itself: its
+    accepted steps add up to t = 1 whatever the state), so the launch has the production shape and a defined end."""
+    import torch
+    from mfm_amd import _lib
+    from tests.test_gpu_replay import _replay_arrays
+    gu, args, dist, model, params, x32, ctx, off, c = _setup(case, rank)
+    n, d = x32.shape
+    sel = np.concatenate([np.arange(64), np.arange(n - 64, n)])
+    beta = 0.8
+    vg = targets.Tempered(dist, beta).value_and_grad
+    pos = _dev(x32); logp = torch.empty(n, dtype=torch.float64, device="cuda"); grad = torch.empty(n, d, device="cuda")
+    ctx.mala_init(pos, beta, logp, grad)
+    st0 = mala.MALAState(x32[sel].astype(np.float64), logp.cpu().numpy()[sel], grad.cpu().numpy()[sel].astype(np.float64))
+    key = prng.PRNGKey(31 + rank)
+    keys = prng.split_at(key, c["n_total"], off + sel)                                   # :303
+    nat = {}
+    flow.rwmh_step(keys, st0, vg, model, params, args, nat)
+    dt_s, ac_s = _replay_arrays([nat["inv"], nat["fwd"]])
+    rp = dict(inv=dict(dt=dt_s[0].astype(np.float64), acc=ac_s[0]), fwd=dict(dt=dt_s[1].astype(np.float64), acc=ac_s[1]))
+    so = {}
+    new_o, info_o = flow.rwmh_step(keys, st0, vg, model, params, args, so, replay=rp)
+    donor = np.arange(n) % 128
+    donor[sel] = np.arange(128)
+    dt, ac = np.ascontiguousarray(dt_s[:, donor]), np.ascontiguousarray(ac_s[:, donor])
+    ratio = torch.zeros(dt.shape, device="cuda"); own = torch.zeros(dt.shape, device="cuda"); diag = torch.zeros(n, 4, dtype=torch.float64, device="cuda")
+    ctx.debug_replay(_dev(dt), _dev(ac), ratio, own, diag)
+    a = torch.empty(n, device="cuda"); ia = torch.empty(n, dtype=torch.uint8, device="cuda"); pr = torch.empty(n, d, device="cuda"); ns = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.flow_step(_lib.FLOW_RWMH, key, beta, pos, logp, grad, a, ia, pr, ns)
+    n_o = so["n_att_inv"] + so["n_att_fwd"]
+    np.testing.assert_array_equal(ns.cpu().numpy()[sel], n_o)                            # attempt counts: exact
+    np.testing.assert_array_equal(ns.cpu().numpy(), n_o[donor])                          # ... and every chain ended where its sequence ends
+    dg = diag.cpu().numpy()[sel]
+    vs = max(1.0, np.abs(so["vol0"]).max(), np.abs(so["volp"]).max())
+    e_p = np.abs(pr.cpu().numpy()[sel] - info_o.proposed_position).max()
+    e_v0, e_vp = np.abs(dg[:, 0] - so["vol0"]), np.abs(dg[:, 1] - so["volp"])
+    e_v = np.maximum(e_v0, e_vp)
+    e_la = np.abs(dg[:, 3] - so["log_alpha"])
+    print(f"{case} rank {rank}: attempts {n_o.mean():.0f} (max {n_o.max()}), |dx'| {e_p:.2e}, |dvol| q90 {np.quantile(e_v, 0.9):.2e} max {e_v.max():.2e} "
+          f"(scale {vs:.1f}), |d log alpha| med {np.median(e_la):.2e} max {e_la.max():.2e}")
+    # phi-four: the bounds of tests/test_gpu_replay.py (measured |dx'| 5e-6, log-det q90 6e-6, max 1.1e-2 of 14).  pines at its
+    # real width: d = 1024 > 128 switches the +-1 clip of grad log pi on (exe_flow_matching.py:351), whose mask is one more kink
+    # per element next to the 1024-wide ReLU layers -- isolated log-det events are more frequent (measured |dx'| 3.3e-5, log-det
+    # q90 1.1e-5 .. 8.8e-5, max 6e-3 of 3.4)
+    wide = case.startswith("pines")
+    assert e_p < (1e-4 if wide else 3e-5) * max(1.0, np.abs(info_o.proposed_position).max())
+    assert np.quantile(e_v, 0.9) < (1e-4 if wide else 2e-5) * vs and e_v.max() < (5e-3 if wide else 2e-3) * vs
+    # log alpha = log pi(x') - volp - log pi(x) - vol0 (:271-274): its error is explained by its terms -- |grad log pi(x')| |dx'|
+    # (first order, per chain) and the two log-det differences
+    gn = vg(info_o.proposed_position.astype(np.float64))[1]
+    dxp = np.linalg.norm(pr.cpu().numpy()[sel] - info_o.proposed_position, axis=1)
+    bound = 2.0 * np.linalg.norm(gn, axis=1) * dxp + e_v0 + e_vp + 1e-3
+    assert (e_la <= bound).all(), (e_la / bound).max()
+    same = ia.cpu().numpy().astype(bool)[sel] == info_o.is_accepted
+    assert same.mean() > 0.9
+    np.testing.assert_allclose(pos.cpu().numpy()[sel][same], new_o.position[same], atol=3e-5 * max(1.0, np.abs(new_o.position).max()))
+    ctx.close()
