@@ -86,9 +86,14 @@ struct Tile {
                          });
   }
 
+  // (hooks of the resident-weight tile below: the streamed tile evaluates its time branch inside every evaluation)
+  __device__ __forceinline__ void prepare1(float) {}
+  __device__ __forceinline__ void prepare5(float, float) {}
+
   // One evaluation of the augmented field for chain g at x = (x0, x1), time tt.  kv = dx/dt, dl = d(logdet)/dt.
-  __device__ __forceinline__ void eval(float x0, float x1, float tt, float (&kv)[2], float& dl, bool reuse_time) {
+  __device__ __forceinline__ void eval(float x0, float x1, float tt, float (&kv)[2], float& dl, int phase) {
     const NetDev& N = *n;
+    const bool reuse_time = phase == 7;       // stages 6 and 7 are both at t + dt
     // ---- Fourier features of the value rows (:70-71), the K = 2 layer on the vector ALU, the mixture's gradient ----
     if (!reuse_time) {
       for (int nt = wave; nt < N.F / 16; nt += NW) {
@@ -183,9 +188,256 @@ struct Tile {
   }
 };
 
+
+// ---- the resident-weight tile ------------------------------------------------------------------------------------------------
+// For the reference's default widths (F = 128 Fourier frequencies, every hidden layer 128 wide: multi_modal.py:159,178-180) the
+// eight waves of the workgroup own one 16-column tile of each layer.  Two consequences:
+//  * the B fragments of the three hidden layers an evaluation passes on its x path (x2, the x half of j1, j2: 3 x 8 float4)
+//    and the wave's k-block of the out layer stay IN REGISTERS for the whole kernel (100 VGPRs): an evaluation issues no
+//    global loads at all -- LDS reads, MFMAs, five barriers;
+//  * everything that depends on t only -- Fourier features, t1, t2, the gate and the st half of j1's pre-activation (with
+//    its bias) -- is evaluated ONCE PER ATTEMPT for the five distinct stage times (t + c_s dt, known when the attempt starts)
+//    of the four chains as one M = 20 (two row tiles) batch with streamed weights, and kept in LDS: 10 KB of j1 accumulator
+//    seeds, 40 gate values.  An evaluation is then x1 (vector ALU) -> x2 -> j1 (K = 128, seeded) -> j2 -> out (K split).
+// Per attempt: 6 x 100 + 260 MFMAs per wave instead of 6 x 232.  Float reassociations against the streamed tile: the j1
+// pre-activation sums its st half (and bias) first.
+struct LdsR { int ff, t1, st, ct, gate, gp, x1, cat, j1, j2, part, gc, total; };
+constexpr int R_LD = 136, R_LDF = 264;      // leading dimensions (128 + 8, 256 + 8: conflict-free ds_read_b128 fragments)
+__host__ __device__ inline LdsR layout_r() {
+  LdsR L; int o = 0;
+  auto take = [&](int cnt) { int r = o; o += (cnt + 3) & ~3; return r; };
+  L.ff = take(32 * R_LDF); L.t1 = take(32 * R_LD); L.st = take(32 * R_LD);
+  L.ct = take(20 * 128); L.gate = take(20 * 2); L.gp = take(NW * 32 * 2);
+  L.x1 = take(16 * R_LD); L.cat = take(16 * R_LD); L.j1 = take(16 * R_LD); L.j2 = take(16 * R_LD);
+  L.part = take(4 * NW * 4); L.gc = take(2 * 4 * 4);
+  L.total = o;
+  return L;
+}
+static bool shape_ok_r(const NetDev& n, int hutch) {
+  return shape_ok(n, hutch) && n.F == 128 && n.ht1 == 128 && n.ht2 == 128 && n.hx1 == 128 && n.hx2 == 128 && n.hj1 == 128 && n.hj2 == 128 &&
+         n.T.n_modes <= 16;
+}
+
+// grad log pi and the DIAGONAL of its Jacobian for a d = 2 mixture, one mode per lane (k = lane & 15): the two calls of
+// gmm_eval_lanes16 with v = e_1, e_2 (targets.cuh) folded into one pass -- (H e_j)_j = sum_k r_k (a_kj^2 - 1/s_kj^2) - g_j^2.
+__device__ __forceinline__ void gmm_grad_hdiag2(const TargetDev& T, float x0, float x1, int k, float (&gg)[2], float (&hd)[2]) {
+  const bool live = k < T.n_modes;
+  float comp = -INFINITY, a[2] = {0.f, 0.f}, iv[2] = {0.f, 0.f};
+  if (live) {
+    comp = T.gmm_logw[k];
+    const float xs[2] = {x0, x1};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float sd = T.gmm_std[k * 2 + j], dx = xs[j] - T.gmm_mode[k * 2 + j], z = dx / sd;
+      comp -= 0.5f * z * z;
+      a[j] = -dx / (sd * sd);
+      iv[j] = 1.f / (sd * sd);
+    }
+  }
+  const float m = group16_max_dpp(comp);
+  const float e = live ? expf(comp - m) : 0.f;
+  const float inv = 1.f / group16_sum_dpp(e);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    gg[j] = group16_sum_dpp(e * a[j]) * inv;
+    hd[j] = group16_sum_dpp(e * (a[j] * a[j] - iv[j])) * inv - gg[j] * gg[j];
+  }
+}
+
+struct TileR {
+  const NetDev* n;
+  LdsR L;
+  float* lds;
+  int lane, wave, g, c, sign, par;
+  float w1[2], b1x, b3, b5, b6, b7[2], b4[2];
+  f32x4 W3f[8], W5f[8], W6f[8], W7f;
+
+  __device__ __forceinline__ void init(const NetDev* net, float* l) {
+    n = net; L = layout_r(); lds = l; par = 0;
+    lane = threadIdx.x & 63; wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); g = lane >> 4; c = lane & 15; sign = 1;
+    for (int i = threadIdx.x; i < L.total; i += NW * 64) lds[i] = 0.f;       // unused rows stay zero
+    const NetDev& N = *n;
+    const int col = wave * 16 + c;
+    w1[0] = N.Wp[N.L[2].w_off + pack_index(0, col, 1)]; w1[1] = N.Wp[N.L[2].w_off + pack_index(1, col, 1)];
+    b1x = N.bias[N.L[2].b_off + col]; b3 = N.bias[N.L[3].b_off + col]; b5 = N.bias[N.L[5].b_off + col]; b6 = N.bias[N.L[6].b_off + col];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { b7[j] = N.bias[N.L[7].b_off + j]; b4[j] = N.bias[N.L[4].b_off + j]; }
+    const f32x4* P3 = reinterpret_cast<const f32x4*>(N.Wp + N.L[3].w_off);
+    const f32x4* P5 = reinterpret_cast<const f32x4*>(N.Wp + N.L[5].w_off);
+    const f32x4* P6 = reinterpret_cast<const f32x4*>(N.Wp + N.L[6].w_off);
+    const f32x4* P7 = reinterpret_cast<const f32x4*>(N.Wp + N.L[7].w_off);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      W3f[kb] = P3[(wave * 8 + kb) * 64 + lane];
+      W5f[kb] = P5[(wave * 16 + kb) * 64 + lane];          // rows 0..127 of the [sx | st] input: the x half
+      W6f[kb] = P6[(wave * 8 + kb) * 64 + lane];
+    }
+    W7f = P7[wave * 64 + lane];
+    __syncthreads();
+  }
+
+  // The time branch for five stage times of chain g (row 4 s + g of the batch is (slot s, chain g)).
+  __device__ __forceinline__ void prepare(const float (&ts)[5]) {
+    const NetDev& N = *n;
+    const int col = wave * 16 + c;
+    {
+      const double f = (double)N.fourier[col];
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const double te = sign > 0 ? (double)ts[s] : 1.0 - (double)ts[s];    // :229
+        double ft = f * te;
+        ft -= rint(ft);
+        float sv, cv;
+        sincospif(2.f * (float)ft, &sv, &cv);                                 // :70-71
+        lds[L.ff + (4 * s + g) * R_LDF + col] = cv;
+        lds[L.ff + (4 * s + g) * R_LDF + 128 + col] = sv;
+      }
+    }
+    __syncthreads();
+    layer_gemm<2, NW, 1>(lds + L.ff, R_LDF, N.Wp + N.L[0].w_off, N.bias + N.L[0].b_off, 16, 8, wave, lane,
+                         [&](int q, int nt, int m, f32x4 acc, float b) {
+#pragma unroll
+                           for (int i = 0; i < 4; ++i) lds[L.t1 + (16 * m + 4 * g + i) * R_LD + nt * 16 + c] = act_f(acc[i] + b, N.act);
+                         });
+    __syncthreads();
+    layer_gemm<2, NW, 1>(lds + L.t1, R_LD, N.Wp + N.L[1].w_off, N.bias + N.L[1].b_off, 8, 8, wave, lane,
+                         [&](int q, int nt, int m, f32x4 acc, float b) {
+#pragma unroll
+                           for (int i = 0; i < 4; ++i) lds[L.st + (16 * m + 4 * g + i) * R_LD + nt * 16 + c] = act_f(acc[i] + b, N.act);
+                         });
+    __syncthreads();
+    {
+      // st half of j1's pre-activation (+ bias) and the wave's k-block of the gate
+      const f32x4* P5 = reinterpret_cast<const f32x4*>(N.Wp + N.L[5].w_off) + (wave * 16 + 8) * 64 + lane;
+      const f32x4 wg = reinterpret_cast<const f32x4*>(N.Wp + N.L[4].w_off)[wave * 64 + lane];
+      f32x4 wf[8];
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) wf[kb] = P5[kb * 64];
+      const float* arow = lds + L.st + c * R_LD + 4 * g;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ag[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(arow + m * 16 * R_LD + kb * 16);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wf[kb][s], acc[m], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + m * 16 * R_LD + wave * 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ag[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wg[s], ag[m], 0, 0, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int R = 16 * m + 4 * g + i;
+          if (R < 20) {
+            lds[L.ct + R * 128 + col] = acc[m][i] + b5;
+            if (c < 2) lds[L.gp + (wave * 32 + R) * 2 + c] = ag[m][i];
+          }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 40) {
+      const int R = threadIdx.x >> 1, j = threadIdx.x & 1;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += lds[L.gp + (w * 32 + R) * 2 + j];
+      lds[L.gate + R * 2 + j] = s + (j ? b4[1] : b4[0]);
+    }
+    // (visible to everyone after the first barrier of the next evaluation)
+  }
+  __device__ __forceinline__ void prepare1(float tt) { const float ts[5] = {tt, tt, tt, tt, tt}; prepare(ts); }
+  __device__ __forceinline__ void prepare5(float t, float dt) {
+    float ts[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) ts[s] = t + dt * DP_TAB[2 + s][6];
+    prepare(ts);
+  }
+
+  // value + two tangent rows through a resident hidden layer
+  __device__ __forceinline__ void hidden(const float* A, const f32x4 (&W)[8], f32x4 acc, float b, float* out) {
+    const float* arow = A + c * R_LD + 4 * g;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(arow + kb * 16);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], W[kb][s], acc, 0, 0, 0);
+    }
+    const float pre = acc[0] + b;
+    float* o = out + (4 * g) * R_LD + wave * 16 + c;
+    o[0] = act_f(pre, n->act);
+    o[R_LD] = mask_pre(pre, acc[1], n->act);
+    o[2 * R_LD] = mask_pre(pre, acc[2], n->act);
+  }
+
+  __device__ __forceinline__ void eval(float x0, float x1, float tt, float (&kv)[2], float& dl, int phase) {
+    const NetDev& N = *n;
+    const int slot = phase < 2 ? 0 : (phase - 2 < 4 ? phase - 2 : 4);       // stages 6 and 7 are both at t + dt
+    const int col = wave * 16 + c;
+    {
+      const float pre = fmaf(x1, w1[1], x0 * w1[0]) + b1x;
+      float* o = lds + L.x1 + (4 * g) * R_LD + col;
+      o[0] = act_f(pre, N.act);
+      o[R_LD] = mask_pre(pre, w1[0], N.act);
+      o[2 * R_LD] = mask_pre(pre, w1[1], N.act);
+    }
+    par ^= 1;
+    if (wave == NW - 1) {            // the mixture's gradient: 4 chains x 16 modes = the lanes of ONE wave
+      float gg[2], hh[2];
+      gmm_grad_hdiag2(N.T, x0, x1, c, gg, hh);
+      if (c == 0) {
+        float* o = lds + L.gc + (par * 4 + g) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool inside = !(N.grad_clip > 0.f) || fabsf(gg[j]) <= N.grad_clip;
+          o[j] = clipf(gg[j], N.grad_clip);
+          o[2 + j] = inside ? hh[j] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    hidden(lds + L.x1, W3f, zero, b3, lds + L.cat);
+    __syncthreads();
+    hidden(lds + L.cat, W5f, f32x4{lds[L.ct + (4 * slot + g) * 128 + col], 0.f, 0.f, 0.f}, 0.f, lds + L.j1);
+    __syncthreads();
+    hidden(lds + L.j1, W6f, zero, b6, lds + L.j2);
+    __syncthreads();
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(lds + L.j2 + c * R_LD + 4 * g + wave * 16);
+      f32x4 acc = zero;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], W7f[s], acc, 0, 0, 0);
+      float* p = lds + L.part + (g * NW + wave) * 4;
+      if (c == 0) { p[0] = acc[0]; p[2] = acc[1]; }
+      if (c == 1) { p[1] = acc[0]; p[3] = acc[2]; }
+    }
+    __syncthreads();
+    float o0 = 0.f, o1 = 0.f, j11 = 0.f, j22 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const f32x4 pa = *reinterpret_cast<const f32x4*>(lds + L.part + (g * NW + w) * 4);
+      o0 += pa[0]; o1 += pa[1]; j11 += pa[2]; j22 += pa[3];
+    }
+    const f32x4 gch = *reinterpret_cast<const f32x4*>(lds + L.gc + (par * 4 + g) * 4);
+    const float g0 = lds[L.gate + (4 * slot + g) * 2], g1 = lds[L.gate + (4 * slot + g) * 2 + 1];
+    // v = nn_xt + nn_t * clip(grad log pi(x)) (:88-90);  trace J = sum_j (d nn_xt e_j)_j + nn_t_j 1[|g_j| <= clip] H_jj
+    const float v0 = o0 + b7[0] + g0 * gch[0], v1 = o1 + b7[1] + g1 * gch[1];
+    const float tr = (j11 + g0 * gch[2]) + (j22 + g1 * gch[3]);
+    kv[0] = sign > 0 ? v0 : -v0; kv[1] = sign > 0 ? v1 : -v1;
+    dl = sign > 0 ? -tr : tr;                                                 // :218 / :239
+  }
+};
+
 // Integrate chain g's augmented ODE from t = 0 to 1 (every lane of group g holds the same state).  The state machine of
 // ode.hip: ode_solve -- phase 0: f0, phase 1: the extra evaluation of the initial-step heuristic, phases 2..7: the six stages.
-__device__ __forceinline__ void solve(Tile& T, float rtol, float atol, int max_attempts, float (&y)[2], float& ell, int& natt,
+template <typename TILE>
+__device__ __forceinline__ void solve(TILE& T, float rtol, float atol, int max_attempts, float (&y)[2], float& ell, int& natt,
                                       const Replay& rp, int rp_solve, int rp_row) {
   const float inv_n = 1.f / 3.f;                    // d + 1 components
   float k[7][2], kl[7];
@@ -211,7 +463,9 @@ __device__ __forceinline__ void solve(Tile& T, float rtol, float atol, int max_a
       xin[q] = y[q] + hs * acc;
     }
     float kv[2], dlv;
-    T.eval(xin[0], xin[1], ts, kv, dlv, phase == 7);
+    if (phase < 2) T.prepare1(ts);            // time branch of the two evaluations of the initial-step heuristic
+    else if (phase == 2) T.prepare5(t, dt);   // ... and of the five distinct stage times of this attempt
+    T.eval(xin[0], xin[1], ts, kv, dlv, phase);
     const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
 #pragma unroll
     for (int j = 0; j < 7; ++j)
@@ -331,9 +585,10 @@ __device__ __forceinline__ void solve(Tile& T, float rtol, float atol, int max_a
   natt = (int)na;
 }
 
+template <typename TILE>
 __global__ __launch_bounds__(NW * 64) void transform_kernel(OdeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  Tile T;
+  TILE T;
   T.init(&a.net, lds);
   T.sign = a.direction;
   const int b = blockIdx.x * 4 + T.g;
@@ -347,9 +602,10 @@ __global__ __launch_bounds__(NW * 64) void transform_kernel(OdeArgs a) {
 }
 
 // One flow-based MH step per chain (random-walk in latent space :264-278, or independent :246-260).
+template <typename TILE>
 __global__ __launch_bounds__(NW * 64) void flow_kernel(OdeArgs a, FlowArgs f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  Tile T;
+  TILE T;
   T.init(&a.net, lds);
   const NetDev& N = a.net;
   const int b = blockIdx.x * 4 + T.g;
@@ -401,24 +657,36 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(OdeArgs a, FlowArgs f) {
   }
 }
 
-// 4-chain tiles while the 16-chain tiling would leave CUs without a workgroup (or under MFM_D2_TILE=4); MFM_D2_TILE=16 keeps
-// the generic tile.
-static bool use_for(const NetDev& n, int hutch, int rows) {
-  if (!shape_ok(n, hutch)) return false;
-  if (const char* e = getenv("MFM_D2_TILE")) return atoi(e) == 4;
-  return rows / 16 < 256;
+// 4-chain tiles while the 16-chain tiling would leave CUs without a workgroup.  MFM_D2_TILE (development / tests): 16 keeps the
+// generic tile, 4 forces the 4-chain tiles, 4s the streamed-weight instance of them even where the resident one fits.
+static int pick(const NetDev& n, int hutch, int rows) {       // 0: generic 16-chain tile, 1: streamed 4-chain, 2: resident 4-chain
+  if (!shape_ok(n, hutch)) return 0;
+  const char* e = getenv("MFM_D2_TILE");
+  if (e && atoi(e) == 16) return 0;
+  if (!e && rows / 16 >= 256) return 0;
+  if (e && e[0] == '4' && e[1] == 's') return 1;
+  return shape_ok_r(n, hutch) ? 2 : 1;
+}
+static bool use_for(const NetDev& n, int hutch, int rows) { return pick(n, hutch, rows) != 0; }
+template <typename TILE>
+static int launch_transform_t(const OdeArgs& a, size_t sm, hipStream_t stream) {
+  (void)hipFuncSetAttribute((const void*)transform_kernel<TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL(transform_kernel<TILE>, dim3(a.n / 4), dim3(NW * 64), sm, stream, a);
+  return 0;
+}
+template <typename TILE>
+static int launch_flow_t(const OdeArgs& a, const FlowArgs& f, size_t sm, hipStream_t stream) {
+  (void)hipFuncSetAttribute((const void*)flow_kernel<TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL(flow_kernel<TILE>, dim3(a.n / 4), dim3(NW * 64), sm, stream, a, f);
+  return 0;
 }
 static int launch_transform(const OdeArgs& a, hipStream_t stream) {
-  const size_t sm = (size_t)layout(a.net).total * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL(transform_kernel, dim3(a.n / 4), dim3(NW * 64), sm, stream, a);
-  return 0;
+  if (pick(a.net, a.hutch, a.n) == 2) return launch_transform_t<TileR>(a, (size_t)layout_r().total * sizeof(float), stream);
+  return launch_transform_t<Tile>(a, (size_t)layout(a.net).total * sizeof(float), stream);
 }
 static int launch_flow(const OdeArgs& a, const FlowArgs& f, hipStream_t stream) {
-  const size_t sm = (size_t)layout(a.net).total * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)flow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL(flow_kernel, dim3(a.n / 4), dim3(NW * 64), sm, stream, a, f);
-  return 0;
+  if (pick(a.net, a.hutch, a.n) == 2) return launch_flow_t<TileR>(a, f, (size_t)layout_r().total * sizeof(float), stream);
+  return launch_flow_t<Tile>(a, f, (size_t)layout(a.net).total * sizeof(float), stream);
 }
 
 }  // namespace d2
