@@ -87,8 +87,7 @@ struct Tile {
   }
 
   // (hooks of the resident-weight tile below: the streamed tile evaluates its time branch inside every evaluation)
-  __device__ __forceinline__ void prepare1(float) {}
-  __device__ __forceinline__ void prepare5(float, float) {}
+  __device__ __forceinline__ void prepare(const float (&)[5]) {}
 
   // One evaluation of the augmented field for chain g at x = (x0, x1), time tt.  kv = dx/dt, dl = d(logdet)/dt.
   __device__ __forceinline__ void eval(float x0, float x1, float tt, float (&kv)[2], float& dl, int phase) {
@@ -244,7 +243,9 @@ __device__ __forceinline__ void gmm_grad_hdiag2(const TargetDev& T, float x0, fl
   }
 }
 
+template <int ACT>          // the hidden non-linearity as a compile-time constant (MFM_ACT_*), or -1: read from the network
 struct TileR {
+  __device__ __forceinline__ int act() const { return ACT >= 0 ? ACT : n->act; }
   const NetDev* n;
   LdsR L;
   float* lds;
@@ -297,13 +298,13 @@ struct TileR {
     layer_gemm<2, NW, 1>(lds + L.ff, R_LDF, N.Wp + N.L[0].w_off, N.bias + N.L[0].b_off, 16, 8, wave, lane,
                          [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
-                           for (int i = 0; i < 4; ++i) lds[L.t1 + (16 * m + 4 * g + i) * R_LD + nt * 16 + c] = act_f(acc[i] + b, N.act);
+                           for (int i = 0; i < 4; ++i) lds[L.t1 + (16 * m + 4 * g + i) * R_LD + nt * 16 + c] = act_f(acc[i] + b, act());
                          });
     __syncthreads();
     layer_gemm<2, NW, 1>(lds + L.t1, R_LD, N.Wp + N.L[1].w_off, N.bias + N.L[1].b_off, 8, 8, wave, lane,
                          [&](int q, int nt, int m, f32x4 acc, float b) {
 #pragma unroll
-                           for (int i = 0; i < 4; ++i) lds[L.st + (16 * m + 4 * g + i) * R_LD + nt * 16 + c] = act_f(acc[i] + b, N.act);
+                           for (int i = 0; i < 4; ++i) lds[L.st + (16 * m + 4 * g + i) * R_LD + nt * 16 + c] = act_f(acc[i] + b, act());
                          });
     __syncthreads();
     {
@@ -351,13 +352,6 @@ struct TileR {
     }
     // (visible to everyone after the first barrier of the next evaluation)
   }
-  __device__ __forceinline__ void prepare1(float tt) { const float ts[5] = {tt, tt, tt, tt, tt}; prepare(ts); }
-  __device__ __forceinline__ void prepare5(float t, float dt) {
-    float ts[5];
-#pragma unroll
-    for (int s = 0; s < 5; ++s) ts[s] = t + dt * DP_TAB[2 + s][6];
-    prepare(ts);
-  }
 
   // value + two tangent rows through a resident hidden layer
   __device__ __forceinline__ void hidden(const float* A, const f32x4 (&W)[8], f32x4 acc, float b, float* out) {
@@ -370,9 +364,9 @@ struct TileR {
     }
     const float pre = acc[0] + b;
     float* o = out + (4 * g) * R_LD + wave * 16 + c;
-    o[0] = act_f(pre, n->act);
-    o[R_LD] = mask_pre(pre, acc[1], n->act);
-    o[2 * R_LD] = mask_pre(pre, acc[2], n->act);
+    o[0] = act_f(pre, act());
+    o[R_LD] = mask_pre(pre, acc[1], act());
+    o[2 * R_LD] = mask_pre(pre, acc[2], act());
   }
 
   __device__ __forceinline__ void eval(float x0, float x1, float tt, float (&kv)[2], float& dl, int phase) {
@@ -382,9 +376,9 @@ struct TileR {
     {
       const float pre = fmaf(x1, w1[1], x0 * w1[0]) + b1x;
       float* o = lds + L.x1 + (4 * g) * R_LD + col;
-      o[0] = act_f(pre, N.act);
-      o[R_LD] = mask_pre(pre, w1[0], N.act);
-      o[2 * R_LD] = mask_pre(pre, w1[1], N.act);
+      o[0] = act_f(pre, act());
+      o[R_LD] = mask_pre(pre, w1[0], act());
+      o[2 * R_LD] = mask_pre(pre, w1[1], act());
     }
     par ^= 1;
     if (wave == NW - 1) {            // the mixture's gradient: 4 chains x 16 modes = the lanes of ONE wave
@@ -463,8 +457,12 @@ __device__ __forceinline__ void solve(TILE& T, float rtol, float atol, int max_a
       xin[q] = y[q] + hs * acc;
     }
     float kv[2], dlv;
-    if (phase < 2) T.prepare1(ts);            // time branch of the two evaluations of the initial-step heuristic
-    else if (phase == 2) T.prepare5(t, dt);   // ... and of the five distinct stage times of this attempt
+    if (phase <= 2) {          // time branch: of the evaluations of the initial-step heuristic (phases 0, 1), of the five distinct
+      float ts5[5];            // stage times of the attempt that starts (phase 2)
+#pragma unroll
+      for (int q = 0; q < 5; ++q) ts5[q] = phase < 2 ? ts : t + dt * DP_TAB[2 + q][6];
+      T.prepare(ts5);
+    }
     T.eval(xin[0], xin[1], ts, kv, dlv, phase);
     const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
 #pragma unroll
@@ -613,25 +611,26 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(OdeArgs a, FlowArgs f) {
   const double lp_old = f.logp[b];
   float y[2] = {f.pos[(size_t)b * 2], f.pos[(size_t)b * 2 + 1]}, ell, vol0, lq_ref = 0.f;
   int natt, natt_tot;
-  // ---- inverse solve from the current position (:267 / :251), key_hutch2 unused (exact trace) ----
-  T.sign = -1;
-  solve(T, a.rtol, a.atol, a.max_attempts, y, ell, natt, a.rp, 0, b);
-  vol0 = ell; natt_tot = natt;
-  // ---- proposal in latent space ----
-  {
-    const float scale = 2.38f / sqrtf(2.f);                                                         // :262
-    float r0 = 0.f, r1 = 0.f;
+  natt_tot = 0; vol0 = 0.f;
+#pragma unroll 1
+  for (int ph = 0; ph < 2; ++ph) {         // ONE call site of the solver: inverse solve (:267 / :251), then the proposal's forward solve
+    if (ph == 1) {
+      // ---- proposal in latent space ----
+      vol0 = ell;
+      const float scale = 2.38f / sqrtf(2.f);                                                       // :262
+      float r0 = 0.f, r1 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const float nz = a.zgen[(size_t)b * 2 + q];
-      if (f.mode == MFM_FLOW_RWMH) y[q] = y[q] + scale * nz;                                        // :268
-      else { const float up = f.ref_std * nz; r0 += y[q] * y[q]; y[q] = up; r1 += up * up; }        // :249
+      for (int q = 0; q < 2; ++q) {
+        const float nz = a.zgen[(size_t)b * 2 + q];
+        if (f.mode == MFM_FLOW_RWMH) y[q] = y[q] + scale * nz;                                      // :268
+        else { const float up = f.ref_std * nz; r0 += y[q] * y[q]; y[q] = up; r1 += up * up; }      // :249
+      }
+      if (f.mode == MFM_FLOW_IMH) lq_ref = -0.5f * (r0 - r1) / (f.ref_std * f.ref_std);             // :254-255
     }
-    if (f.mode == MFM_FLOW_IMH) lq_ref = -0.5f * (r0 - r1) / (f.ref_std * f.ref_std);               // :254-255
+    T.sign = ph == 0 ? -1 : 1;
+    solve(T, a.rtol, a.atol, a.max_attempts, y, ell, natt, a.rp, ph, b);
+    natt_tot += natt;
   }
-  T.sign = 1;
-  solve(T, a.rtol, a.atol, a.max_attempts, y, ell, natt, a.rp, 1, b);
-  natt_tot += natt;
   // ---- target at the proposal (:270 / :252), tempered: beta * loglik + logprior (the mixture has no prior term) ----
   double lp; float gg[2];
   if (N.T.n_modes <= 16) gmm_eval_lanes16<2>(N.T, y, T.c, &lp, gg);
@@ -657,15 +656,18 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(OdeArgs a, FlowArgs f) {
   }
 }
 
-// 4-chain tiles while the 16-chain tiling would leave CUs without a workgroup.  MFM_D2_TILE (development / tests): 16 keeps the
-// generic tile, 4 forces the 4-chain tiles, 4s the streamed-weight instance of them even where the resident one fits.
+// Which tiling serves a launch of `rows` samples.  The resident-weight 4-chain tile wherever its shape fits (measured against the
+// 16-chain tile: flow step of 512 chains 14.3 -> 2.75 ms, of 4096 chains 35.6 -> 24.1 ms, transform of 409,600 draws 568 -> 400 ms);
+// the streamed 4-chain tile for other widths while the 16-chain tiling would leave CUs without a workgroup (it pays 4 x the
+// weight traffic per chain: 868 ms on the 409,600 draws).  MFM_D2_TILE (development / tests): 16 forces the generic tile, 4 the
+// 4-chain tiles, 4s the streamed instance of them even where the resident one fits.
 static int pick(const NetDev& n, int hutch, int rows) {       // 0: generic 16-chain tile, 1: streamed 4-chain, 2: resident 4-chain
   if (!shape_ok(n, hutch)) return 0;
   const char* e = getenv("MFM_D2_TILE");
   if (e && atoi(e) == 16) return 0;
-  if (!e && rows / 16 >= 256) return 0;
   if (e && e[0] == '4' && e[1] == 's') return 1;
-  return shape_ok_r(n, hutch) ? 2 : 1;
+  if (shape_ok_r(n, hutch)) return 2;
+  return (e || rows / 16 < 256) ? 1 : 0;
 }
 static bool use_for(const NetDev& n, int hutch, int rows) { return pick(n, hutch, rows) != 0; }
 template <typename TILE>
@@ -681,11 +683,17 @@ static int launch_flow_t(const OdeArgs& a, const FlowArgs& f, size_t sm, hipStre
   return 0;
 }
 static int launch_transform(const OdeArgs& a, hipStream_t stream) {
-  if (pick(a.net, a.hutch, a.n) == 2) return launch_transform_t<TileR>(a, (size_t)layout_r().total * sizeof(float), stream);
+  if (pick(a.net, a.hutch, a.n) == 2) {
+    const size_t sm = (size_t)layout_r().total * sizeof(float);
+    return a.net.act == MFM_ACT_RELU ? launch_transform_t<TileR<MFM_ACT_RELU>>(a, sm, stream) : launch_transform_t<TileR<-1>>(a, sm, stream);
+  }
   return launch_transform_t<Tile>(a, (size_t)layout(a.net).total * sizeof(float), stream);
 }
 static int launch_flow(const OdeArgs& a, const FlowArgs& f, hipStream_t stream) {
-  if (pick(a.net, a.hutch, a.n) == 2) return launch_flow_t<TileR>(a, f, (size_t)layout_r().total * sizeof(float), stream);
+  if (pick(a.net, a.hutch, a.n) == 2) {
+    const size_t sm = (size_t)layout_r().total * sizeof(float);
+    return a.net.act == MFM_ACT_RELU ? launch_flow_t<TileR<MFM_ACT_RELU>>(a, f, sm, stream) : launch_flow_t<TileR<-1>>(a, f, sm, stream);
+  }
   return launch_flow_t<Tile>(a, f, (size_t)layout(a.net).total * sizeof(float), stream);
 }
 
