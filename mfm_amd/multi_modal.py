@@ -22,20 +22,12 @@ from .exe_flow_matching import run
 from .exe_others import run as run_others
 
 
-def _dirichlet(key, alpha):
-    """Gamma(alpha) draws by Marsaglia-Tsang with the host PRNG (the reference's 16-mode weights come from
-    jax.random.dirichlet(PRNGKey(0)...) whose gamma sampler is not restated: parameters are a build-side fixture)."""
-    rng = np.random.default_rng(int(key[1]))
-    g = rng.gamma(alpha)
-    return g / g.sum()
-
-
 def gmm16_parameters(num_modes=16, dim=2, lim=(-16, 16)):
     """(modes, covs, weights) of the `gaussian-mixture` example, multi_modal.py:39-47 (frozen in tests/golden/gmm16_params.npz)."""
     key_mode, key_cov, key_weight = jr.split(jr.PRNGKey(0), 3)
     modes = jr.uniform(key_mode, (num_modes, dim), lim[0] * .8, lim[1] * .8)
     covs = np.exp(.5 * jr.normal(key_cov, (num_modes, dim)))
-    weights = _dirichlet(key_weight, 4. * np.ones(num_modes))
+    weights = jr.dirichlet(key_weight, 4. * np.ones(num_modes))                # :45 (jax's gamma sampler restated: random.py)
     return modes, covs, weights
 
 

@@ -91,3 +91,40 @@ def truncated_normal(key, lower, upper, shape):
     a, b = erf(lower / np.sqrt(2.0)), erf(upper / np.sqrt(2.0))
     out = np.sqrt(2.0) * erfinv(uniform(key, shape, a, b))
     return np.clip(out, np.nextafter(lower, np.inf), np.nextafter(upper, -np.inf))
+
+
+def _gamma_one_log(key, alpha):
+    """log of one Gamma(alpha, 1) draw: ``jax._src.random._gamma_one(key, alpha, log_space=True)`` @ jax 0.4.26 (third-party,
+    restated from the published source: Marsaglia & Tsang's squeeze / rejection loop on threefry sub-keys, float64).  Key
+    plumbing: ``key, subkey = split(key)`` (the boost draw, used when alpha < 1), then per rejection round
+    ``key, x_key, U_key = split(key, 3)``; the proposal ``x`` is redrawn from ``split(x_key)`` while ``1 + c x <= 0``."""
+    alpha = float(alpha)
+    boost = alpha >= 1.0
+    alpha_orig = alpha
+    if not boost:
+        alpha = alpha + 1.0
+    d = alpha - 1.0 / 3.0
+    c = (1.0 / 3.0) / np.sqrt(d)
+    key, subkey = split(key)
+    X, V, U = 0.0, 1.0, 2.0                               # initial state: the loop condition holds
+    while U >= 1.0 - 0.0331 * (X * X) and np.log(U) >= X * 0.5 + d * ((1.0 - V) + np.log(V)):
+        key, x_key, U_key = split(key, 3)
+        kx, x, v = x_key, 0.0, -1.0
+        while v <= 0.0:
+            kx, sk = split(kx)
+            x = float(normal(sk, ()))
+            v = 1.0 + x * c
+        X, V, U = x * x, (v * v) * v, float(uniform(U_key, ()))
+    log_samples = np.log1p(-float(uniform(subkey, ())))   # -jax.random.exponential(subkey)
+    log_boost = 0.0 if (boost or log_samples == 0.0) else log_samples * (1.0 / alpha_orig)
+    return (np.log(d) + log_boost) + np.log(V)
+
+
+def dirichlet(key, alpha):
+    """``jax.random.dirichlet(key, alpha)`` for a 1-d ``alpha`` (multi_modal.py:45): log-space gamma draws on ``split(key, n)``
+    (``_gamma_impl``), then a softmax (``_dirichlet``)."""
+    alpha = np.asarray(alpha, dtype=np.float64)
+    keys = split(key, alpha.shape[0])
+    ls = np.array([_gamma_one_log(keys[i], alpha[i]) for i in range(alpha.shape[0])])
+    w = np.exp(ls - ls.max())
+    return w / w.sum()

@@ -179,3 +179,44 @@ def split_rows(keys, num):
     x1 = cnt[None, num:].repeat(n, 0)
     y0, y1 = threefry2x32((keys[:, 0:1], keys[:, 1:2]), x0, x1)
     return np.concatenate([y0, y1], axis=1).reshape(n, num, 2)
+
+
+# jax.random.dirichlet (multi_modal.py:45) ------------------------------------------------------------------------------------
+
+def gamma_log(key, alpha):
+    """``jax._src.random._gamma_one(key, alpha, log_space=True)`` (jax 0.4.26; third-party, restated from the published source
+    -- PARITY UNPINNED; the sampler is checked distributionally against scipy.stats.gamma in tests/test_oracle_prng.py):
+    Marsaglia-Tsang with ``d = alpha - 1/3``, ``c = 1 / (3 sqrt(d))``, squeeze ``U < 1 - 0.0331 x^4`` or
+    ``log U < x^2 / 2 + d (1 - v^3 + log v^3)``; alpha < 1 is boosted through ``log U' / alpha`` from the FIRST sub-key."""
+    a = np.float64(alpha)
+    boost = a >= 1.0
+    a0 = a
+    a = a if boost else a + 1.0
+    d = a - np.float64(1.0 / 3.0)
+    c = np.float64(1.0 / 3.0) / np.sqrt(d)
+    key, subkey = split(key)
+    X, V, U = np.float64(0.0), np.float64(1.0), np.float64(2.0)
+    while True:
+        cond = (U >= 1.0 - 0.0331 * (X * X)) and (np.log(U) >= X * 0.5 + d * ((1.0 - V) + np.log(V)))
+        if not cond:
+            break
+        key, x_key, u_key = split(key, 3)
+        kx, x, v = x_key, np.float64(0.0), np.float64(-1.0)
+        while v <= 0.0:
+            kx, sub = split(kx)
+            x = np.float64(normal(sub, ()).reshape(())[()])
+            v = 1.0 + x * c
+        X, V = x * x, (v * v) * v
+        U = np.float64(uniform(u_key, ()).reshape(())[()])
+    log_samples = np.log1p(-np.float64(uniform(subkey, ()).reshape(())[()]))
+    log_boost = 0.0 if (boost or log_samples == 0.0) else log_samples * (1.0 / a0)
+    return (np.log(d) + log_boost) + np.log(V)
+
+
+def dirichlet(key, alpha):
+    """``jax.random.dirichlet``: ``softmax(loggamma(key, alpha))`` with one sub-key per component (``split(key, n)``)."""
+    alpha = np.asarray(alpha, dtype=np.float64)
+    keys = split(key, alpha.shape[0])
+    ls = np.array([gamma_log(keys[i], alpha[i]) for i in range(alpha.shape[0])])
+    w = np.exp(ls - ls.max())
+    return w / w.sum()

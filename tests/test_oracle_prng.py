@@ -51,3 +51,22 @@ def test_normal_moments_and_range():
     assert abs(x.mean()) < 0.01 and abs(x.std() - 1) < 0.01
     u = prng.uniform(prng.PRNGKey(5), (200000,))
     assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.005
+
+
+def test_dirichlet_restatement():
+    """jax.random.dirichlet (multi_modal.py:45: the 16-mode mixture's weights) = softmax of log-space gamma draws on
+    split(key, n).  jax itself is absent: the sampler is checked as a SAMPLER (Kolmogorov-Smirnov against scipy's gamma law
+    for boosted and unboosted shapes), the oracle's and the host module's restatements against each other bit for bit."""
+    from scipy import stats
+    from mfm_amd import random as jr
+    key = prng.split(prng.PRNGKey(0), 3)[2]
+    w = prng.dirichlet(key, 4.0 * np.ones(16))
+    np.testing.assert_array_equal(w, jr.dirichlet(key, 4.0 * np.ones(16)))
+    assert abs(w.sum() - 1.0) < 1e-14 and (w > 0).all()
+    for a in (0.3, 1.0, 4.0):
+        keys = prng.split(prng.PRNGKey(7), 600)
+        x = np.exp([prng.gamma_log(k, a) for k in keys])
+        assert stats.kstest(x, stats.gamma(a).cdf).pvalue > 1e-3, a
+    d = np.array([prng.dirichlet(k, 4.0 * np.ones(4)) for k in prng.split(prng.PRNGKey(9), 300)])
+    np.testing.assert_allclose(d.mean(0), 0.25, atol=0.02)                         # E[w_i] = alpha_i / sum(alpha)
+    np.testing.assert_allclose(d.var(0), 0.25 * 0.75 / 17.0, rtol=0.3)             # Var[w_i] = a_i (a_0 - a_i) / (a_0^2 (a_0 + 1))

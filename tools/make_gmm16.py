@@ -1,11 +1,12 @@
 """Freeze the parameters of the 16-mode `gaussian-mixture` target (BASELINE configs[1]).
 
 The reference draws them at start-up from jax.random.PRNGKey(0) (multi_modal.py:39-47): 16 modes U(-12.8, 12.8)^2, per-coordinate
-variances exp(0.5 N(0, 1)), weights Dirichlet(4 * 1_16).  jax's gamma sampler (behind `dirichlet`) is third-party arithmetic that
-is not restated here, and jax cannot be imported in the build container, so -- as SURVEY.md section 8(c) prescribes -- the
-parameters are a committed fixture drawn ONCE with the build's own generator: the threefry conventions of mfm_amd/random.py for
-the modes and variances (the same call sequence as the reference) and a numpy gamma draw seeded by the weight key.
-`mfm_amd.multi_modal.main` constructs the target by the same recipe; tests/test_golden.py checks that it reproduces this file.
+variances exp(0.5 N(0, 1)), weights Dirichlet(4 * 1_16).  jax cannot be imported in the build container, so the draws are made
+with the build's own restatement of jax.random (mfm_amd/random.py: threefry conventions; `dirichlet` = jax's log-space
+Marsaglia-Tsang gamma sampler on split(key, 16) + softmax, restated from the published source of jax 0.4.26 and checked
+distributionally in tests/test_oracle_prng.py -- third-party arithmetic, parity unpinned) in the reference's call sequence, and
+frozen here so the GPU tests and bench.py have a fixed target.  `mfm_amd.multi_modal.main` constructs the target by the same
+recipe; tests/test_oracle_replay_final.py checks that it reproduces this file.
 
 Usage: python tools/make_gmm16.py  ->  tests/golden/gmm16_params.npz
 """
