@@ -183,7 +183,7 @@ def pmc_traffic(kernel_class, workload="phi-four"):
     files = {"phi-four": ("profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"),       # newest committed summary first
              "gaussian-mixture": ("profiles/r02_gmm_pmc_summary.json",), "4-mode": ("profiles/r02_4mode_pmc_summary.json",),
              "pines": ("profiles/r02_pines_pmc_summary.json",)}.get(workload, ())
-    pattern = {"fm_eval": "fm_eval64"}.get(kernel_class, kernel_class)
+    pattern = {"fm_eval": "fm_eval_kernel"}.get(kernel_class, kernel_class)
     if workload == "pines":
         return None, None      # its roofline entry is the whole training step (many launches): per-kernel traffic is in the summary file
     for rel in files:

@@ -414,34 +414,41 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
 // t1 / j1, x1 / j2) so that 64 rows fit in LDS.  Same per-sample arithmetic as fm_fwd_bwd_kernel<.., TRAIN = false> (same
 // k-order per accumulator); the per-workgroup loss partial covers 64 samples instead of 16.  For dp <= 16 (the mixtures).
 struct FmEvalLds { int a, lda, b, ldb, c, ldc, x, ldx, g, ldg, tgt, tt, gcs, red, gmm, total; };
-__host__ __device__ inline FmEvalLds fm_eval_lds_layout(const NetDev& n) {
+__host__ __device__ inline FmEvalLds fm_eval_lds_layout(const NetDev& n, int R = 64) {      // R: samples per workgroup
   FmEvalLds L; int o = 0;
   auto take = [&](int cnt) { int r = o; o += cnt; return r; };
   auto mx = [](int a, int b) { return a > b ? a : b; };
-  L.lda = mx(n.F2p, n.hx2 + n.ht2) + 8; L.a = take(64 * L.lda);       // Fourier features, then [sx | st]
-  L.ldb = mx(n.ht1, n.hj1) + 8;         L.b = take(64 * L.ldb);       // t1, then j1
-  L.ldc = mx(n.hx1, n.hj2) + 8;         L.c = take(64 * L.ldc);       // x1, then j2
-  L.ldx = n.dp + 8;                     L.x = take(64 * L.ldx);       // cond (data at column 4)
-  L.ldg = n.dp + 8;                     L.g = take(64 * L.ldg);       // gate
-  L.tgt = take(64 * n.dp); L.tt = take(64); L.gcs = take(64 * 8); L.red = take(32);
+  L.lda = mx(n.F2p, n.hx2 + n.ht2) + 8; L.a = take(R * L.lda);       // Fourier features, then [sx | st]
+  L.ldb = mx(n.ht1, n.hj1) + 8;         L.b = take(R * L.ldb);       // t1, then j1
+  L.ldc = mx(n.hx1, n.hj2) + 8;         L.c = take(R * L.ldc);       // x1, then j2
+  L.ldx = n.dp + 8;                     L.x = take(R * L.ldx);       // cond (data at column 4)
+  L.ldg = n.dp + 8;                     L.g = take(R * L.ldg);       // gate
+  L.tgt = take(R * n.dp); L.tt = take(R); L.gcs = take(R * 8); L.red = take(32);
   L.gmm = take(n.T.kind == MFM_TARGET_GMM ? n.T.n_modes * (2 * n.d + 1) : 0);      // mixture parameters, staged once per workgroup
   L.total = o;
   return L;
 }
-__global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_eval64_kernel(FmArgs a) {
+// MT row tiles of 16 samples per workgroup.  MT = 4: every streamed weight fragment feeds four MFMA tiles, one workgroup per CU
+// (137 KB of LDS).  MT = 2: half the LDS and <= 128 registers, so TWO workgroups share a CU and one's batch construction
+// (threefry + erfinv draws, sincos, the mixture's gradient: 15 % of a workgroup's cycles, all vector ALU), epilogues and
+// barriers run under the other's MFMAs -- the measured section stamps of the MT = 4 kernel put its matrix pipe at 52 %.
+template <int MT, int ACT>       // ACT: the hidden non-linearity as a compile-time constant (MFM_ACT_*), or -1: read from the network
+__global__ __launch_bounds__((MLP_WAVES_FM * 64), (MT == 2 ? 4 : 2)) void fm_eval_kernel(FmArgs a) {      // (threads, waves per SIMD)
+  constexpr int R = 16 * MT;
+  const int act = ACT >= 0 ? ACT : a.net.act;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const NetDev& n = a.net;
-  const FmEvalLds L = fm_eval_lds_layout(n);
+  const FmEvalLds L = fm_eval_lds_layout(n, R);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
-  const int b0 = blockIdx.x * 64, d = n.d;
+  const int b0 = blockIdx.x * R, d = n.d;
   constexpr int NT_ = MLP_WAVES_FM * 64;
   float* bA = lds + L.a; float* bB = lds + L.b; float* bC = lds + L.c; float* bX = lds + L.x; float* bG = lds + L.g;
   float* bT = lds + L.tgt; float* btt = lds + L.tt; float* gcs = lds + L.gcs; double* red = reinterpret_cast<double*>(lds + L.red);
   FM_STAMP(0);
   // ---- batch construction (:151-169 / :139-147), rows past the end of the batch are zero rows that do not count ----
-  for (int i = threadIdx.x; i < 64 * L.ldx; i += NT_) bX[i] = 0.f;
-  for (int i = threadIdx.x; i < 64 * n.dp; i += NT_) bT[i] = 0.f;
-  for (int r = threadIdx.x; r < 64; r += NT_)
+  for (int i = threadIdx.x; i < R * L.ldx; i += NT_) bX[i] = 0.f;
+  for (int i = threadIdx.x; i < R * n.dp; i += NT_) bT[i] = 0.f;
+  for (int r = threadIdx.x; r < R; r += NT_)
     btt[r] = b0 + r < a.B ? (float)uniform01(a.key_time, a.chain_offset + (uint32_t)(b0 + r), a.n_total) : 0.f;      // :154 / :142
   TargetDev Tl = n.T;                       // the mixture's parameters from LDS: gmm_eval walks them twice per row, one row per thread
   if (n.T.kind == MFM_TARGET_GMM) {
@@ -452,7 +459,32 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_eval64_kernel(FmArgs a
     Tl.gmm_mode = gm; Tl.gmm_std = gm + K * d; Tl.gmm_logw = gm + 2 * K * d;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 64 * d; e += NT_) {          // only the d live columns draw (the pads of cond / target stay zero)
+  // only the d live columns draw (the pads of cond / target stay zero).  With few columns (the d = 2 mixtures: 2 R elements on
+  // 512 threads) the two Gaussian draws of an element go to two threads and meet in LDS (float64, in the t1 buffer, which is
+  // free until the first GEMM): one threefry + erfinv chain per thread instead of two in sequence
+  if (a.cond_flow && 2 * R * d <= NT_) {
+    double* stage = reinterpret_cast<double*>(bB);
+    const int e = threadIdx.x >> 1, which = threadIdx.x & 1;
+    if (e < R * d) {
+      const int row = e / d, col = e - row * d;
+      const uint32_t bg = a.chain_offset + (uint32_t)(b0 + row);
+      double v = 0.0;
+      if (b0 + row < a.B)
+        v = which == 0 ? a.ref_std * normal64(split_at(a.key_ref, a.n_total, bg), (uint32_t)col, (uint32_t)d)                  // :155
+                       : normal64(a.key_gauss, bg * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);                     // :166
+      stage[2 * e + which] = v;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < R * d; q += NT_) {
+      const int row = q / d, col = q - row * d;
+      if (b0 + row < a.B) {
+        const double x1v = a.pos[(size_t)(b0 + row) * d + col], t = btt[row], x0 = stage[2 * q], ne = stage[2 * q + 1];
+        bX[row * L.ldx + 4 + col] = (float)((double)a.sigma * ne + t * x1v + (1.0 - t) * x0);                                   // :167
+        bT[row * n.dp + col] = (float)(x1v - x0);                                                                               // :168
+      }
+    }
+  } else
+  for (int e = threadIdx.x; e < R * d; e += NT_) {
     const int row = e / d, col = e - row * d;
     if (b0 + row < a.B) {
       const uint32_t bg = a.chain_offset + (uint32_t)(b0 + row);
@@ -475,7 +507,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_eval64_kernel(FmArgs a
   if (NT_ % n.F == 0) {
     const int col = threadIdx.x % n.F;
     const double f = n.fourier[col];
-    for (int row = threadIdx.x / n.F; row < 64; row += NT_ / n.F) {
+    for (int row = threadIdx.x / n.F; row < R; row += NT_ / n.F) {
       double ft = f * (double)btt[row];
       ft -= rint(ft);
       float sv, cvv;
@@ -483,7 +515,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_eval64_kernel(FmArgs a
       bA[row * L.lda + col] = cvv; bA[row * L.lda + n.F + col] = sv;
     }
   } else {
-    for (int e = threadIdx.x; e < 64 * n.F; e += NT_) {
+    for (int e = threadIdx.x; e < R * n.F; e += NT_) {
       const int row = e / n.F, col = e - row * n.F;
       double ft = (double)n.fourier[col] * (double)btt[row];
       ft -= rint(ft);
@@ -492,7 +524,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_eval64_kernel(FmArgs a
       bA[row * L.lda + col] = cvv; bA[row * L.lda + n.F + col] = sv;
     }
   }
-  for (int e = threadIdx.x; e < 64 * (n.F2p - 2 * n.F); e += NT_) {      // pad columns of the first layer's K (F2p = ceil16(2 F))
+  for (int e = threadIdx.x; e < R * (n.F2p - 2 * n.F); e += NT_) {      // pad columns of the first layer's K (F2p = ceil16(2 F))
     const int w = n.F2p - 2 * n.F, row = e / w;
     bA[row * L.lda + 2 * n.F + (e - row * w)] = 0.f;
   }
@@ -503,14 +535,15 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_eval64_kernel(FmArgs a
   // 512 threads busy (the serial per-row walk over the modes was ~3.4 k instructions on one wave, 8-14 k cycles on the critical
   // path of every workgroup).  The sums run over the modes in another order than gmm_eval's loop: float rounding only.
   if (n.T.kind == MFM_TARGET_GMM && n.T.n_modes <= 16) {
-    for (int p = threadIdx.x; p < 64 * 16; p += NT_) {
+    for (int p = threadIdx.x; p < R * 16; p += NT_) {
       const int row = p >> 4;
       double lp; float gg[8];
-      gmm_eval_lanes16<8>(Tl, bX + row * L.ldx + 4, p & 15, &lp, gg);
+      if (d == 2) gmm_eval_lanes16<2>(Tl, bX + row * L.ldx + 4, p & 15, &lp, gg);      // (the same sums; the unrolled walk over 8 - d dead columns dropped)
+      else gmm_eval_lanes16<8>(Tl, bX + row * L.ldx + 4, p & 15, &lp, gg);
       if ((p & 15) == 0)
         for (int j = 0; j < d; ++j) gcs[row * 8 + j] = gg[j];
     }
-  } else if (n.T.kind == MFM_TARGET_GMM && wave == MLP_WAVES_FM - 1) {
+  } else if (n.T.kind == MFM_TARGET_GMM && wave == MLP_WAVES_FM - 1 && lane < R) {
     const int row = lane;
     double lp; float gg[8];
     gmm_eval<8>(Tl, bX + row * L.ldx + 4, &lp, gg);
@@ -520,39 +553,54 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_eval64_kernel(FmArgs a
   auto relu_store = [&](float* out, int ldo, int coff) {
     return [&, out, ldo, coff](int q, int nt, int m, f32x4 acc, float bias) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) out[(16 * m + 4 * g + i) * ldo + coff + nt * 16 + c] = act_f(acc[i] + bias, n.act);
+      for (int i = 0; i < 4; ++i) out[(16 * m + 4 * g + i) * ldo + coff + nt * 16 + c] = act_f(acc[i] + bias, act);
     };
   };
   auto L_ = [&](int l) -> const LayerDesc& { return n.L[l]; };
-  layer_gemm<4, MLP_WAVES_FM>(bA, L.lda, n.Wp + L_(0).w_off, n.bias + L_(0).b_off, L_(0).Kp / 16, L_(0).Np / 16, wave, lane, relu_store(bB, L.ldb, 0));       // t1
+  layer_gemm<MT, MLP_WAVES_FM>(bA, L.lda, n.Wp + L_(0).w_off, n.bias + L_(0).b_off, L_(0).Kp / 16, L_(0).Np / 16, wave, lane, relu_store(bB, L.ldb, 0));       // t1
   FM_STAMP(4);
-  layer_gemm<4, MLP_WAVES_FM>(bX + 4, L.ldx, n.Wp + L_(2).w_off, n.bias + L_(2).b_off, L_(2).Kp / 16, L_(2).Np / 16, wave, lane, relu_store(bC, L.ldc, 0));   // x1
+  if (d == 2) {        // x1 with K = 2: two multiply-adds per output on the vector ALU (as a GEMM job its 16-deep padded K and the
+                       // wait of seven idle waves cost 7 k cycles per workgroup)
+    const float* W2 = n.Wp + L_(2).w_off;
+    if (NT_ % n.hx1 == 0) {          // a thread keeps its column (two weights and the bias in registers) while it walks the rows
+      const int col = threadIdx.x % n.hx1;
+      const float w0 = W2[pack_index(0, col, 1)], w1 = W2[pack_index(1, col, 1)], bb = n.bias[L_(2).b_off + col];
+      for (int row = threadIdx.x / n.hx1; row < R; row += NT_ / n.hx1)
+        bC[row * L.ldc + col] = act_f(fmaf(bX[row * L.ldx + 5], w1, bX[row * L.ldx + 4] * w0) + bb, act);
+    } else
+    for (int e = threadIdx.x; e < R * n.hx1; e += NT_) {
+      const int row = e / n.hx1, col = e - row * n.hx1;
+      const float pre = fmaf(bX[row * L.ldx + 5], W2[pack_index(1, col, 1)], bX[row * L.ldx + 4] * W2[pack_index(0, col, 1)]) + n.bias[L_(2).b_off + col];
+      bC[row * L.ldc + col] = act_f(pre, act);
+    }
+  } else
+  layer_gemm<MT, MLP_WAVES_FM>(bX + 4, L.ldx, n.Wp + L_(2).w_off, n.bias + L_(2).b_off, L_(2).Kp / 16, L_(2).Np / 16, wave, lane, relu_store(bC, L.ldc, 0));   // x1
   __syncthreads();
   FM_STAMP(5);
-  layer_gemm<4, MLP_WAVES_FM>(bB, L.ldb, n.Wp + L_(1).w_off, n.bias + L_(1).b_off, L_(1).Kp / 16, L_(1).Np / 16, wave, lane, relu_store(bA, L.lda, n.hx2));   // st
-  layer_gemm<4, MLP_WAVES_FM>(bC, L.ldc, n.Wp + L_(3).w_off, n.bias + L_(3).b_off, L_(3).Kp / 16, L_(3).Np / 16, wave, lane, relu_store(bA, L.lda, 0));       // sx
+  layer_gemm<MT, MLP_WAVES_FM>(bB, L.ldb, n.Wp + L_(1).w_off, n.bias + L_(1).b_off, L_(1).Kp / 16, L_(1).Np / 16, wave, lane, relu_store(bA, L.lda, n.hx2));   // st
+  layer_gemm<MT, MLP_WAVES_FM>(bC, L.ldc, n.Wp + L_(3).w_off, n.bias + L_(3).b_off, L_(3).Kp / 16, L_(3).Np / 16, wave, lane, relu_store(bA, L.lda, 0));       // sx
   __syncthreads();
   FM_STAMP(6);
   // gate and out have dp / 16 = 1 column tile: instead of ONE wave pushing the four row tiles through it (the other seven
   // waiting at the barrier), four waves take one row tile each
   const bool narrow = n.dp == 16;
   if (narrow) {
-    if (wave < 4)
+    if (wave < MT)
       layer_gemm<1, 1>(bA + n.hx2 + wave * 16 * L.lda, L.lda, n.Wp + L_(4).w_off, n.bias + L_(4).b_off, L_(4).Kp / 16, 1, 0, lane,
                        [&](int q, int nt, int m, f32x4 acc, float bias) {
 #pragma unroll
                          for (int i = 0; i < 4; ++i) bG[(16 * wave + 4 * g + i) * L.ldg + c] = acc[i] + bias;
                        });
   } else
-  layer_gemm<4, MLP_WAVES_FM>(bA + n.hx2, L.lda, n.Wp + L_(4).w_off, n.bias + L_(4).b_off, L_(4).Kp / 16, L_(4).Np / 16, wave, lane,                         // gate
+  layer_gemm<MT, MLP_WAVES_FM>(bA + n.hx2, L.lda, n.Wp + L_(4).w_off, n.bias + L_(4).b_off, L_(4).Kp / 16, L_(4).Np / 16, wave, lane,                         // gate
                               [&](int q, int nt, int m, f32x4 acc, float bias) {
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) bG[(16 * m + 4 * g + i) * L.ldg + nt * 16 + c] = acc[i] + bias;
                               });
-  layer_gemm<4, MLP_WAVES_FM>(bA, L.lda, n.Wp + L_(5).w_off, n.bias + L_(5).b_off, L_(5).Kp / 16, L_(5).Np / 16, wave, lane, relu_store(bB, L.ldb, 0));       // j1
+  layer_gemm<MT, MLP_WAVES_FM>(bA, L.lda, n.Wp + L_(5).w_off, n.bias + L_(5).b_off, L_(5).Kp / 16, L_(5).Np / 16, wave, lane, relu_store(bB, L.ldb, 0));       // j1
   __syncthreads();
   FM_STAMP(7);
-  layer_gemm<4, MLP_WAVES_FM>(bB, L.ldb, n.Wp + L_(6).w_off, n.bias + L_(6).b_off, L_(6).Kp / 16, L_(6).Np / 16, wave, lane, relu_store(bC, L.ldc, 0));       // j2
+  layer_gemm<MT, MLP_WAVES_FM>(bB, L.ldb, n.Wp + L_(6).w_off, n.bias + L_(6).b_off, L_(6).Kp / 16, L_(6).Np / 16, wave, lane, relu_store(bC, L.ldc, 0));       // j2
   __syncthreads();
   FM_STAMP(8);
   float loss_loc = 0.f;        // out + loss (:88-90, :177-178)
@@ -569,11 +617,11 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_eval64_kernel(FmArgs a
     }
   };
   if (narrow) {
-    if (wave < 4)
+    if (wave < MT)
       layer_gemm<1, 1>(bC + wave * 16 * L.ldc, L.ldc, n.Wp + L_(7).w_off, n.bias + L_(7).b_off, L_(7).Kp / 16, 1, 0, lane,
                        [&](int q, int nt, int m, f32x4 acc, float bias) { out_epi(wave, 0, acc, bias); });
   } else
-  layer_gemm<4, MLP_WAVES_FM>(bC, L.ldc, n.Wp + L_(7).w_off, n.bias + L_(7).b_off, L_(7).Kp / 16, L_(7).Np / 16, wave, lane,
+  layer_gemm<MT, MLP_WAVES_FM>(bC, L.ldc, n.Wp + L_(7).w_off, n.bias + L_(7).b_off, L_(7).Kp / 16, L_(7).Np / 16, wave, lane,
                               [&](int q, int nt, int m, f32x4 acc, float bias) { out_epi(m, nt, acc, bias); });
   FM_STAMP(9);
   const double lw = wave_sum((double)loss_loc);
@@ -761,16 +809,27 @@ __global__ void reduce_loss_kernel(const double* part, int n, double* out, int a
 
 // ---- launchers ---------------------------------------------------------------------------------------------
 // number of per-workgroup loss partials the forward-only launch of `n` samples leaves in loss_part
-static bool fm_eval64_ok(const NetDev& n, int B) {
-  return n.dp <= 16 && n.T.kind != MFM_TARGET_LGCP && B >= 64 * 256 && (size_t)fm_eval_lds_layout(n).total * sizeof(float) <= 160 * 1024 && !getenv("MFM_EVAL16");
+static int fm_eval_rows(const NetDev& n, int B) {      // samples per workgroup of the forward-only kernel (0: the 16-chain training tile)
+  if (n.dp > 16 || n.T.kind == MFM_TARGET_LGCP || B < 64 * 256 || getenv("MFM_EVAL16")) return 0;
+  const char* e = getenv("MFM_EVAL_ROWS");
+  const int r = e ? atoi(e) : 32;
+  if ((r != 32 && r != 64) || (size_t)fm_eval_lds_layout(n, r).total * sizeof(float) > (r == 32 ? 80 : 160) * 1024) return 0;
+  return r;
 }
-int fm_eval_parts(const NetDev& n, int B) { return fm_eval64_ok(n, B) ? (B + 63) / 64 : B / 16; }
+int fm_eval_parts(const NetDev& n, int B) { const int r = fm_eval_rows(n, B); return r ? (B + r - 1) / r : B / 16; }
 
 int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
-  if (!train && fm_eval64_ok(a.net, a.B)) {
-    const size_t sm64 = (size_t)fm_eval_lds_layout(a.net).total * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)fm_eval64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm64);
-    hipLaunchKernelGGL(fm_eval64_kernel, dim3((a.B + 63) / 64), dim3(MLP_WAVES_FM * 64), sm64, stream, a);
+  if (const int r = train ? 0 : fm_eval_rows(a.net, a.B)) {
+    const size_t smr = (size_t)fm_eval_lds_layout(a.net, r).total * sizeof(float);
+#define FM_EVAL_LAUNCH(MT_, ACT_)                                                                                     \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)fm_eval_kernel<MT_, ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr); \
+    hipLaunchKernelGGL((fm_eval_kernel<MT_, ACT_>), dim3((a.B + 16 * MT_ - 1) / (16 * MT_)), dim3(MLP_WAVES_FM * 64), smr, stream, a); \
+  } while (0)
+    const bool relu = a.net.act == MFM_ACT_RELU;
+    if (r == 32) { if (relu) FM_EVAL_LAUNCH(2, MFM_ACT_RELU); else FM_EVAL_LAUNCH(2, -1); }
+    else { if (relu) FM_EVAL_LAUNCH(4, MFM_ACT_RELU); else FM_EVAL_LAUNCH(4, -1); }
+#undef FM_EVAL_LAUNCH
     return 0;
   }
   const FmLds L = fm_lds_layout(a.net, train);

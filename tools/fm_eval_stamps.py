@@ -11,13 +11,14 @@ params = gu.rand_params(model, seed=3)
 ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, max_eval=n_eval)
 xs = torch.randn(n_eval, 2, device="cuda") * 8
 loss = torch.zeros(1, dtype=torch.float64, device="cuda")
-buf = torch.zeros(6400 * 32, dtype=torch.int64, device="cuda")
+buf = torch.zeros(12800 * 32, dtype=torch.int64, device="cuda")
 ctx.lib.mfm_debug_fm_buffer.argtypes = [C.c_void_p]
 assert ctx.lib.mfm_debug_fm_buffer(C.c_void_p(buf.data_ptr())) == 0
 for _ in range(2):
     ctx.fm_loss(prng.PRNGKey(1), xs, loss, n_total=n_eval)
 torch.cuda.synchronize()
-s = buf.cpu().numpy().reshape(6400, 32)[:, :11].astype(np.float64)
+rows = int(os.environ.get("MFM_EVAL_ROWS", "32"))
+s = buf.cpu().numpy().reshape(12800, 32)[:n_eval // rows, :11].astype(np.float64)
 dlt = np.diff(s, axis=1)
 names = ["zero + t + cond/target draws", "fourier features + barrier", "gmm grad (8 lanes per wave)", "t1 job", "x1 job + barrier", "st, sx jobs + barrier",
          "gate, j1 jobs + barrier", "j2 job + barrier", "out job + loss", "loss reduction"]
