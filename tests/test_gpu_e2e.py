@@ -1,0 +1,144 @@
+"""END-TO-END parity at the reference's real shapes: `mfm_amd.exe_flow_matching.run` on the GPU against frozen runs of the CPU
+oracle (tests/golden/e2e_*.npz, made by tools/make_e2e_golden.py: minutes to hours of CPU time per seed).
+
+* BASELINE configs[0] -- `--example 4-mode --num_chain 512 --learning_iter 100 --mcmc_per_flow_steps 10 --seed 1`
+  (multi_modal.py:65-85, every other flag at its default: hidden 128, Fourier 128, exact trace, n_ts = 5, `eval_step` on 51,200
+  exact samples, final sampling of 51,200 flow samples + importance resampling, logpdf / KSD / MMD:
+  exe_flow_matching.py:432-449,453-490);
+* the reference's own phi-four defaults (multi_modal.py:50-63: d = 64, 1024 chains, step 1e-4, exact trace, K = 10), three
+  MALA / flow cycles.
+
+Tolerances.  Until the first flow step (iterations 1..10) GPU and oracle see the same chains and the same
+noise: traces agree to float32 rounding.  From the first flow-MH step on, a borderline accept decision may differ between
+float32 and float64 (and the two adaptive solvers stop at slightly different points), which changes one chain's state and
+through the gradient every later iteration: same-seed traces then agree to a FRACTION OF THE SEED-TO-SEED SPREAD of the oracle
+itself (three frozen seeds), which is the yardstick every statistical bound below is written in.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _gold(case):
+    z = np.load(os.path.join(GOLD, f"e2e_{case}.npz"))
+    seeds = [int(s) for s in z["seeds"]]
+    return {s: {k[len(f"s{s}_"):]: z[k] for k in z.files if k.startswith(f"s{s}_")} for s in seeds}
+
+
+def _spread(g, key):
+    a = np.stack([np.asarray(g[s][key], dtype=np.float64) for s in sorted(g)])
+    return a.max(0) - a.min(0)
+
+
+def _run(case):
+    from mfm_amd import distributions as D, exe_flow_matching as E
+    from oracle import loop
+    from tools.make_e2e_golden import CASES
+    args = loop.default_args(seed=1, **CASES[case])
+    if case == "4mode":
+        dist = D.GaussianMixture(8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4)
+        tg = dist.sample_model
+    else:
+        dist, tg = D.PhiFour(64), None
+    res, res_, ex = E.run(dist, args, tg, log_every=1000, return_extras=True)
+    return args, res, res_, ex
+
+
+def _rel(a, b):
+    return np.abs(np.asarray(a, dtype=np.float64) - b) / np.maximum(np.abs(b), 1e-300)
+
+
+def test_four_mode_512_chains_100_iterations_matches_frozen_oracle_run():
+    g = _gold("4mode")
+    o = g[1]
+    args, res, res_, ex = _run("4mode")
+    m = ex["metrics"]                                          # loss | acc mean | acc std | target loss
+    K1 = 10                                                    # iterations before the first flow step (count 11)
+    pre = dict(loss=_rel(m[:K1, 0], o["loss"][:K1]).max(), target_loss=_rel(m[:K1, 3], o["target_loss"][:K1]).max(),
+               beta=_rel(ex["betas"][:K1], o["beta"][:K1]).max(), acc_mean=np.abs(m[:K1, 1] - o["acc_mean"][:K1]).max(),
+               acc_std=np.abs(m[:K1, 2] - o["acc_std"][:K1]).max())
+    print("4-mode e2e, iterations 1..10 (same chains, same noise):", {k: f"{v:.1e}" for k, v in pre.items()})
+    assert pre["loss"] < 1e-6 and pre["target_loss"] < 1e-6 and pre["beta"] < 1e-6, pre
+    assert pre["acc_mean"] < 1e-5 and pre["acc_std"] < 1e-5, pre
+    np.testing.assert_allclose(ex["lrs"], o["learning_rate"], rtol=1e-12)
+    # ---- after the first flow step: same-seed difference against the oracle's own seed-to-seed spread ----
+    mala_it = np.array([i for i in range(100) if (i + 1) % 11 != 0])
+    post = {}
+    for name, got, key in (("loss", m[:, 0], "loss"), ("target_loss", m[:, 3], "target_loss"), ("beta", ex["betas"], "beta")):
+        d = np.abs(np.asarray(got, dtype=np.float64) - o[key])[K1:]
+        sp = _spread(g, key)[K1:]
+        post[name] = (float(np.median(_rel(got, o[key])[K1:])), float(_rel(got, o[key])[K1:].max()), float(np.median(d) / max(np.median(sp), 1e-300)))
+    d_acc = np.abs(m[mala_it, 1] - o["acc_mean"][mala_it])
+    print("   iterations 11..100: (median rel, max rel, median |d| / median seed spread):", {k: tuple(f"{x:.1e}" for x in v) for k, v in post.items()},
+          f"MALA acceptance |d| max {d_acc.max():.1e}")
+    # measured: loss median 6e-4 / worst iteration 4e-2 (0.4 % of the seed spread), target loss 1.7e-4 / 1.1e-3, beta 1.7e-5,
+    # MALA acceptance 6.5e-4
+    for name in post:
+        assert post[name][2] < 0.05, (name, post[name])       # a twentieth of the spread between seeds
+    assert post["loss"][0] < 5e-3 and post["loss"][1] < 0.1 and post["target_loss"][1] < 5e-3 and post["beta"][1] < 1e-3, post
+    assert d_acc.max() < 5e-3
+    # ---- final chains: first two moments ----
+    pos = ex["states"].position.cpu().numpy().astype(np.float64)
+    occ = lambda x: np.array([((x[:, 0] > 0) == a) & ((x[:, 1] > 0) == b) for a in (True, False) for b in (True, False)]).sum(1)
+    occ_g, occ_o = occ(pos), occ(o["chain_pos"].astype(np.float64))
+    sec = (pos[:, :, None] * pos[:, None, :]).mean(0)
+    print(f"   final chains: mode occupancy gpu {occ_g} oracle {occ_o}; mean gpu {pos.mean(0)} oracle {o['chain_mean']}; "
+          f"second moment rel diff {np.abs(sec - o['chain_second']).max() / np.abs(o['chain_second']).max():.1e}")
+    assert np.abs(occ_g - occ_o).max() <= 8                    # chains whose flow-MH decisions differ may sit in another mode (measured: 3)
+    assert np.abs(pos.mean(0) - o["chain_mean"]).max() < 0.25 * _spread(g, "chain_mean").max()
+    assert np.abs(sec - o["chain_second"]).max() < 2e-2 * np.abs(o["chain_second"]).max()
+    # ---- final flow samples (51,200 draws through the trained flow) and the reference's result vector (:561) ----
+    fs = ex["flow_samples"].cpu().numpy().astype(np.float64); es = ex["exact_samples"].cpu().numpy().astype(np.float64)
+    fin = dict(logpdf=(res[0], o["logpdf"]), ksd_u=(res[1], o["ksd_u"]), ksd_v=(res[2], o["ksd_v"]), mmd=(res[3], o["mmd"]),
+               logpdf_exact=(res_[0], o["logpdf_exact"]), ksd_v_exact=(res_[2], o["ksd_v_exact"]), mmd_exact=(res_[3], o["mmd_exact"]))
+    rep = {k: (float(a), float(b), float(abs(a - b) / max(float(_spread(g, k)), 1e-300))) for k, (a, b) in fin.items()}
+    print("   final metrics (gpu, oracle, |d| / seed spread):", {k: tuple(f"{x:.4g}" for x in v) for k, v in rep.items()})
+    print(f"   flow samples: mean gpu {fs.mean(0)} oracle {o['flow_mean']}, second gpu {(fs ** 2).mean(0)} oracle {o['flow_second']}; "
+          f"resampled: mean gpu {es.mean(0)} oracle {o['exact_mean']}")
+    # the flow's own samples: measured 0.4 .. 2 % of the seed spread (logpdf -4.308 vs -4.309, KSD-V 0.01192 vs 0.01194, MMD 2.28e-3
+    # vs 2.30e-3).  The importance-RESAMPLED set is a categorical draw of 51,200 from weights with an effective sample size of
+    # ~12,000: borderline picks differ with the last bits of the weights, and its metrics carry that Monte-Carlo noise (logpdf
+    # 0.025 apart = 0.55 of the seed spread, sd of the estimator ~ 1 / sqrt(ESS) ~ 0.01): bounded by the spread itself.
+    for k in ("logpdf", "ksd_u", "ksd_v", "mmd"):
+        assert rep[k][2] < 0.1, (k, rep[k])
+    for k in ("logpdf_exact", "ksd_v_exact", "mmd_exact"):
+        assert rep[k][2] < 1.0, (k, rep[k])
+    assert np.abs(fs.mean(0) - o["flow_mean"]).max() < 0.5 * max(_spread(g, "flow_mean").max(), 0.1)
+    assert np.abs((fs ** 2).mean(0) - o["flow_second"]).max() < 0.5 * max(_spread(g, "flow_second").max(), 0.5)
+    ex["engine"].close()
+
+
+def test_phi_four_reference_defaults_three_cycles_match_frozen_oracle_run():
+    g = _gold("phi4")
+    o = g[1]
+    args, res, res_, ex = _run("phi4")
+    m = ex["metrics"]
+    K1 = 10
+    pre = dict(loss=_rel(m[:K1, 0], o["loss"][:K1]).max(), beta=_rel(ex["betas"][:K1], o["beta"][:K1]).max(),
+               acc_mean=np.abs(m[:K1, 1] - o["acc_mean"][:K1]).max(), acc_std=np.abs(m[:K1, 2] - o["acc_std"][:K1]).max())
+    print("phi-four e2e, iterations 1..10:", {k: f"{v:.1e}" for k, v in pre.items()})
+    assert pre["loss"] < 2e-6 and pre["beta"] < 1e-6 and pre["acc_mean"] < 2e-5 and pre["acc_std"] < 2e-5, pre      # float32 acceptance probabilities next to 1
+    np.testing.assert_allclose(ex["lrs"], o["learning_rate"], rtol=1e-12)
+    mala_it = np.array([i for i in range(33) if (i + 1) % 11 != 0])
+    rl, rb = _rel(m[:, 0], o["loss"])[K1:], _rel(ex["betas"], o["beta"])[K1:]
+    sp = _spread(g, "loss")[K1:]
+    frac = np.median(np.abs(m[K1:, 0] - o["loss"][K1:])) / np.median(sp)
+    d_acc = np.abs(m[mala_it, 1] - o["acc_mean"][mala_it])
+    print(f"   iterations 11..33: loss rel median {np.median(rl):.1e} max {rl.max():.1e} (|d| / seed spread {frac:.2e}), beta rel max {rb.max():.1e}, "
+          f"MALA acceptance |d| max {d_acc.max():.1e}")
+    # measured: loss 8.6e-5 median / 2.2e-4 worst iteration (0.2 % of the seed spread), beta 2.6e-4, MALA acceptance 2.9e-6
+    assert frac < 0.05 and rl.max() < 2e-3 and rb.max() < 2e-3 and d_acc.max() < 1e-4
+    pos = ex["states"].position.cpu().numpy().astype(np.float64)
+    dm, ds = np.abs(pos.mean(0) - o["chain_mean"]).max(), np.abs((pos ** 2).mean(0) - o["chain_second"]).max()
+    print(f"   final chains: |d mean| {dm:.1e} (seed spread {_spread(g, 'chain_mean').max():.1e}), |d second| {ds:.1e} (seed spread {_spread(g, 'chain_second').max():.1e}); "
+          f"logpdf gpu {res[0]:.1f} oracle {float(o['logpdf']):.1f} (seed spread {float(_spread(g, 'logpdf')):.1f}), KSD-V gpu {res[2]:.1f} oracle {float(o['ksd_v']):.1f}")
+    # measured: mean 1.3e-3 (2 % of the seed spread), second moment 3.7e-3 (8 %), logpdf -3866.4 both, KSD-V 4640.0 vs 4639.9
+    assert dm < 0.1 * _spread(g, "chain_mean").max() and ds < 0.25 * _spread(g, "chain_second").max()
+    assert abs(res[0] - float(o["logpdf"])) < 0.05 * float(_spread(g, "logpdf"))
+    assert abs(res[2] - float(o["ksd_v"])) < 0.05 * float(_spread(g, "ksd_v"))
+    ex["engine"].close()
