@@ -67,7 +67,7 @@ struct mfm_ctx {
   WsLayout ws;
   bool has_target, has_fourier;
   float *master, *mu, *nu, *Wp, *WpT, *bias, *fourier;
-  float *acts, *dzs, *slabs;
+  float *acts, *dzs, *slabs, *dacts;
   double* loss_part; int loss_cap;
   WgradJob* jobs; int n_jobs, split;
   OptState* opt; int* flag;
@@ -209,11 +209,6 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
   if (x->cfg.ref_std == 0.0) x->cfg.ref_std = 1.0;           // zero-initialised config: the default 'stdgauss'
   if (!(x->cfg.ref_std > 0.0)) return fail(MFM_EINVAL, "ref_std must be positive");
   bool use_wide = c.kernel_family == MFM_FAMILY_WIDE;
-  if (c.activation >= MFM_ACT_GELU) {      // gelu / swish: the backward pass needs the pre-activations, which only the wide family keeps
-    if (c.kernel_family == MFM_FAMILY_TILE)
-      return fail(MFM_EUNSUPPORTED, "gelu / swish run on the wide kernel family (the fused tile keeps activations, not pre-activations, in LDS)");
-    use_wide = true;
-  }
   {
     const FmLds L = fm_lds_layout(n, true);
     size_t sm_ode; int tpw_ode;
@@ -243,6 +238,7 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
   ALLOC(x->Wp, n.n_packed); ALLOC(x->WpT, n.n_packed); ALLOC(x->bias, n.n_bias); ALLOC(x->fourier, n.F);
   if (!use_wide) {       // packed activation / gradient workspaces of the fused family
     ALLOC(x->acts, (size_t)x->ws.a_tiles * nbb * 256); ALLOC(x->dzs, (size_t)x->ws.z_tiles * nbb * 256);
+    if (c.activation >= MFM_ACT_GELU) ALLOC(x->dacts, (size_t)x->ws.a_tiles * nbb * 256);      // gelu / swish: f'(pre-activation), see FmArgs
     ALLOC(x->slabs, (size_t)x->split * n.n_params);
   }
   ALLOC(x->loss_part, x->loss_cap);
@@ -266,7 +262,7 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
 extern "C" int mfm_destroy(mfm_ctx* x) {
   if (!x) return MFM_OK;
   hipDeviceSynchronize();
-  void* ps[] = {x->master, x->mu, x->nu, x->Wp, x->WpT, x->bias, x->fourier, x->acts, x->dzs, x->slabs, x->loss_part,
+  void* ps[] = {x->master, x->mu, x->nu, x->Wp, x->WpT, x->bias, x->fourier, x->acts, x->dzs, x->dacts, x->slabs, x->loss_part,
                 x->jobs, x->opt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->beta_out,
                 x->d_att, x->att_buf};
   for (void* p : ps) if (p) hipFree(p);
@@ -507,7 +503,7 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
   }
   a.n_total = n_total; a.chain_offset = offset; a.B = n; a.sigma = x->cfg.sigma; a.cond_flow = x->cfg.cond_flow;
   a.ref_std = x->cfg.ref_std;
-  a.pos = d_samples; a.acts = x->acts; a.dzs = x->dzs; a.loss_part = x->loss_part;
+  a.pos = d_samples; a.acts = x->acts; a.dzs = x->dzs; a.dacts = x->dacts; a.loss_part = x->loss_part;
   if (x->wide) {      // R rows per pass; the loss is accumulated over the passes
     wide::Ctx* w = x->wide;
     for (int r0 = 0; r0 < n; r0 += w->R) {

@@ -31,6 +31,8 @@ struct FmArgs {
   const float* pos;      // [B][d] samples x1
   float* acts;           // packed activations (TRAIN only)
   float* dzs;            // packed pre-activation gradients (TRAIN only)
+  float* dacts;          // gelu / swish (TRAIN only): f'(pre-activation) of every hidden unit, packed like `acts` -- their backward
+                         // pass cannot recover f' from the stored output (relu, tanh, elu can), and LDS has no room for it
   double* loss_part;     // [gridDim.x] partial sums of squared residuals
   double ref_std;        // reference distribution of the flow: x0 = ref_std * normal (IndepGaussian(dim, var), distributions.py:93-97)
   const double* pre_x0; const double* pre_eps; const float* pre_t;   // non-null: the batch's draws, produced ahead of time by noise_kernel
@@ -255,6 +257,12 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
         out[(4 * g + i) * ldo + coff + nt * 16 + c] = v[i];
       }
       if (TRAIN) store_packed(a.acts, a_tile + nt, nbb, bb, lane, v);
+      if (TRAIN && n.act >= MFM_ACT_GELU) {          // the derivative the backward epilogue of this tile will need (same lane, same slots)
+        f32x4 dv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dv[i] = dact_pre(acc[i] + bias, n.act);
+        store_packed(a.dacts, a_tile + nt, nbb, bb, lane, dv);
+      }
     };
   };
   if (n.T.kind == MFM_TARGET_LGCP)      // grad log pi(cond) = c - a exp(cond) - K^-1 (cond - mu)
@@ -332,14 +340,21 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   if (!TRAIN) return;
 
   // ---------------- backward (data gradients only; weight gradients: wgrad_kernel) -----------------------------
+  // tangent of the loss through a hidden activation: from the stored OUTPUT (relu / tanh / elu), or times the derivative the
+  // forward epilogue of the same tile left in `dacts` (gelu / swish)
+  auto dmask = [&](float y, float t, const f32x4& dd, int i) { return n.act >= MFM_ACT_GELU ? t * dd[i] : mask_out(y, t, n.act); };
+  auto dload = [&](int a_tile, int nt) {
+    return n.act >= MFM_ACT_GELU ? reinterpret_cast<const f32x4*>(a.dacts)[((size_t)(a_tile + nt) * nbb + bb) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
   // d j2
   layer_gemm<1, MLP_WAVES_FM>(bDV, L.lddv, n.WpT + n.L[7].w_off, nullptr, n.L[7].Np / 16, n.L[7].Kp / 16, wave, lane,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
+                     const f32x4 dd = dload(a.ws.a_j2, nt);
 #pragma unroll
                      for (int i = 0; i < 4; ++i) {
                        const int row = 4 * g + i, col = nt * 16 + c;
-                       z[i] = mask_out(bJ2[row * L.ldj2 + col], acc[i], n.act);
+                       z[i] = dmask(bJ2[row * L.ldj2 + col], acc[i], dd, i);
                        bD1[row * L.ldd1 + col] = z[i];
                      }
                      store_packed(a.dzs, a.ws.z_j2 + nt, nbb, bb, lane, z);
@@ -349,10 +364,11 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   layer_gemm<1, MLP_WAVES_FM>(bD1, L.ldd1, n.WpT + n.L[6].w_off, nullptr, n.L[6].Np / 16, n.L[6].Kp / 16, wave, lane,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
+                     const f32x4 dd = dload(a.ws.a_j1, nt);
 #pragma unroll
                      for (int i = 0; i < 4; ++i) {
                        const int row = 4 * g + i, col = nt * 16 + c;
-                       z[i] = mask_out(bJ1[row * L.ldj1 + col], acc[i], n.act);
+                       z[i] = dmask(bJ1[row * L.ldj1 + col], acc[i], dd, i);
                        bD2[row * L.ldd2 + col] = z[i];
                      }
                      store_packed(a.dzs, a.ws.z_j1 + nt, nbb, bb, lane, z);
@@ -364,10 +380,11 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                      const int col = nt * 16 + c;
                      const bool is_sx = col < n.hx2;
                      f32x4 z;
+                     const f32x4 dd = is_sx ? dload(a.ws.a_sx, nt) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                      for (int i = 0; i < 4; ++i) {
                        const int row = 4 * g + i;
-                       z[i] = is_sx ? mask_out(bCat[row * L.ldcat + col], acc[i], n.act) : acc[i];
+                       z[i] = is_sx ? dmask(bCat[row * L.ldcat + col], acc[i], dd, i) : acc[i];
                        bDC[row * L.ldcat + col] = z[i];
                      }
                      if (is_sx) store_packed(a.dzs, a.ws.z_x2 + nt, nbb, bb, lane, z);
@@ -377,11 +394,12 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   layer_gemm<1, MLP_WAVES_FM>(bG, L.ldg, n.WpT + n.L[4].w_off, nullptr, n.L[4].Np / 16, n.L[4].Kp / 16, wave, lane,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
+                     const f32x4 dd = dload(a.ws.a_st, nt);
 #pragma unroll
                      for (int i = 0; i < 4; ++i) {
                        const int row = 4 * g + i, col = n.hx2 + nt * 16 + c;
                        const float ds = acc[i] + bDC[row * L.ldcat + col];
-                       z[i] = mask_out(bCat[row * L.ldcat + col], ds, n.act);
+                       z[i] = dmask(bCat[row * L.ldcat + col], ds, dd, i);
                        bDC[row * L.ldcat + col] = z[i];
                      }
                      store_packed(a.dzs, a.ws.z_t2 + nt, nbb, bb, lane, z);
@@ -391,15 +409,17 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   layer_gemm<1, MLP_WAVES_FM>(bDC, L.ldcat, n.WpT + n.L[3].w_off, nullptr, n.L[3].Np / 16, n.L[3].Kp / 16, wave, lane,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
+                     const f32x4 dd = dload(a.ws.a_x1, nt);
 #pragma unroll
-                     for (int i = 0; i < 4; ++i) z[i] = mask_out(bX1[(4 * g + i) * L.ldx1 + nt * 16 + c], acc[i], n.act);
+                     for (int i = 0; i < 4; ++i) z[i] = dmask(bX1[(4 * g + i) * L.ldx1 + nt * 16 + c], acc[i], dd, i);
                      store_packed(a.dzs, a.ws.z_x1 + nt, nbb, bb, lane, z);
                    });
   layer_gemm<1, MLP_WAVES_FM>(bDC + n.hx2, L.ldcat, n.WpT + n.L[1].w_off, nullptr, n.L[1].Np / 16, n.L[1].Kp / 16, wave, lane,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
+                     const f32x4 dd = dload(a.ws.a_t1, nt);
 #pragma unroll
-                     for (int i = 0; i < 4; ++i) z[i] = mask_out(bT1[(4 * g + i) * L.ldt1 + nt * 16 + c], acc[i], n.act);
+                     for (int i = 0; i < 4; ++i) z[i] = dmask(bT1[(4 * g + i) * L.ldt1 + nt * 16 + c], acc[i], dd, i);
                      store_packed(a.dzs, a.ws.z_t1 + nt, nbb, bb, lane, z);
                    });
   FM_STAMP(5);

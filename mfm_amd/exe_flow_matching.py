@@ -372,6 +372,12 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     # ---- final flow samples + importance resampling (:453-459), over ALL N samples on every rank --------------------
     fin = final_sampling(eng, dist, args, key_gen, transform_and_logdet, state.params)
     flow_samples, exact_samples, samples_logdensity = fin["flow_samples"], fin["exact_samples"], fin["samples_logdensity"]
+    if getattr(args, "check", False) and real_samples is not None:                          # :462-467 (--check: the exact samples' own scores)
+        real_chk = allgather_cat(real_samples)
+        logger.info(f"Logpdf of real samples= {_logprob_any(eng, real_chk).mean().item()}")
+        stein_chk = stein_disc(eng, real_chk)
+        logger.info(f"Stein U, V disc of real samples= {stein_chk[0]}, {stein_chk[1]}")
+        logger.info(f"Max mean disc of NF+MCMC samples= {eng.ctx.max_mean_disc(real_chk, real_chk)}")       # (the reference's label)
     logpdf = samples_logdensity.mean().item()                                               # :469
     logger.info(f"Logpdf of flow samples= {logpdf}")
     stein = stein_disc(eng, flow_samples)                                                   # :471 (mcmc_utils.py:28-85)

@@ -25,8 +25,7 @@ def test_create_rejects_bad_configurations():
         _ctx(dim=1024, hidden_x=(1024, 1024), hidden_t=(1024, 1024), hidden_xt=(1024, 1024), kernel_family=_lib.FAMILY_TILE)
     with pytest.raises(_lib.MfmError, match="Hutchinson"):          # wide family + exact trace
         _ctx(dim=1024, hidden_x=(1024, 1024), hidden_t=(1024, 1024), hidden_xt=(1024, 1024), hutch=0)
-    with pytest.raises(_lib.MfmError, match="gelu / swish"):
-        _ctx(activation=_lib.ACTIVATIONS["gelu"], kernel_family=_lib.FAMILY_TILE)
+    _ctx(activation=_lib.ACTIVATIONS["gelu"], kernel_family=_lib.FAMILY_TILE).close()      # served since round 3 (stored f'(pre-activation))
     with pytest.raises(_lib.MfmError, match="unknown activation"):
         _ctx(activation=9)
     with pytest.raises(_lib.MfmError, match="kernel_family"):

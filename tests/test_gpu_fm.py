@@ -167,3 +167,38 @@ def test_finite_check_in_the_reduction_matches_separate_check(family):
     assert ctxs[0].opt_state()["count"] == 5 and ctxs[0].opt_state()["notfinite_count"] == 0
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("kind", ["phi4-256", "gmm", "pines-wide"])
+def test_unconditional_flow_matching_batch_matches_oracle(kind):
+    """cond_flow = False (exe_flow_matching.py:139-147: x_t = t x1 + (1 - (1 - sigma) t) x0, target x1 - (1 - sigma) x0, two-way key
+    split): not reachable from the reference's CLI (multi_modal.py:162-163 fix cond_flow = True) but selectable through
+    `create_train_state`'s args; loss and gradient of every kernel family against the oracle's `flow_batch`."""
+    import torch
+    from tests import gpu_util as gu
+    B = 32
+    if kind == "phi4-256":
+        args, dist, k, model, state = gu.phi4_setup(d=256, B=B, cond_flow=False)
+    elif kind == "gmm":
+        args, dist, k, model, state = gu.gmm4_setup(B=B, hidden=32, F=16, cond_flow=False)
+    else:
+        from mfm_amd import _lib
+        args, dist, k, model, state = gu.lgcp_setup(n=8, B=B, hidden=48, F=16, cond_flow=False)
+    params = gu.rand_params(model, seed=7)
+    fam = {}
+    if kind == "pines-wide":
+        fam = dict(family=_lib.FAMILY_WIDE)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, **fam)
+    x32 = dist.init_params.astype(np.float32)
+    key = prng.PRNGKey(12)
+    lo, go = fm.loss_and_grad(model, params, key, x32.astype(np.float64), args.sigma, cond_flow=False)
+    lc, _ = fm.loss_and_grad(model, params, key, x32.astype(np.float64), args.sigma, cond_flow=True, need_grad=False)
+    assert abs(lo - lc) > 1e-3 * abs(lo)                                  # the two batches differ: the flag is not ignored
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctx.n_params, device="cuda")
+    ctx.fm_loss_grad(key, _dev(x32), loss, grads)
+    assert abs(loss.item() - lo) < 2e-5 * abs(lo), (loss.item(), lo)
+    assert _relerr(grads.cpu().numpy(), gu.flat_params(go)) < 3e-4
+    ev = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ctx.fm_loss(key, _dev(x32), ev)
+    assert abs(ev.item() - lo) < 2e-5 * abs(lo)
+    ctx.close()
