@@ -396,11 +396,19 @@ static void launch_gemm(const Gemm& a, hipStream_t s) {
 struct WgLayer { const float* A; int lda; const float* Z; int ldz; int K, N, Kp, Np, m_w, m_b; };
 struct WgJob { int layer, kt, nt; };
 struct WgArgs { WgLayer L[MLP_NLAYER]; const WgJob* jobs; int n_jobs; int rows; float* grads;
-                int* bad; };   // non-null: raise *bad when a gradient element is not finite (the optimizer's apply_if_finite check)
+                int* bad;      // non-null: raise *bad when a gradient element is not finite (the optimizer's apply_if_finite check)
+                int n_full; }; // jobs [0, n_full) run one per wave (4 per workgroup); jobs [n_full, n_jobs) one per WORKGROUP, rows split over its waves
 
 __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
+  // The jobs are equal (one 64 x 64 block over all rows) and two waves share a SIMD, so 2048 of them fill the chip exactly; the
+  // pines widths have 2112.  Run one per wave, the 64 left over started when the first 2048 ended and ran ALONE on 16 CUs for a
+  // whole job's time (3 job times where 2.06 are needed).  They are therefore given a workgroup each, their rows split over the
+  // four waves and the partial blocks summed through LDS in a fixed order (deterministic): 2 + 1/4 job times.
+  __shared__ f32x4 red[3][17][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
-  const int job = blockIdx.x * 4 + wave;
+  const int n_full_wg = a.n_full >> 2;
+  const bool split = (int)blockIdx.x >= n_full_wg;
+  const int job = split ? a.n_full + ((int)blockIdx.x - n_full_wg) : (int)blockIdx.x * 4 + wave;
   if (job >= a.n_jobs) return;
   // The job and its layer descriptor are wave-uniform: read them as scalars ONCE.  Indexing the kernel-argument array with a
   // per-lane value made the compiler re-read `lda` / `ldz` from memory -- and wait with vmcnt(0) -- in front of every operand
@@ -409,13 +417,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
             jnt = __builtin_amdgcn_readfirstlane(a.jobs[job].nt);
   struct { int layer, kt, nt; } J = {jl, jkt, jnt};
   const WgLayer L = a.L[jl];
-  const int lda = L.lda, ldz = L.ldz, rows = a.rows;
+  const int lda = L.lda, ldz = L.ldz, rows = split ? a.rows >> 2 : a.rows, row0 = split ? wave * (a.rows >> 2) : 0;
   const int ac = 64 * J.kt + 4 * c, zc = 64 * J.nt + 4 * c;
   const bool av = ac < L.Kp, zv = zc < L.Np;
   // lanes beyond the padded widths read column 0 (valid memory): what they accumulate lands in rows / columns of the 64 x 64
   // block that are never stored (an MFMA keeps the M rows and the N columns of its operands apart)
-  const float* ap = L.A + (size_t)g * lda + (av ? ac : 0);
-  const float* zp = L.Z + (size_t)g * ldz + (zv ? zc : 0);
+  const float* ap = L.A + (size_t)(row0 + g) * lda + (av ? ac : 0);
+  const float* zp = L.Z + (size_t)(row0 + g) * ldz + (zv ? zc : 0);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[4][4], bs = zero;
 #pragma unroll
@@ -456,6 +464,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
     macs(q1);
   }
   if (r < rows) macs(q0);              // odd number of 16-row blocks
+  if (split) {                         // (uniform over the workgroup)
+    if (wave > 0) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) red[wave - 1][4 * s + u][lane] = acc[s][u];
+      red[wave - 1][16][lane] = bs;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[s][u] += red[w][4 * s + u][lane];
+      bs += red[w][16][lane];
+    }
+  }
   // acc[s][u][i] = dW[64 kt + 4 (4 g + i) + s][64 nt + 4 c + u]
   float* gw = a.grads + L.m_w;
   const bool vec = (L.N & 3) == 0;
@@ -664,26 +691,54 @@ struct OdeBuf {
   WReplay rp;
 };
 
+// The row kernels walk a chain's d columns with one wavefront.  With d a multiple of 4 (every example of the reference) a lane takes
+// FOUR consecutive columns per step -- 128-bit loads and stores of the seven stage derivatives, the state and the stage input --
+// where the one-column walk of round 2 issued sixteen dependent 4-byte accesses per array and lane (stage_prep 23.5 us,
+// stage_finish 16.7 us per call at 1024 x 1024: 14 % of a field evaluation's time).  Rows that have reached t = 1 are skipped:
+// their state no longer changes and nothing reads what an evaluation leaves for them.
+template <typename T> struct RowV;
+template <> struct RowV<float> {
+  static constexpr int W = 1;
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float sum(float v) { return v; }
+  static __device__ __forceinline__ float absv(float v) { return fabsf(v); }
+  static __device__ __forceinline__ float maxv(float x, float y) { return fmaxf(x, y); }
+  static __device__ __forceinline__ float zero() { return 0.f; }
+};
+template <> struct RowV<f32x4> {
+  static constexpr int W = 4;
+  static __device__ __forceinline__ f32x4 ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void st(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+  static __device__ __forceinline__ float sum(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+  static __device__ __forceinline__ f32x4 absv(f32x4 v) { return f32x4{fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3])}; }
+  static __device__ __forceinline__ f32x4 maxv(f32x4 x, f32x4 y) { return f32x4{fmaxf(x[0], y[0]), fmaxf(x[1], y[1]), fmaxf(x[2], y[2]), fmaxf(x[3], y[3])}; }
+  static __device__ __forceinline__ f32x4 zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+};
+
 // stage input of phase p: X = y + h sum_j TAB[p][j] k_j, Fourier features of the stage time (:70-71, :229)
+template <typename T>
 __global__ __launch_bounds__(256) void stage_prep_kernel(OdeBuf a, int phase) {
+  using V = RowV<T>;
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.rows) return;
+  if (phase >= 2 && a.rs.done[b]) return;
   float cf[7];
 #pragma unroll
   for (int j = 0; j < 7; ++j) cf[j] = W_TAB[phase][j];
   const float h = phase == 1 ? a.rs.h0[b] : a.rs.dt[b];
   const float ts = a.rs.t[b] + h * cf[6];
   const size_t o0 = (size_t)b * a.dp, ks = (size_t)a.rows * a.dp;
-  for (int col = lane; col < a.dp; col += 64) {
-    float v = 0.f;
+  for (int col = lane * V::W; col < a.dp; col += 64 * V::W) {
+    T v = V::zero();
     if (col < a.d) {
-      float acc = 0.f;
+      T acc = V::zero();
 #pragma unroll
       for (int j = 0; j < 6; ++j)
-        if (cf[j] != 0.f) acc += cf[j] * a.K[j * ks + o0 + col];
-      v = a.Y[o0 + col] + h * acc;
+        if (cf[j] != 0.f) acc += cf[j] * V::ld(a.K + j * ks + o0 + col);
+      v = V::ld(a.Y + o0 + col) + h * acc;
     }
-    a.X[o0 + col] = v;
+    V::st(a.X + o0 + col, v);
   }
   if (phase != 7) {        // stages 6 and 7 share t + dt: the time branch of stage 6 is still valid
     const double te = a.sign > 0 ? (double)ts : 1.0 - (double)ts;
@@ -694,19 +749,22 @@ __global__ __launch_bounds__(256) void stage_prep_kernel(OdeBuf a, int phase) {
 // end of a field evaluation: k_dst = +-v, kl_dst = -+ z . J z, then the phase-specific part of the state machine
 // (phase 0 / 1: initial step size, Hairer II.4 order 4; phase 7: error norm, accept / reject, step-size controller,
 // 4th-order interpolation at t = 1, FSAL) -- the same float32 arithmetic as ode_solve() in ode.hip.
+template <typename T>
 __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) {
+  using V = RowV<T>;
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.rows) return;
+  if (phase >= 2 && a.rs.done[b]) return;
   const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
   const size_t o0 = (size_t)b * a.dp, ks = (size_t)a.rows * a.dp;
   const int R = a.rows;
   float dpart = 0.f;
-  for (int col = lane; col < a.d; col += 64) {
+  for (int col = lane * V::W; col < a.d; col += 64 * V::W) {
     const size_t o = o0 + col;
-    const float gt = a.gate[o];
-    const float v = a.out[o] + gt * a.gc[o];
-    a.K[dst * ks + o] = a.sign > 0 ? v : -v;
-    if (a.Z) dpart += a.Z[o] * (a.outT[o] + gt * a.hz[o]);
+    const T gt = V::ld(a.gate + o);
+    const T v = V::ld(a.out + o) + gt * V::ld(a.gc + o);
+    V::st(a.K + dst * ks + o, a.sign > 0 ? v : -v);
+    if (a.Z) dpart += V::sum(V::ld(a.Z + o) * (V::ld(a.outT + o) + gt * V::ld(a.hz + o)));
   }
   dpart = wave_sum(dpart);
   const float dl = a.sign > 0 ? -dpart : dpart;                 // :218 / :239
@@ -714,11 +772,11 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
   const float atol = a.atol, rtol = a.rtol;
   if (phase == 0) {
     float p0 = 0.f, p1 = 0.f;
-    for (int col = lane; col < a.d; col += 64) {
-      const float y = a.Y[o0 + col], k0 = a.K[o0 + col];      // same lane wrote K[0] above
-      const float sc = atol + fabsf(y) * rtol;
-      const float a0 = y / sc, a1 = k0 / sc;
-      p0 += a0 * a0; p1 += a1 * a1;
+    for (int col = lane * V::W; col < a.d; col += 64 * V::W) {
+      const T y = V::ld(a.Y + o0 + col), k0 = V::ld(a.K + o0 + col);      // same lane wrote K[0] above
+      const T sc = atol + V::absv(y) * rtol;
+      const T a0 = y / sc, a1 = k0 / sc;
+      p0 += V::sum(a0 * a0); p1 += V::sum(a1 * a1);
     }
     p0 = wave_sum(p0); p1 = wave_sum(p1);
     if (lane == 0) {
@@ -729,11 +787,11 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
     }
   } else if (phase == 1) {
     float p2 = 0.f;
-    for (int col = lane; col < a.d; col += 64) {
-      const float y = a.Y[o0 + col];
-      const float sc = atol + fabsf(y) * rtol;
-      const float a2 = (a.K[ks + o0 + col] - a.K[o0 + col]) / sc;
-      p2 += a2 * a2;
+    for (int col = lane * V::W; col < a.d; col += 64 * V::W) {
+      const T y = V::ld(a.Y + o0 + col);
+      const T sc = atol + V::absv(y) * rtol;
+      const T a2 = (V::ld(a.K + ks + o0 + col) - V::ld(a.K + o0 + col)) / sc;
+      p2 += V::sum(a2 * a2);
     }
     p2 = wave_sum(p2);
     if (lane == 0) {
@@ -754,15 +812,15 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
     for (int j = 0; j < 6; ++j) kl[j] = a.rs.kl[j * R + b];
     kl[6] = dl;
     float e2 = 0.f;
-    for (int col = lane; col < a.d; col += 64) {
+    for (int col = lane * V::W; col < a.d; col += 64 * V::W) {
       const size_t o = o0 + col;
-      float er = 0.f;
+      T er = V::zero();
 #pragma unroll
-      for (int j = 0; j < 7; ++j) er += W_E[j] * a.K[j * ks + o];
+      for (int j = 0; j < 7; ++j) er += W_E[j] * V::ld(a.K + j * ks + o);
       er *= dti;
-      const float tol = atol + rtol * fmaxf(fabsf(a.Y[o]), fabsf(a.X[o]));
-      const float rr = er / tol;
-      e2 += rr * rr;
+      const T tol = atol + rtol * V::maxv(V::absv(V::ld(a.Y + o)), V::absv(V::ld(a.X + o)));
+      const T rr = er / tol;
+      e2 += V::sum(rr * rr);
     }
     e2 = wave_sum(e2);
     const bool active = !dn && na < a.max_attempts && dti > 0.f;
@@ -803,24 +861,24 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
           const float pc = -4.f * f0 + f1 - 11.f * y0 - 5.f * y1 + 16.f * ym;
           ell_n = (((pa * sfrac + pb) * sfrac + pc) * sfrac + f0) * sfrac + y0;
         }
-        for (int col = lane; col < a.d; col += 64) {
+        for (int col = lane * V::W; col < a.d; col += 64 * V::W) {
           const size_t o = o0 + col;
-          float km = 0.f;
+          T km = V::zero();
 #pragma unroll
-          for (int j = 0; j < 7; ++j) km += W_M[j] * a.K[j * ks + o];
-          const float x0 = a.Y[o], x1 = a.X[o], xm = x0 + dti * km, g0 = dti * a.K[o], g1 = dti * a.K[6 * ks + o];
-          const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
-          const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
-          const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
-          a.Y[o] = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
+          for (int j = 0; j < 7; ++j) km += W_M[j] * V::ld(a.K + j * ks + o);
+          const T x0 = V::ld(a.Y + o), x1 = V::ld(a.X + o), xm = x0 + dti * km, g0 = dti * V::ld(a.K + o), g1 = dti * V::ld(a.K + 6 * ks + o);
+          const T qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
+          const T qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
+          const T qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
+          V::st(a.Y + o, (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0);
         }
         dn_n = 1;
       } else {
         ell_n = l1;
-        for (int col = lane; col < a.d; col += 64) {
+        for (int col = lane * V::W; col < a.d; col += 64 * V::W) {
           const size_t o = o0 + col;
-          a.Y[o] = a.X[o];
-          a.K[o] = a.K[6 * ks + o];               // FSAL
+          V::st(a.Y + o, V::ld(a.X + o));
+          V::st(a.K + o, V::ld(a.K + 6 * ks + o));               // FSAL
         }
         kl0_n = kl[6];
       }
@@ -1232,7 +1290,11 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
     a.L[l] = WgLayer{A[l], lda[l], Z[l], ldz[l], L.K, L.N, L.Kp, L.Np, L.m_w, L.m_b};
   }
   a.jobs = w->jobs; a.n_jobs = w->n_jobs; a.rows = rows; a.grads = d_grads; a.bad = c.bad;
-  hipLaunchKernelGGL(wgrad_kernel, dim3((w->n_jobs + 3) / 4), dim3(256), 0, s, a);
+  // what does not fill the chip's 2048 wave slots a whole number of times, if it is a tail of at most one workgroup per CU
+  const int rem = w->n_jobs % 2048;
+  const bool tail = w->n_jobs > 2048 && rem > 0 && rem <= 256 && rows % 64 == 0 && !getenv("MFM_WIDE_WGRAD_NOSPLIT");
+  a.n_full = tail ? w->n_jobs - rem : (w->n_jobs + 3) / 4 * 4;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_full / 4 + (tail ? rem : 0)), dim3(256), 0, s, a);
   return 0;
 }
 
@@ -1257,6 +1319,15 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
   hipLaunchKernelGGL(ode_init_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, w->rs, rows);
   if (hipMemsetAsync(w->K, 0, (size_t)7 * rows * n.dp * sizeof(float), s) != hipSuccess) return -4;
   probe_setup(w, n, rows, s);
+  const bool vec4 = (n.d & 3) == 0 && (n.dp & 3) == 0;
+  auto stage_prep = [&](const OdeBuf& ob, int phase) {
+    if (vec4) hipLaunchKernelGGL(stage_prep_kernel<f32x4>, dim3(grid4(rows)), dim3(256), 0, s, ob, phase);
+    else hipLaunchKernelGGL(stage_prep_kernel<float>, dim3(grid4(rows)), dim3(256), 0, s, ob, phase);
+  };
+  auto stage_finish = [&](const OdeBuf& ob, int phase) {
+    if (vec4) hipLaunchKernelGGL(stage_finish_kernel<f32x4>, dim3(grid4(rows)), dim3(256), 0, s, ob, phase);
+    else hipLaunchKernelGGL(stage_finish_kernel<float>, dim3(grid4(rows)), dim3(256), 0, s, ob, phase);
+  };
   auto read_active = [&](int& v) -> int {
     if (hipMemcpyAsync(w->h_active, w->n_active, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return -4;
     if (hipStreamSynchronize(s) != hipSuccess) return -4;
@@ -1265,9 +1336,9 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
   };
   for (int phase = 0; phase < 2; ++phase) {                   // f0 and the extra evaluation of the initial-step heuristic
     if (phase == 1 && hipMemsetAsync(w->n_active, 0, sizeof(int), s) != hipSuccess) return -4;
-    hipLaunchKernelGGL(stage_prep_kernel, dim3(grid4(rows)), dim3(256), 0, s, o, phase);
+    stage_prep(o, phase); 
     field_eval(w, n, xstage, true, true, rows, s);
-    hipLaunchKernelGGL(stage_finish_kernel, dim3(grid4(rows)), dim3(256), 0, s, o, phase);
+    stage_finish(o, phase);
   }
   int active = 0;
   if (read_active(active)) return -4;
@@ -1275,9 +1346,9 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
   for (int it = 0; active > 0 && it < c.max_attempts; ++it) {
     if (hipMemsetAsync(w->n_active, 0, sizeof(int), s) != hipSuccess) return -4;
     for (int phase = 2; phase < 8; ++phase) {
-      hipLaunchKernelGGL(stage_prep_kernel, dim3(grid4(rows)), dim3(256), 0, s, o, phase);
+      stage_prep(o, phase);
       field_eval(w, n, xstage, true, phase != 7, rows, s);
-      hipLaunchKernelGGL(stage_finish_kernel, dim3(grid4(rows)), dim3(256), 0, s, o, phase);
+      stage_finish(o, phase);
     }
     if (read_active(active)) return -4;
   }
