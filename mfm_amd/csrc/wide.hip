@@ -575,12 +575,14 @@ struct TgtArgs {
   TargetDev T; float clip; int rows, d, dp;
   const float* X; const float* Z; const float* KV; const float* KZ;
   float* GC; float* HZ;
+  const int* cmap;          // non-null: X / KV / GC / HZ rows are COMPACT (row j = chain cmap[j]); Z / KZ stay indexed by chain
 };
 __global__ __launch_bounds__(256) void target_kernel(TgtArgs a) {
   const size_t n = (size_t)a.rows * a.dp;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
     const int col = (int)(idx % a.dp);
     const size_t r0 = idx - col;
+    const size_t zi = a.cmap ? (size_t)a.cmap[idx / a.dp] * a.dp + col : idx;       // the chain's row of the per-solve constants
     float gc = 0.f, hz = 0.f;
     if (col < a.d) {
       const float x = a.X[idx];
@@ -589,13 +591,13 @@ __global__ __launch_bounds__(256) void target_kernel(TgtArgs a) {
         const float xl = col > 0 ? a.X[idx - 1] : 0.f, xr = col + 1 < a.d ? a.X[idx + 1] : 0.f;
         graw = -a.T.tbeta * (a.T.coef * (2.f * x - xl - xr) - x * (1.f - x * x) / a.T.coef);
         if (a.Z) {
-          const float v = a.Z[idx], vl = col > 0 ? a.Z[idx - 1] : 0.f, vr = col + 1 < a.d ? a.Z[idx + 1] : 0.f;
+          const float v = a.Z[zi], vl = col > 0 ? a.Z[zi - 1] : 0.f, vr = col + 1 < a.d ? a.Z[zi + 1] : 0.f;
           hraw = -a.T.tbeta * (a.T.coef * (2.f * v - vl - vr) - (1.f - 3.f * x * x) * v / a.T.coef);
         }
       } else {
         const float ex = a.T.poisson_a * expf(x);
         graw = a.T.counts[col] - ex - a.KV[idx];
-        if (a.Z) hraw = -ex * a.Z[idx] - a.KZ[idx];
+        if (a.Z) hraw = -ex * a.Z[zi] - a.KZ[zi];
       }
       gc = clipf(graw, a.clip);
       const bool inside = !(a.clip > 0.f) || fabsf(graw) <= a.clip;
@@ -688,6 +690,7 @@ struct OdeBuf {
   const float* fourier;
   const float* out; const float* outT; const float* gate; const float* gc; const float* hz;   // results of the evaluation
   int* n_active;
+  const int* cpos;     // non-null: chain b's row in the COMPACT evaluation buffers (X, ffat, out, outT, gate, gc, hz), -1: not integrating
   WReplay rp;
 };
 
@@ -723,12 +726,14 @@ __global__ __launch_bounds__(256) void stage_prep_kernel(OdeBuf a, int phase) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.rows) return;
   if (phase >= 2 && a.rs.done[b]) return;
+  const int cp = a.cpos ? a.cpos[b] : b;
+  if (cp < 0) return;
   float cf[7];
 #pragma unroll
   for (int j = 0; j < 7; ++j) cf[j] = W_TAB[phase][j];
   const float h = phase == 1 ? a.rs.h0[b] : a.rs.dt[b];
   const float ts = a.rs.t[b] + h * cf[6];
-  const size_t o0 = (size_t)b * a.dp, ks = (size_t)a.rows * a.dp;
+  const size_t o0 = (size_t)b * a.dp, ks = (size_t)a.rows * a.dp, oc = (size_t)cp * a.dp;
   for (int col = lane * V::W; col < a.dp; col += 64 * V::W) {
     T v = V::zero();
     if (col < a.d) {
@@ -738,11 +743,11 @@ __global__ __launch_bounds__(256) void stage_prep_kernel(OdeBuf a, int phase) {
         if (cf[j] != 0.f) acc += cf[j] * V::ld(a.K + j * ks + o0 + col);
       v = V::ld(a.Y + o0 + col) + h * acc;
     }
-    V::st(a.X + o0 + col, v);
+    V::st(a.X + oc + col, v);
   }
   if (phase != 7) {        // stages 6 and 7 share t + dt: the time branch of stage 6 is still valid
     const double te = a.sign > 0 ? (double)ts : 1.0 - (double)ts;
-    fourier_row(a.fourier, a.F, a.F2p, te, a.ffat + (size_t)b * a.F2p, lane);
+    fourier_row(a.fourier, a.F, a.F2p, te, a.ffat + (size_t)cp * a.F2p, lane);
   }
 }
 
@@ -755,16 +760,18 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.rows) return;
   if (phase >= 2 && a.rs.done[b]) return;
+  const int cp = a.cpos ? a.cpos[b] : b;
+  if (cp < 0) return;
   const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
-  const size_t o0 = (size_t)b * a.dp, ks = (size_t)a.rows * a.dp;
+  const size_t o0 = (size_t)b * a.dp, ks = (size_t)a.rows * a.dp, oc = (size_t)cp * a.dp;      // state row / compact evaluation row
   const int R = a.rows;
   float dpart = 0.f;
   for (int col = lane * V::W; col < a.d; col += 64 * V::W) {
-    const size_t o = o0 + col;
-    const T gt = V::ld(a.gate + o);
-    const T v = V::ld(a.out + o) + gt * V::ld(a.gc + o);
+    const size_t o = o0 + col, e = oc + col;
+    const T gt = V::ld(a.gate + e);
+    const T v = V::ld(a.out + e) + gt * V::ld(a.gc + e);
     V::st(a.K + dst * ks + o, a.sign > 0 ? v : -v);
-    if (a.Z) dpart += V::sum(V::ld(a.Z + o) * (V::ld(a.outT + o) + gt * V::ld(a.hz + o)));
+    if (a.Z) dpart += V::sum(V::ld(a.Z + o) * (V::ld(a.outT + e) + gt * V::ld(a.hz + e)));
   }
   dpart = wave_sum(dpart);
   const float dl = a.sign > 0 ? -dpart : dpart;                 // :218 / :239
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
 #pragma unroll
       for (int j = 0; j < 7; ++j) er += W_E[j] * V::ld(a.K + j * ks + o);
       er *= dti;
-      const T tol = atol + rtol * V::maxv(V::absv(V::ld(a.Y + o)), V::absv(V::ld(a.X + o)));
+      const T tol = atol + rtol * V::maxv(V::absv(V::ld(a.Y + o)), V::absv(V::ld(a.X + oc + col)));
       const T rr = er / tol;
       e2 += V::sum(rr * rr);
     }
@@ -866,7 +873,7 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
           T km = V::zero();
 #pragma unroll
           for (int j = 0; j < 7; ++j) km += W_M[j] * V::ld(a.K + j * ks + o);
-          const T x0 = V::ld(a.Y + o), x1 = V::ld(a.X + o), xm = x0 + dti * km, g0 = dti * V::ld(a.K + o), g1 = dti * V::ld(a.K + 6 * ks + o);
+          const T x0 = V::ld(a.Y + o), x1 = V::ld(a.X + oc + col), xm = x0 + dti * km, g0 = dti * V::ld(a.K + o), g1 = dti * V::ld(a.K + 6 * ks + o);
           const T qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
           const T qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
           const T qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
@@ -877,7 +884,7 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
         ell_n = l1;
         for (int col = lane * V::W; col < a.d; col += 64 * V::W) {
           const size_t o = o0 + col;
-          V::st(a.Y + o, V::ld(a.X + o));
+          V::st(a.Y + o, V::ld(a.X + oc + col));
           V::st(a.K + o, V::ld(a.K + 6 * ks + o));               // FSAL
         }
         kl0_n = kl[6];
@@ -890,6 +897,40 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
       a.rs.t[b] = t_n; a.rs.dt[b] = dt_n; a.rs.ell[b] = ell_n; a.rs.kl[b] = kl0_n; a.rs.natt[b] = na_n; a.rs.done[b] = dn_n;
       if (!dn_n && na_n < a.max_attempts && dt_n > 0.f) atomicAdd(a.n_active, 1);
     }
+  }
+}
+
+// Compaction map of an attempt: the chains still integrating (the predicate stage_finish counts n_active with), in chain order.
+// One workgroup; cmap[j] = chain of compact row j, cpos[chain] = its compact row or -1.
+__global__ __launch_bounds__(1024) void compact_map_kernel(RowState rs, int rows, int max_attempts, int* cmap, int* cpos) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < rows; r0 += 1024) {
+    const int b = r0 + (int)threadIdx.x;
+    const bool act = b < rows && !rs.done[b] && rs.natt[b] < max_attempts && rs.dt[b] > 0.f;
+    const unsigned long long m = __ballot(act);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    const int j = off + __popcll(m & ((1ull << lane) - 1ull));
+    if (b < rows) cpos[b] = act ? j : -1;
+    if (act) cmap[j] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base += t; }
+    __syncthreads();
+  }
+}
+// dst[j][:] = src[cmap[j]][:] for j < n (128-bit copies; ld multiple of 4)
+__global__ void gather_rows_c_kernel(const float* src, const int* cmap, int n, int ld, float* dst) {
+  const int l4 = ld >> 2;
+  const size_t tot = (size_t)n * l4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+    const size_t j = i / l4, c = i - j * l4;
+    reinterpret_cast<f32x4*>(dst + j * ld)[c] = reinterpret_cast<const f32x4*>(src + (size_t)cmap[j] * ld)[c];
   }
 }
 
@@ -1111,6 +1152,8 @@ struct Ctx {
   double* loss_part; int n_loss_part;
   WgJob* jobs = nullptr; int n_jobs = 0;
   int* n_active = nullptr; int* h_active = nullptr;
+  // row compaction of the host-driven solver (solve): map, inverse map, the compact copy of z W_x1, the probe constants in use
+  int *cmap = nullptr, *cpos = nullptr; float* tz1c = nullptr; const float* tz1_use = nullptr; const int* cmap_use = nullptr;
 };
 
 static int create(const NetDev& n, int rows_cap, Ctx** out) {
@@ -1148,6 +1191,11 @@ static int create(const NetDev& n, int rows_cap, Ctx** out) {
   if (hipMalloc((void**)&w->loss_part, w->n_loss_part * sizeof(double)) != hipSuccess) return -4;
   if (hipMalloc((void**)&w->n_active, 16) != hipSuccess) return -4;
   if (hipHostMalloc((void**)&w->h_active, 16, hipHostMallocDefault) != hipSuccess) return -4;
+  if (hipMalloc((void**)&w->cmap, 2 * R * sizeof(int)) != hipSuccess) return -4;
+  w->cpos = w->cmap + R;
+  (void)hipMemset(w->cmap, 0, 2 * R * sizeof(int));
+  if (hipMalloc((void**)&w->tz1c, R * n.hx1 * sizeof(float)) != hipSuccess) return -4;
+  w->tz1_use = nullptr;
   std::vector<WgJob> jobs;
   for (int l = 0; l < MLP_NLAYER; ++l)
     for (int nt = 0; nt * 64 < n.L[l].Np; ++nt)
@@ -1167,6 +1215,8 @@ static void destroy(Ctx* w) {
   if (w->n_active) (void)hipFree(w->n_active);
   if (w->h_active) (void)hipHostFree(w->h_active);
   if (w->jobs) (void)hipFree(w->jobs);
+  if (w->cmap) (void)hipFree(w->cmap);
+  if (w->tz1c) (void)hipFree(w->tz1c);
   delete w;
 }
 
@@ -1197,6 +1247,7 @@ static void target_eval(Ctx* w, const NetDev& n, const float* X, const float* Z,
   if (n.T.kind == MFM_TARGET_LGCP) launch_gemm(kinv(n, X, w->kv, rows, true), s);
   TgtArgs t; memset(&t, 0, sizeof t);
   t.T = n.T; t.clip = n.grad_clip; t.rows = rows; t.d = n.d; t.dp = n.dp; t.X = X; t.Z = Z; t.KV = w->kv; t.KZ = w->kz; t.GC = w->gc; t.HZ = Z ? w->hz : nullptr;
+  t.cmap = w->cmap_use;
   hipLaunchKernelGGL(target_kernel, dim3(grid_el((size_t)rows * n.dp)), dim3(256), 0, s, t);
 }
 
@@ -1209,7 +1260,7 @@ static void time_branch(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
 // x branch + joint layers on value rows X (and tangent rows: z in w->zp, z W_x1 in w->tz1)
 static void x_branch(Ctx* w, const NetDev& n, const float* X, bool tangent, int rows, hipStream_t s) {
   Gemm g = fwd(n, 2, X, n.dp, w->x1, n.hx1, 0, rows, 1); g.P = w->px1;
-  if (tangent) { g.YT = w->x1T; g.TS = w->tz1; g.ldts = n.hx1; }
+  if (tangent) { g.YT = w->x1T; g.TS = w->tz1_use ? w->tz1_use : w->tz1; g.ldts = n.hx1; }
   launch_gemm(g, s);
   g = fwd(n, 3, w->x1, n.hx1, w->catv, w->cat, 0, rows, 1); g.P = w->pcat;
   if (tangent) { g.XT = w->x1T; g.KBT = g.KB; g.YT = w->catT; }
@@ -1343,15 +1394,30 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
   int active = 0;
   if (read_active(active)) return -4;
   // every row stops after max_attempts attempted steps, so the loop is bounded even if the read-back misbehaves
+  // Row compaction: the chains of a solve end after different numbers of attempts (13.2 on average, 15.8 for the slowest, at the
+  // pines shape), and the layer GEMMs are the cost.  From the attempt on in which fewer chains than rows are integrating, the
+  // evaluation buffers are COMPACT: stage_prep writes chain b's stage input and Fourier row to row cpos[b], the GEMMs run on
+  // ceil16(active) rows, stage_finish reads chain b's results from row cpos[b]; per-solve constants the GEMMs take per row
+  // (z W_x1) are gathered once per attempt, the element-wise target kernel follows the map.  The number of rows is the
+  // read-back the loop already makes.
+  static const bool no_compact = getenv("MFM_WIDE_NOCOMPACT") != nullptr;
   for (int it = 0; active > 0 && it < c.max_attempts; ++it) {
     if (hipMemsetAsync(w->n_active, 0, sizeof(int), s) != hipSuccess) return -4;
+    int rc = rows;
+    if (!no_compact && active < rows) {
+      hipLaunchKernelGGL(compact_map_kernel, dim3(1), dim3(1024), 0, s, w->rs, rows, c.max_attempts, w->cmap, w->cpos);
+      hipLaunchKernelGGL(gather_rows_c_kernel, dim3(grid_el((size_t)active * n.hx1 / 4)), dim3(256), 0, s, w->tz1, w->cmap, active, n.hx1, w->tz1c);
+      rc = (active + 15) & ~15;
+      o.cpos = w->cpos; w->tz1_use = w->tz1c; w->cmap_use = w->cmap;
+    }
     for (int phase = 2; phase < 8; ++phase) {
       stage_prep(o, phase);
-      field_eval(w, n, xstage, true, phase != 7, rows, s);
+      field_eval(w, n, xstage, true, phase != 7, rc, s);
       stage_finish(o, phase);
     }
-    if (read_active(active)) return -4;
+    if (read_active(active)) { w->tz1_use = nullptr; w->cmap_use = nullptr; return -4; }
   }
+  w->tz1_use = nullptr; w->cmap_use = nullptr;
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
