@@ -367,6 +367,19 @@ static void launch_gemm(const Gemm& a, hipStream_t s) {
   if (big) {
     dim3 grid((a.NT + 3) / 4, (MT + 7) / 8);
     hipLaunchKernelGGL((gemm_kernel<4, 2, false>), grid, dim3(256), 0, s, a);
+  } else if (a.rows <= 512 && !getenv("MFM_WIDE_NO_SMALL_TILES")) {
+    // few rows (the compacted attempts of a solve's tail, small batches): with 64 x 64 workgroup tiles a 256-row layer is 64
+    // workgroups on 256 CUs and lasts as long as the 1024-row one.  Smaller tiles of the register-only kernel keep the chip
+    // covered: 32 rows x 64 features up to 512 rows, 32 x 32 up to 256.
+    if (a.rows <= 256) {
+      dim3 grid((a.NT + 1) / 2, (MT + 1) / 2);
+      if (dual) hipLaunchKernelGGL((gemm_kernel<1, 1, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_kernel<1, 1, false>), grid, dim3(256), 0, s, a);
+    } else {
+      dim3 grid((a.NT + 3) / 4, (MT + 1) / 2);
+      if (dual) hipLaunchKernelGGL((gemm_kernel<1, 2, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_kernel<1, 2, false>), grid, dim3(256), 0, s, a);
+    }
   } else {
     dim3 grid((a.NT + 3) / 4, (MT + 3) / 4);
     // the LDS-staged kernel needs an even number of whole 64-wide K steps (every width of the reference's pines networks); MFM_WIDE_NOLDS=1
