@@ -180,10 +180,12 @@ def pmc_traffic(kernel_class, workload="phi-four"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc passes of this
     same command, tools/prof_round.sh): 2 * FETCH_SIZE + WRITE_SIZE, both reported in KB; the factor 2 is the gfx950
     correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section).  None when no summary is present."""
-    files = {"phi-four": ("profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"),       # newest committed summary first
-             "gaussian-mixture": ("profiles/r02_gmm_pmc_summary.json",), "4-mode": ("profiles/r02_4mode_pmc_summary.json",),
-             "pines": ("profiles/r02_pines_pmc_summary.json",)}.get(workload, ())
-    pattern = {"fm_eval": "fm_eval_kernel"}.get(kernel_class, kernel_class)
+    files = {"phi-four": ("profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"),    # newest committed summary first
+             "gaussian-mixture": ("profiles/r03_gmm_pmc_summary.json", "profiles/r02_gmm_pmc_summary.json"),
+             "4-mode": ("profiles/r03_4mode_pmc_summary.json", "profiles/r02_4mode_pmc_summary.json"),
+             "pines": ("profiles/r03_pines_pmc_summary.json", "profiles/r02_pines_pmc_summary.json")}.get(workload, ())
+    # kernel class -> what its kernel is called in the summaries (the d = 2 flow step runs d2::flow_kernel since round 3)
+    patterns = {"fm_eval": ("fm_eval_kernel", "fm_eval64"), "flow_step": ("flow_step", "d2::flow_kernel")}.get(kernel_class, (kernel_class,))
     if workload == "pines":
         return None, None      # its roofline entry is the whole training step (many launches): per-kernel traffic is in the summary file
     for rel in files:
@@ -192,7 +194,7 @@ def pmc_traffic(kernel_class, workload="phi-four"):
         except Exception:
             continue
         for name, c in d.items():
-            if pattern in name and isinstance(c.get("FETCH_SIZE"), dict) and isinstance(c.get("WRITE_SIZE"), dict):
+            if any(pt in name for pt in patterns) and isinstance(c.get("FETCH_SIZE"), dict) and isinstance(c.get("WRITE_SIZE"), dict):
                 return int((2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024), rel
     return None, None
 

@@ -704,6 +704,8 @@ struct OdeBuf {
   const float* out; const float* outT; const float* gate; const float* gc; const float* hz;   // results of the evaluation
   int* n_active;
   const int* cpos;     // non-null: chain b's row in the COMPACT evaluation buffers (X, ffat, out, outT, gate, gc, hz), -1: not integrating
+  int tb_rows;         // > 0: time-branch batching -- at phase 2 stage_prep writes the Fourier rows of the attempt's FIVE distinct stage
+                       // times to ffat[(s * tb_rows + row)] (slot s), and no Fourier rows in the other phases
   WReplay rp;
 };
 
@@ -758,7 +760,17 @@ __global__ __launch_bounds__(256) void stage_prep_kernel(OdeBuf a, int phase) {
     }
     V::st(a.X + oc + col, v);
   }
-  if (phase != 7) {        // stages 6 and 7 share t + dt: the time branch of stage 6 is still valid
+  if (a.tb_rows > 0) {
+    if (phase == 2) {
+      const float t0 = a.rs.t[b];
+#pragma unroll 1
+      for (int sl = 0; sl < 5; ++sl) {
+        const float tsl = t0 + h * W_TAB[2 + sl][6];
+        const double te = a.sign > 0 ? (double)tsl : 1.0 - (double)tsl;
+        fourier_row(a.fourier, a.F, a.F2p, te, a.ffat + ((size_t)sl * a.tb_rows + cp) * a.F2p, lane);
+      }
+    }
+  } else if (phase != 7) {        // stages 6 and 7 share t + dt: the time branch of stage 6 is still valid
     const double te = a.sign > 0 ? (double)ts : 1.0 - (double)ts;
     fourier_row(a.fourier, a.F, a.F2p, te, a.ffat + (size_t)cp * a.F2p, lane);
   }
@@ -1167,6 +1179,8 @@ struct Ctx {
   int* n_active = nullptr; int* h_active = nullptr;
   // row compaction of the host-driven solver (solve): map, inverse map, the compact copy of z W_x1, the probe constants in use
   int *cmap = nullptr, *cpos = nullptr; float* tz1c = nullptr; const float* tz1_use = nullptr; const int* cmap_use = nullptr;
+  // time-branch batch of an attempt (five stage times): Fourier rows, t1, [sx | st], gate, each 5 R rows
+  float *ffat5 = nullptr, *t15 = nullptr, *cat5 = nullptr, *gate5 = nullptr;
 };
 
 static int create(const NetDev& n, int rows_cap, Ctx** out) {
@@ -1209,6 +1223,12 @@ static int create(const NetDev& n, int rows_cap, Ctx** out) {
   (void)hipMemset(w->cmap, 0, 2 * R * sizeof(int));
   if (hipMalloc((void**)&w->tz1c, R * n.hx1 * sizeof(float)) != hipSuccess) return -4;
   w->tz1_use = nullptr;
+  {
+    const size_t n5 = 5 * R * ((size_t)n.F2p + n.ht1 + w->cat + n.dp);
+    if (hipMalloc((void**)&w->ffat5, n5 * sizeof(float)) != hipSuccess) return -4;
+    (void)hipMemset(w->ffat5, 0, n5 * sizeof(float));
+    w->t15 = w->ffat5 + 5 * R * n.F2p; w->cat5 = w->t15 + 5 * R * n.ht1; w->gate5 = w->cat5 + 5 * R * w->cat;
+  }
   std::vector<WgJob> jobs;
   for (int l = 0; l < MLP_NLAYER; ++l)
     for (int nt = 0; nt * 64 < n.L[l].Np; ++nt)
@@ -1230,6 +1250,7 @@ static void destroy(Ctx* w) {
   if (w->jobs) (void)hipFree(w->jobs);
   if (w->cmap) (void)hipFree(w->cmap);
   if (w->tz1c) (void)hipFree(w->tz1c);
+  if (w->ffat5) (void)hipFree(w->ffat5);
   delete w;
 }
 
@@ -1414,6 +1435,7 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
   // (z W_x1) are gathered once per attempt, the element-wise target kernel follows the map.  The number of rows is the
   // read-back the loop already makes.
   static const bool no_compact = getenv("MFM_WIDE_NOCOMPACT") != nullptr;
+  static const bool no_tbatch = getenv("MFM_WIDE_NO_TBATCH") != nullptr;
   for (int it = 0; active > 0 && it < c.max_attempts; ++it) {
     if (hipMemsetAsync(w->n_active, 0, sizeof(int), s) != hipSuccess) return -4;
     int rc = rows;
@@ -1423,6 +1445,30 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
       rc = (active + 15) & ~15;
       o.cpos = w->cpos; w->tz1_use = w->tz1c; w->cmap_use = w->cmap;
     }
+    if (!no_tbatch) {
+      // Time-branch batching: Fourier features -> t1 -> st -> gate depend on t only and the six stage times of an attempt
+      // (five distinct) are known when it starts: ONE chain of three GEMMs on 5 rc rows (slot-major) instead of five chains
+      // on rc rows -- 12 launches fewer per attempt, and GEMMs tall enough to keep every CU busy past their first tile
+      OdeBuf ob = o;
+      ob.tb_rows = rc; ob.ffat = w->ffat5;
+      stage_prep(ob, 2);
+      {
+        const int r5 = 5 * rc;
+        launch_gemm(fwd(n, 0, w->ffat5, n.F2p, w->t15, n.ht1, 0, r5, 1), s);
+        launch_gemm(fwd(n, 1, w->t15, n.ht1, w->cat5, w->cat, n.hx2, r5, 1), s);
+        launch_gemm(fwd(n, 4, w->cat5 + n.hx2, w->cat, w->gate5, n.dp, 0, r5, 0), s);
+      }
+      float* const cat_keep = w->catv;
+      for (int phase = 2; phase < 8; ++phase) {
+        const int slot = phase - 2 < 4 ? phase - 2 : 4;
+        ob.gate = w->gate5 + (size_t)slot * rc * n.dp;
+        w->catv = w->cat5 + (size_t)slot * rc * w->cat;        // x2 writes its sx half into the slot's [sx | st] rows, j1 reads them
+        if (phase > 2) stage_prep(ob, phase);
+        field_eval(w, n, xstage, true, false, rc, s);
+        stage_finish(ob, phase);
+      }
+      w->catv = cat_keep;
+    } else
     for (int phase = 2; phase < 8; ++phase) {
       stage_prep(o, phase);
       field_eval(w, n, xstage, true, phase != 7, rc, s);
