@@ -363,7 +363,11 @@ static void launch_gemm(const Gemm& a, hipStream_t s) {
   const int MT = a.rows / 16;
   // 2 x 2 waves per workgroup; wave tile (16 MTW) rows x (16 NTW) features.  Small problems (this path runs ~1024 rows)
   // take the 32 x 32 wave tile so that the launch still covers the 1024 SIMDs.
-  const bool big = (long long)MT * a.NT >= 4 * 4096 && !dual;
+  // tall launches (the batched time branch: 5 x rows) without whole 128-wide K steps keep round 1's 128 x 64 register-only tile;
+  // wherever the LDS-staged kernel applies it is the faster one at every height (pines flow step 54.4 -> 51.8 ms when the batched
+  // time-branch GEMMs moved to it)
+  static const bool no_lds_any = getenv("MFM_WIDE_NOLDS") != nullptr;
+  const bool big = (long long)MT * a.NT >= 4 * 4096 && !dual && (no_lds_any || (a.KB & 7) != 0);
   if (big) {
     dim3 grid((a.NT + 3) / 4, (MT + 7) / 8);
     hipLaunchKernelGGL((gemm_kernel<4, 2, false>), grid, dim3(256), 0, s, a);
