@@ -114,7 +114,9 @@ def test_flow_rwmh_step_matches_oracle(d, hidden, F):
         la_g, la_o = np.log(acc.cpu().numpy().astype(np.float64)), np.log(info.acceptance_rate)
     fin = np.isfinite(la_g) & np.isfinite(la_o)
     if fin.any():
-        assert np.abs(la_g[fin] - la_o[fin]).max() < 0.5
+        dla = np.abs(la_g[fin] - la_o[fin])
+        print(f"natural-controller flow step: |d log alpha| median {np.median(dla):.2e} max {dla.max():.2e} (|log alpha| up to {np.abs(la_o[fin]).max():.1f})")
+        assert dla.max() < 0.05                      # two adaptive solves with their own controllers: measured 2.5e-3 .. 3.6e-3 of |log alpha| <= 97
     np.testing.assert_array_equal(isacc.cpu().numpy().astype(bool)[~fin | (np.abs(la_o) > 1)], info.is_accepted[~fin | (np.abs(la_o) > 1)])
     tot = stats["n_att_inv"] + stats["n_att_fwd"]
     dn = np.abs(ns.cpu().numpy() - tot)
@@ -164,7 +166,9 @@ def test_flow_imh_step_matches_oracle():
         la_g, la_o = np.log(acc.cpu().numpy().astype(np.float64)), np.log(info.acceptance_rate)
     fin = np.isfinite(la_g) & np.isfinite(la_o)
     if fin.any():
-        assert np.abs(la_g[fin] - la_o[fin]).max() < 0.5
+        dla = np.abs(la_g[fin] - la_o[fin])
+        print(f"natural-controller flow step: |d log alpha| median {np.median(dla):.2e} max {dla.max():.2e} (|log alpha| up to {np.abs(la_o[fin]).max():.1f})")
+        assert dla.max() < 0.05                      # two adaptive solves with their own controllers: measured 2.5e-3 .. 3.6e-3 of |log alpha| <= 97
     sure = ~fin | (np.abs(la_o) > 1)
     np.testing.assert_array_equal(isacc.cpu().numpy().astype(bool)[sure], info.is_accepted[sure])
     ctx.close()
@@ -205,7 +209,9 @@ def test_lgcp_transform_and_flow_step_match_oracle():
     with np.errstate(divide="ignore"):
         la_g, la_o = np.log(acc.cpu().numpy().astype(np.float64)), np.log(info.acceptance_rate)
     fin = np.isfinite(la_g) & np.isfinite(la_o)
-    assert fin.any() and np.abs(la_g[fin] - la_o[fin]).max() < 0.5
+    dla = np.abs(la_g[fin] - la_o[fin])
+    print(f"natural-controller flow step (mixture): |d log alpha| median {np.median(dla):.2e} max {dla.max():.2e}")
+    assert fin.any() and dla.max() < 0.15         # measured 4.4e-2 (median 2e-4)
     sure = ~fin | (np.abs(la_o) > 1)
     np.testing.assert_array_equal(isacc.cpu().numpy().astype(bool)[sure], info.is_accepted[sure])
     same = isacc.cpu().numpy().astype(bool) == info.is_accepted
