@@ -36,6 +36,7 @@ struct FmArgs {
   double* loss_part;     // [gridDim.x] partial sums of squared residuals
   double ref_std;        // reference distribution of the flow: x0 = ref_std * normal (IndepGaussian(dim, var), distributions.py:93-97)
   const double* pre_x0; const double* pre_eps; const float* pre_t;   // non-null: the batch's draws, produced ahead of time by noise_kernel
+  int stagger_cycles;    // fm_eval_kernel<2, .>: start delay of the second workgroup of every CU (0: none)
 };
 
 struct FmLds {           // float offsets into dynamic LDS
@@ -456,6 +457,17 @@ template <int MT, int ACT>       // ACT: the hidden non-linearity as a compile-t
 __global__ __launch_bounds__((MLP_WAVES_FM * 64), (MT == 2 ? 4 : 2)) void fm_eval_kernel(FmArgs a) {      // (threads, waves per SIMD)
   constexpr int R = 16 * MT;
   const int act = ACT >= 0 ? ACT : a.net.act;
+  if constexpr (MT == 2) {
+    // Two workgroups share a CU so that one's vector-ALU phases (batch construction, epilogues) run under the other's MFMAs --
+    // but workgroups dispatched together and equally long stay IN PHASE (both in their prologue, both in their GEMMs).  The
+    // second workgroup of every CU of the first dispatch round starts half a workgroup's time late; slots freed later inherit
+    // the stagger.  (Dispatch order: one workgroup per CU over the whole chip, then the second.)
+    const int stagger = a.stagger_cycles;
+    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stagger) __builtin_amdgcn_s_sleep(64);
+    }
+  }
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const NetDev& n = a.net;
   const FmEvalLds L = fm_eval_lds_layout(n, R);
@@ -846,6 +858,9 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)fm_eval_kernel<MT_, ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr); \
     hipLaunchKernelGGL((fm_eval_kernel<MT_, ACT_>), dim3((a.B + 16 * MT_ - 1) / (16 * MT_)), dim3(MLP_WAVES_FM * 64), smr, stream, a); \
   } while (0)
+    FmArgs a2 = a;
+    { const char* e = getenv("MFM_EVAL_STAGGER"); a2.stagger_cycles = e ? atoi(e) : 30000; }       // measured: 1.023 -> 0.994 ms on 409,600 samples (any delay of 20 k .. 70 k cycles)
+    const FmArgs& a = a2;
     const bool relu = a.net.act == MFM_ACT_RELU;
     if (r == 32) { if (relu) FM_EVAL_LAUNCH(2, MFM_ACT_RELU); else FM_EVAL_LAUNCH(2, -1); }
     else { if (relu) FM_EVAL_LAUNCH(4, MFM_ACT_RELU); else FM_EVAL_LAUNCH(4, -1); }
