@@ -92,10 +92,11 @@ __device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf
 // with its dimensions, activation and target kind as compile-time constants -- loop bounds, tile counts and the LDS layout fold, the K loops
 // unroll; offsets into the parameter buffers stay the host's.  Same arithmetic as the generic instance (the compiler's multiply-add
 // contraction may differ in the last bits).
-template <int TPW, bool TRAIN, bool STATIC = false>
-__global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs a) {
+template <int TPW, bool TRAIN, bool STATIC = false, int ACT = -1>      // ACT >= 0: the activation as a compile-time constant (the five-way
+__global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs a) {      // run-time selection in every epilogue triples the code)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   NetDev nloc = a.net;
+  if constexpr (ACT >= 0) nloc.act = ACT;
   if constexpr (STATIC) {
     nloc.d = 256; nloc.dp = 256; nloc.F = 128; nloc.F2p = 256;
     nloc.ht1 = nloc.ht2 = nloc.hx1 = nloc.hx2 = nloc.hj1 = nloc.hj2 = 128;
@@ -872,11 +873,12 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
   if (sm > 160 * 1024) return -3;
   const int tpw = (a.net.dp / 16 + MLP_WAVES_FM - 1) / MLP_WAVES_FM;
   dim3 grid(a.B / 16), block((MLP_WAVES_FM * 64));
-#define FM_LAUNCH(T, TR)                                                                                   \
+#define FM_LAUNCH_A(T, TR, ACT_)                                                                           \
   do {                                                                                                     \
-    (void)hipFuncSetAttribute((const void*)fm_fwd_bwd_kernel<T, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-    hipLaunchKernelGGL((fm_fwd_bwd_kernel<T, TR>), grid, block, sm, stream, a);                           \
+    (void)hipFuncSetAttribute((const void*)fm_fwd_bwd_kernel<T, TR, false, ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+    hipLaunchKernelGGL((fm_fwd_bwd_kernel<T, TR, false, ACT_>), grid, block, sm, stream, a);              \
   } while (0)
+#define FM_LAUNCH(T, TR) do { if (a.net.act == MFM_ACT_RELU) FM_LAUNCH_A(T, TR, MFM_ACT_RELU); else FM_LAUNCH_A(T, TR, -1); } while (0)
   const NetDev& n = a.net;
   bool headline = n.d == 256 && n.dp == 256 && n.F == 128 && n.F2p == 256 && n.ht1 == 128 && n.ht2 == 128 && n.hx1 == 128 &&
                   n.hx2 == 128 && n.hj1 == 128 && n.hj2 == 128 && n.T.kind == MFM_TARGET_PHI4 && n.act == MFM_ACT_RELU && !getenv("MFM_GENERIC_FM");
@@ -896,6 +898,7 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
   }
 #undef FM_LAUNCH_S
 #undef FM_LAUNCH
+#undef FM_LAUNCH_A
   return 0;
 }
 
