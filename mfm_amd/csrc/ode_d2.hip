@@ -21,6 +21,10 @@
 // Differences to the generic tile are float reassociations only (K-split sums of the out / gate layers, FMA of the K = 2
 // layer); the replay instrumentation (mfm_debug_replay) is carried so the same step-for-step parity tests run on both.
 namespace d2 {
+#ifdef MFM_STAMPS
+__device__ unsigned long long d2_dummy;
+#define d2_cyc T.cyc
+#endif
 
 constexpr int NW = 8;
 
@@ -47,6 +51,12 @@ static bool shape_ok(const NetDev& n, int hutch) {
 }
 
 struct Tile {
+  static constexpr int CHAINS = 4;                 // chains per workgroup
+#ifdef MFM_STAMPS
+  unsigned long long cyc[4] = {0, 0, 0, 0};
+#endif
+  __device__ __forceinline__ int chain() const { return blockIdx.x * 4 + g; }        // the chain this lane carries
+  __device__ __forceinline__ bool writer() const { return wave == 0 && c == 0; }     // ONE lane per chain
   const NetDev* n;
   Lds L;
   float* lds;
@@ -245,6 +255,12 @@ __device__ __forceinline__ void gmm_grad_hdiag2(const TargetDev& T, float x0, fl
 
 template <int ACT>          // the hidden non-linearity as a compile-time constant (MFM_ACT_*), or -1: read from the network
 struct TileR {
+  static constexpr int CHAINS = 4;
+#ifdef MFM_STAMPS
+  unsigned long long cyc[4] = {0, 0, 0, 0};
+#endif
+  __device__ __forceinline__ int chain() const { return blockIdx.x * 4 + g; }
+  __device__ __forceinline__ bool writer() const { return wave == 0 && c == 0; }
   __device__ __forceinline__ int act() const { return ACT >= 0 ? ACT : n->act; }
   const NetDev* n;
   LdsR L;
@@ -428,6 +444,14 @@ struct TileR {
   }
 };
 
+
+// (Measured and dropped, round 3: a FOUR-ROW tile -- two chains per workgroup as two v_mfma_f32_4x4x1 passes sharing the resident
+// fragments, a quarter of the matrix-pipe time per chain and layer.  Parity-green on the first run, and no faster: in-kernel stamps
+// (tools/d2_cycles.py) put the resident tile at 9.7 k cycles per evaluation for 6.4 k of matrix pipe and the four-row tile at 10.0 k
+// for 3.6 k -- an evaluation is five barrier-separated phases of ~2 k cycles whose length is a dependent chain (LDS read -> MFMA
+// chain -> fold / epilogue -> barrier), not matrix throughput; with twice the workgroups it lost on large launches: 4096-chain
+// flow step 43.6 ms against 24.9.)
+
 // Integrate chain g's augmented ODE from t = 0 to 1 (every lane of group g holds the same state).  The state machine of
 // ode.hip: ode_solve -- phase 0: f0, phase 1: the extra evaluation of the initial-step heuristic, phases 2..7: the six stages.
 template <typename TILE>
@@ -457,13 +481,22 @@ __device__ __forceinline__ void solve(TILE& T, float rtol, float atol, int max_a
       xin[q] = y[q] + hs * acc;
     }
     float kv[2], dlv;
+#ifdef MFM_STAMPS
+    const unsigned long long c0_ = __builtin_amdgcn_s_memtime();
+#endif
     if (phase <= 2) {          // time branch: of the evaluations of the initial-step heuristic (phases 0, 1), of the five distinct
       float ts5[5];            // stage times of the attempt that starts (phase 2)
 #pragma unroll
       for (int q = 0; q < 5; ++q) ts5[q] = phase < 2 ? ts : t + dt * DP_TAB[2 + q][6];
       T.prepare(ts5);
     }
+#ifdef MFM_STAMPS
+    const unsigned long long c1_ = __builtin_amdgcn_s_memtime();
+#endif
     T.eval(xin[0], xin[1], ts, kv, dlv, phase);
+#ifdef MFM_STAMPS
+    { const unsigned long long c2_ = __builtin_amdgcn_s_memtime(); d2_cyc[0] += c1_ - c0_; d2_cyc[1] += c2_ - c1_; d2_cyc[2] += 1; if (phase <= 2) d2_cyc[3] += 1; }
+#endif
     const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
 #pragma unroll
     for (int j = 0; j < 7; ++j)
@@ -496,7 +529,7 @@ __device__ __forceinline__ void solve(TILE& T, float rtol, float atol, int max_a
       dt = fminf(100.f * h0, h1);
       if (rp.dt) {
         const size_t o = rp.at(rp_solve, rp_row, 0);
-        if (T.wave == 0 && T.c == 0) rp.dt_own[o] = dt;
+        if (T.writer()) rp.dt_own[o] = dt;
         dt = rp.dt[o];
       }
       phase = 2;
@@ -536,7 +569,7 @@ __device__ __forceinline__ void solve(TILE& T, float rtol, float atol, int max_a
         const int j = (int)na;
         const bool in = j < rp.cap, nx = j + 1 < rp.cap;
         const size_t o = rp.at(rp_solve, rp_row, in ? j : 0);
-        if (T.wave == 0 && T.c == 0 && in) { rp.ratio[o] = ratio; if (nx) rp.dt_own[o + 1] = ndt; }
+        if (T.writer() && in) { rp.ratio[o] = ratio; if (nx) rp.dt_own[o + 1] = ndt; }
         acc = in && rp.acc[o] != 0;
         ndt = nx ? rp.dt[o + 1] : 0.f;
       }
@@ -589,10 +622,10 @@ __global__ __launch_bounds__(NW * 64) void transform_kernel(OdeArgs a) {
   TILE T;
   T.init(&a.net, lds);
   T.sign = a.direction;
-  const int b = blockIdx.x * 4 + T.g;
+  const int b = T.chain();
   float y[2] = {a.in[(size_t)b * 2], a.in[(size_t)b * 2 + 1]}, ell; int natt;
   solve(T, a.rtol, a.atol, a.max_attempts, y, ell, natt, a.rp, 0, b);
-  if (T.wave == 0 && T.c == 0) {
+  if (T.writer()) {
     a.out[(size_t)b * 2] = y[0]; a.out[(size_t)b * 2 + 1] = y[1];
     a.ldj[b] = ell;
     if (a.nsteps) a.nsteps[b] = natt;
@@ -603,10 +636,13 @@ __global__ __launch_bounds__(NW * 64) void transform_kernel(OdeArgs a) {
 template <typename TILE>
 __global__ __launch_bounds__(NW * 64) void flow_kernel(OdeArgs a, FlowArgs f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef MFM_STAMPS
+  const unsigned long long fc0_ = __builtin_amdgcn_s_memtime();
+#endif
   TILE T;
   T.init(&a.net, lds);
   const NetDev& N = a.net;
-  const int b = blockIdx.x * 4 + T.g;
+  const int b = T.chain();
   const Key2 kb = split_at(f.key, f.n_total, f.chain_offset + (uint32_t)b);                         // :303
   const double lp_old = f.logp[b];
   float y[2] = {f.pos[(size_t)b * 2], f.pos[(size_t)b * 2 + 1]}, ell, vol0, lq_ref = 0.f;
@@ -641,7 +677,7 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(OdeArgs a, FlowArgs f) {
   const double ap = exp(la);
   const double u = uniform01(split_at(kb, 4, 1), 0, 1);
   const bool acc = u <= ap;                       // NaN compares false -> reject
-  if (T.wave == 0 && T.c == 0) {
+  if (T.writer()) {
     if (a.rp.diag) { double* o = a.rp.diag + 4 * (size_t)b; o[0] = vol0; o[1] = ell; o[2] = lpn; o[3] = la; }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -654,6 +690,12 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(OdeArgs a, FlowArgs f) {
     if (f.accepted) f.accepted[b] = acc ? 1 : 0;
     if (f.nsteps) f.nsteps[b] = natt_tot;
   }
+#ifdef MFM_STAMPS
+  if (g_flow_dbg && threadIdx.x == 0) {
+    unsigned long long* o = g_flow_dbg + blockIdx.x * 64;
+    o[0] = __builtin_amdgcn_s_memtime() - fc0_; o[2] = T.cyc[2]; o[3] = T.cyc[1]; o[5] = T.cyc[3]; o[6] = T.cyc[0];
+  }
+#endif
 }
 
 // Which tiling serves a launch of `rows` samples.  The resident-weight 4-chain tile wherever its shape fits (measured against the
@@ -673,13 +715,13 @@ static bool use_for(const NetDev& n, int hutch, int rows) { return pick(n, hutch
 template <typename TILE>
 static int launch_transform_t(const OdeArgs& a, size_t sm, hipStream_t stream) {
   (void)hipFuncSetAttribute((const void*)transform_kernel<TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL(transform_kernel<TILE>, dim3(a.n / 4), dim3(NW * 64), sm, stream, a);
+  hipLaunchKernelGGL(transform_kernel<TILE>, dim3(a.n / TILE::CHAINS), dim3(NW * 64), sm, stream, a);
   return 0;
 }
 template <typename TILE>
 static int launch_flow_t(const OdeArgs& a, const FlowArgs& f, size_t sm, hipStream_t stream) {
   (void)hipFuncSetAttribute((const void*)flow_kernel<TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL(flow_kernel<TILE>, dim3(a.n / 4), dim3(NW * 64), sm, stream, a, f);
+  hipLaunchKernelGGL(flow_kernel<TILE>, dim3(a.n / TILE::CHAINS), dim3(NW * 64), sm, stream, a, f);
   return 0;
 }
 static int launch_transform(const OdeArgs& a, hipStream_t stream) {
@@ -687,6 +729,7 @@ static int launch_transform(const OdeArgs& a, hipStream_t stream) {
     const size_t sm = (size_t)layout_r().total * sizeof(float);
     return a.net.act == MFM_ACT_RELU ? launch_transform_t<TileR<MFM_ACT_RELU>>(a, sm, stream) : launch_transform_t<TileR<-1>>(a, sm, stream);
   }
+
   return launch_transform_t<Tile>(a, (size_t)layout(a.net).total * sizeof(float), stream);
 }
 static int launch_flow(const OdeArgs& a, const FlowArgs& f, hipStream_t stream) {
@@ -694,6 +737,7 @@ static int launch_flow(const OdeArgs& a, const FlowArgs& f, hipStream_t stream) 
     const size_t sm = (size_t)layout_r().total * sizeof(float);
     return a.net.act == MFM_ACT_RELU ? launch_flow_t<TileR<MFM_ACT_RELU>>(a, f, sm, stream) : launch_flow_t<TileR<-1>>(a, f, sm, stream);
   }
+
   return launch_flow_t<Tile>(a, f, (size_t)layout(a.net).total * sizeof(float), stream);
 }
 
