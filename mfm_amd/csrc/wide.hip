@@ -1189,6 +1189,7 @@ struct Ctx {
 
 static int create(const NetDev& n, int rows_cap, Ctx** out) {
   Ctx* w = new Ctx();
+  *out = w;            // handed over at once: whatever a failure below leaves allocated is freed by the caller's destroy()
   w->R = (rows_cap + 15) & ~15;
   w->d = n.d; w->dp = n.dp; w->F2p = n.F2p; w->ht1 = n.ht1; w->ht2 = n.ht2; w->hx1 = n.hx1; w->hx2 = n.hx2; w->hj1 = n.hj1; w->hj2 = n.hj2;
   w->cat = n.hx2 + n.ht2;
@@ -1206,7 +1207,7 @@ static int create(const NetDev& n, int rows_cap, Ctx** out) {
   const size_t o_pt1 = need_pre ? take(R * n.ht1) : 0, o_pcat = need_pre ? take(R * w->cat) : 0, o_px1 = need_pre ? take(R * n.hx1) : 0,
                o_pj1 = need_pre ? take(R * n.hj1) : 0, o_pj2 = need_pre ? take(R * n.hj2) : 0;
   w->pool_floats = o;
-  if (hipMalloc((void**)&w->pool, o * sizeof(float)) != hipSuccess) { delete w; return -4; }
+  if (hipMalloc((void**)&w->pool, o * sizeof(float)) != hipSuccess) return -4;
   (void)hipMemset(w->pool, 0, o * sizeof(float));
   float* p = w->pool;
   w->ffat = p + o_ffat; w->t1 = p + o_t1; w->catv = p + o_cat; w->cond = p + o_cond; w->x1 = p + o_x1; w->j1 = p + o_j1; w->j2 = p + o_j2;
@@ -1240,7 +1241,6 @@ static int create(const NetDev& n, int rows_cap, Ctx** out) {
   w->n_jobs = (int)jobs.size();
   if (hipMalloc((void**)&w->jobs, jobs.size() * sizeof(WgJob)) != hipSuccess) return -4;
   (void)hipMemcpy(w->jobs, jobs.data(), jobs.size() * sizeof(WgJob), hipMemcpyHostToDevice);
-  *out = w;
   return 0;
 }
 

@@ -142,3 +142,34 @@ def test_phi_four_reference_defaults_three_cycles_match_frozen_oracle_run():
     assert abs(res[0] - float(o["logpdf"])) < 0.05 * float(_spread(g, "logpdf"))
     assert abs(res[2] - float(o["ksd_v"])) < 0.05 * float(_spread(g, "ksd_v"))
     ex["engine"].close()
+
+
+def test_headline_shape_one_cycle_matches_frozen_oracle_run():
+    """BASELINE configs[2] at its real shape -- phi-four d = 256, 4096 chains, K = 100, --hutch (the benchmarked configuration) --
+    for one full MALA / flow cycle and two iterations after its flow step (103 iterations, ~10 min of oracle time per seed):
+    100 annealed MALA + training iterations on the same chains and noise, the flow-MH step of iteration 101 (two adaptive Dopri5
+    solves per chain, ~170 attempted steps each), the iterations after it, the final flow samples and their scores."""
+    g = _gold("phi4_256")
+    o = g[1]
+    args, res, res_, ex = _run("phi4_256")
+    m = ex["metrics"]
+    K1 = 100
+    pre = dict(loss=_rel(m[:K1, 0], o["loss"][:K1]).max(), beta=_rel(ex["betas"][:K1], o["beta"][:K1]).max(),
+               acc_mean=np.abs(m[:K1, 1] - o["acc_mean"][:K1]).max(), acc_std=np.abs(m[:K1, 2] - o["acc_std"][:K1]).max())
+    print("phi-four d=256 / 4096 chains e2e, iterations 1..100:", {k: f"{v:.1e}" for k, v in pre.items()})
+    assert pre["loss"] < 5e-6 and pre["beta"] < 1e-5 and pre["acc_mean"] < 5e-5 and pre["acc_std"] < 5e-5, pre
+    np.testing.assert_allclose(ex["lrs"], o["learning_rate"], rtol=1e-12)
+    # the flow step of iteration 101: attempted Dopri5 steps per chain (both solves), acceptance (unclipped mean of exp(log alpha))
+    c = ex["engine"].ctx.counters()
+    natt_g = c["dopri_attempts"] / max(c["ode_solves"], 1) * 2.0
+    natt_o = float(np.sum(o["n_att"][0]))
+    rl = _rel(m[K1:, 0], o["loss"][K1:])
+    print(f"   flow step: attempts per chain gpu {natt_g:.1f} oracle {natt_o:.1f}; acceptance gpu {m[K1, 1]:.3e} oracle {o['acc_mean'][K1]:.3e}; "
+          f"loss iterations 101..103 rel {rl}")
+    pos = ex["states"].position.cpu().numpy().astype(np.float64)
+    dm, ds = np.abs(pos.mean(0) - o["chain_mean"]).max(), np.abs((pos ** 2).mean(0) - o["chain_second"]).max()
+    print(f"   final chains: |d mean| {dm:.1e} (seed spread {_spread(g, 'chain_mean').max():.1e}), |d second| {ds:.1e} (seed spread {_spread(g, 'chain_second').max():.1e}); "
+          f"logpdf gpu {res[0]:.1f} oracle {float(o['logpdf']):.1f} (seed spread {float(_spread(g, 'logpdf')):.1f}), KSD-V gpu {res[2]:.1f} oracle {float(o['ksd_v']):.1f} "
+          f"(seed spread {float(_spread(g, 'ksd_v')):.1f})")
+    ex["engine"].close()
+    return dict(pre=pre, natt=(natt_g, natt_o), rl=rl, dm=dm, ds=ds)

@@ -8,7 +8,9 @@ tests/test_gpu_e2e.py are derived from):
   trace, n_ts = 5, eval_iter 100 -> ``eval_step`` on 51,200 exact samples every iteration, final sampling of 51,200
   flow samples + importance resampling, logpdf / KSD-U / KSD-V / MMD: ``exe_flow_matching.py:432-449,453-490``);
 * ``phi4``   the reference's own phi-four defaults (``multi_modal.py:50-63``: d = 64, 1024 chains, step 1e-4,
-  eval_iter 1; exact trace, K = 10) over three MALA/flow cycles (``--learning_iter 33``).
+  eval_iter 1; exact trace, K = 10) over three MALA/flow cycles (``--learning_iter 33``);
+* ``phi4_256``  BASELINE configs[2] (the headline): phi-four d = 256, 4096 chains, K = 100, ``--hutch``, 103 iterations
+  (one full cycle with its flow step at iteration 101, two iterations after it).
 
 The reference itself cannot be run here (no jax) and ships no fixtures: these are outputs of the ORACLE (oracle/),
 frozen because they take minutes to hours of CPU time; they are not outputs of the reference.
@@ -28,6 +30,9 @@ CASES = {
                   eval_iter=100, hutchs=False),
     "phi4": dict(example="phi-four", dim=64, num_chain=1024, learning_iter=33, mcmc_per_flow_steps=10.0, step_size=1e-4,
                  eval_iter=1, hutchs=False),
+    # BASELINE configs[2], the headline: phi-four d = 256, 4096 chains, K = 100, --hutch -- one full MALA / flow cycle + 2 iterations
+    "phi4_256": dict(example="phi-four", dim=256, num_chain=4096, learning_iter=103, mcmc_per_flow_steps=100.0, step_size=1e-4,
+                     eval_iter=1, hutchs=True),
 }
 
 
@@ -38,7 +43,7 @@ def make_dist(case):
         modes, covs, w = 8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4
         d = targets.GaussianMixture(modes, covs, w)
         return d, d.sample_model_rows
-    return targets.PhiFour(64), None
+    return targets.PhiFour(CASES[case]["dim"]), None
 
 
 def run_one(job):
@@ -60,7 +65,7 @@ def run_one(job):
                target_loss=np.array(tr["target_loss"]) if tr["target_loss"] else np.zeros(0))
     pos = out["states"].position
     res.update(chain_mean=pos.mean(0), chain_second=(pos[:, :, None] * pos[:, None, :]).mean(0) if pos.shape[1] <= 8 else (pos ** 2).mean(0),
-               chain_logdensity_mean=out["states"].logdensity.mean(), chain_pos=pos.astype(np.float32) if case == "4mode" else pos[:64].astype(np.float32))
+               chain_logdensity_mean=out["states"].logdensity.mean(), chain_pos=pos.astype(np.float32) if case == "4mode" else pos[:64, :64].astype(np.float32))
     print(f"[{case} seed {seed}] loop done in {time.time() - t0:.0f} s; final sampling", flush=True)
     st = {}
     x, ex, info = loop.final_sampling(out["model"], out["state"].params, dist, args, out["keys"]["gen"], stats=st)   # :453-459
