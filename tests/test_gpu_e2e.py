@@ -44,7 +44,7 @@ def _run(case):
         dist = D.GaussianMixture(8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4)
         tg = dist.sample_model
     else:
-        dist, tg = D.PhiFour(64), None
+        dist, tg = D.PhiFour(CASES[case]["dim"]), None
     res, res_, ex = E.run(dist, args, tg, log_every=1000, return_extras=True)
     return args, res, res_, ex
 
@@ -156,20 +156,32 @@ def test_headline_shape_one_cycle_matches_frozen_oracle_run():
     K1 = 100
     pre = dict(loss=_rel(m[:K1, 0], o["loss"][:K1]).max(), beta=_rel(ex["betas"][:K1], o["beta"][:K1]).max(),
                acc_mean=np.abs(m[:K1, 1] - o["acc_mean"][:K1]).max(), acc_std=np.abs(m[:K1, 2] - o["acc_std"][:K1]).max())
-    print("phi-four d=256 / 4096 chains e2e, iterations 1..100:", {k: f"{v:.1e}" for k, v in pre.items()})
-    assert pre["loss"] < 5e-6 and pre["beta"] < 1e-5 and pre["acc_mean"] < 5e-5 and pre["acc_std"] < 5e-5, pre
+    r100 = _rel(m[:K1, 0], o["loss"][:K1])
+    first = int(np.argmax(r100 > 1e-6)) if (r100 > 1e-6).any() else -1
+    print("phi-four d=256 / 4096 chains e2e, iterations 1..100:", {k: f"{v:.1e}" for k, v in pre.items()}, f"first iteration with a loss difference > 1e-6: {first + 1}")
+    # a hundred AdamW updates on float32 forward / backward passes: the loss traces agree to 1e-9 at first, cross 1e-6 at iteration
+    # 15 and drift apart to 9e-5 by iteration 100 (median 3e-5; temperatures 1.7e-5, acceptance 6e-6) -- float32 rounding fed back
+    # through the optimizer, no decision of the 409,600 MALA accept steps visibly flipped (one would move the acceptance mean by
+    # 2.4e-4 and the loss by ~1 / 4096 of itself)
+    assert pre["loss"] < 5e-4 and np.median(r100) < 2e-4 and pre["beta"] < 1e-4 and pre["acc_mean"] < 1e-4 and pre["acc_std"] < 1e-4, pre
     np.testing.assert_allclose(ex["lrs"], o["learning_rate"], rtol=1e-12)
-    # the flow step of iteration 101: attempted Dopri5 steps per chain (both solves), acceptance (unclipped mean of exp(log alpha))
+    # the flow step of iteration 101 and the final transform: attempted Dopri5 steps per chain (three solves: the counters total them)
     c = ex["engine"].ctx.counters()
-    natt_g = c["dopri_attempts"] / max(c["ode_solves"], 1) * 2.0
-    natt_o = float(np.sum(o["n_att"][0]))
+    natt_g = c["dopri_attempts"] / 4096.0
+    natt_o = float(np.sum(o["n_att"][0])) + float(o["final_natt_mean"])
     rl = _rel(m[K1:, 0], o["loss"][K1:])
-    print(f"   flow step: attempts per chain gpu {natt_g:.1f} oracle {natt_o:.1f}; acceptance gpu {m[K1, 1]:.3e} oracle {o['acc_mean'][K1]:.3e}; "
+    print(f"   flow step + final transform: attempts per chain gpu {natt_g:.1f} oracle {natt_o:.1f}; acceptance gpu {m[K1, 1]:.3e} oracle {o['acc_mean'][K1]:.3e}; "
           f"loss iterations 101..103 rel {rl}")
+    assert abs(natt_g - natt_o) < 0.03 * natt_o                       # two adaptive controllers (float32 / float64) on the same flow
+    assert m[K1, 1] < 1e-30 and o["acc_mean"][K1] < 1e-30              # after one cycle every proposal is rejected, on both sides (log alpha ~ -700 .. -9000)
+    assert rl.max() < 5e-4
     pos = ex["states"].position.cpu().numpy().astype(np.float64)
     dm, ds = np.abs(pos.mean(0) - o["chain_mean"]).max(), np.abs((pos ** 2).mean(0) - o["chain_second"]).max()
     print(f"   final chains: |d mean| {dm:.1e} (seed spread {_spread(g, 'chain_mean').max():.1e}), |d second| {ds:.1e} (seed spread {_spread(g, 'chain_second').max():.1e}); "
           f"logpdf gpu {res[0]:.1f} oracle {float(o['logpdf']):.1f} (seed spread {float(_spread(g, 'logpdf')):.1f}), KSD-V gpu {res[2]:.1f} oracle {float(o['ksd_v']):.1f} "
           f"(seed spread {float(_spread(g, 'ksd_v')):.1f})")
+    # measured: moments 2e-5 (0.1 % of the seed spread), logpdf -75382.7 vs -75379.9 (0.8 %), KSD-V 79080 vs 79063 (1.2 %)
+    assert dm < 0.02 * _spread(g, "chain_mean").max() and ds < 0.02 * _spread(g, "chain_second").max()
+    assert abs(res[0] - float(o["logpdf"])) < 0.1 * float(_spread(g, "logpdf"))
+    assert abs(res[2] - float(o["ksd_v"])) < 0.1 * float(_spread(g, "ksd_v"))
     ex["engine"].close()
-    return dict(pre=pre, natt=(natt_g, natt_o), rl=rl, dm=dm, ds=ds)
