@@ -43,6 +43,12 @@ def _run(case):
     if case == "4mode":
         dist = D.GaussianMixture(8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4)
         tg = dist.sample_model
+    elif case == "gmm16":
+        gp = np.load(os.path.join(GOLD, "gmm16_params.npz"))
+        dist = D.GaussianMixture(gp["modes"], gp["covs"], gp["weights"])
+        tg = dist.sample_model
+    elif case == "pines":
+        dist, tg = D.LogGaussianCoxPines(1024), None
     else:
         dist, tg = D.PhiFour(CASES[case]["dim"]), None
     res, res_, ex = E.run(dist, args, tg, log_every=1000, return_extras=True)
@@ -185,3 +191,45 @@ def test_headline_shape_one_cycle_matches_frozen_oracle_run():
     assert abs(res[0] - float(o["logpdf"])) < 0.1 * float(_spread(g, "logpdf"))
     assert abs(res[2] - float(o["ksd_v"])) < 0.1 * float(_spread(g, "ksd_v"))
     ex["engine"].close()
+
+
+@pytest.mark.parametrize("case", ["gmm16", "pines"])
+def test_loop_of_the_other_baseline_configurations_matches_frozen_oracle_runs(case):
+    """The training loop of BASELINE configs[1] (16-mode mixture, 4096 chains, K = 100, exact trace, `eval_step` on 409,600 exact
+    samples every iteration) and of one GPU's share of configs[4] (pines 32 x 32, 1024 chains, hidden 1024, --hutch: the wide
+    kernel family) at their real shapes: one full cycle and two iterations after its flow step, against frozen oracle runs."""
+    g = _gold(case)
+    o = g[1]
+    args, res, res_, ex = _run(case)
+    m = ex["metrics"]
+    K1 = 100
+    r100 = _rel(m[:K1, 0], o["loss"][:K1])
+    pre = dict(loss=r100.max(), loss_median=float(np.median(r100)), beta=_rel(ex["betas"][:K1], o["beta"][:K1]).max(),
+               acc_mean=np.abs(m[:K1, 1] - o["acc_mean"][:K1]).max(), acc_std=np.abs(m[:K1, 2] - o["acc_std"][:K1]).max())
+    if o["target_loss"].size:
+        pre["target_loss"] = _rel(m[:K1, 3], o["target_loss"][:K1]).max()
+    print(f"{case} e2e, iterations 1..100:", {k: f"{v:.1e}" for k, v in pre.items()})
+    rl = _rel(m[K1:, 0], o["loss"][K1:])
+    pos = ex["states"].position.cpu().numpy().astype(np.float64)
+    dm = np.abs(pos.mean(0) - o["chain_mean"]).max()
+    sec_o = o["chain_second"]
+    sec_g = (pos[:, :, None] * pos[:, None, :]).mean(0) if sec_o.ndim == 2 else (pos ** 2).mean(0)
+    ds = np.abs(sec_g - sec_o).max()
+    print(f"   flow iteration: acceptance gpu {m[K1, 1]:.3e} oracle {o['acc_mean'][K1]:.3e}, oracle attempts (inverse, forward) {o['n_att'][0]}; loss iterations 101..103 rel {rl}; "
+          f"final chains |d mean| {dm:.1e} (seed spread {_spread(g, 'chain_mean').max():.1e}), |d second| {ds:.1e} (seed spread {_spread(g, 'chain_second').max():.1e})")
+    np.testing.assert_allclose(ex["lrs"], o["learning_rate"], rtol=1e-12)
+    ex["engine"].close()
+    sm, ss = _spread(g, "chain_mean").max(), _spread(g, "chain_second").max()
+    la_g, la_o = np.log(max(m[K1, 1], 1e-300)), np.log(max(float(o["acc_mean"][K1]), 1e-300))
+    if case == "gmm16":
+        # measured: loss 2.2e-4 worst / 2e-5 median over the 100 MALA iterations (annealing active: 4096 chains spread over 16 modes,
+        # acceptance ~0.6: a chain whose accept decision differs moves the sum by ~1 / 4096), eval loss 5e-4, temperature 6e-8;
+        # flow iteration: the UNCLIPPED mean acceptance 3.513 vs 3.495; loss after it 3e-5 .. 1.3e-3; final moments 4 % / 6 % of the seed spread
+        assert pre["loss"] < 1e-3 and pre["loss_median"] < 1e-4 and pre["target_loss"] < 2e-3 and pre["beta"] < 1e-5 and pre["acc_mean"] < 1e-5, pre
+        assert abs(la_g - la_o) < 0.05 and rl.max() < 5e-3 and dm < 0.15 * sm and ds < 0.15 * ss, (la_g, la_o, rl, dm / sm, ds / ss)
+    else:
+        # measured: loss 2.5e-5 worst / 3e-6 median, temperature 8e-5, acceptance 6e-6; the flow iteration's unclipped mean acceptance
+        # is exp(log alpha) of its largest chain (log alpha ~ 30: 1.2e13 vs 6.6e12, i.e. 0.57 apart in the log -- the clipped field's
+        # log-det, DESIGN.md section 2); loss after it 5e-5; final moments 0.7 % of the seed spread
+        assert pre["loss"] < 2e-4 and pre["loss_median"] < 2e-5 and pre["beta"] < 5e-4 and pre["acc_mean"] < 1e-4, pre
+        assert abs(la_g - la_o) < 1.5 and rl.max() < 5e-4 and dm < 0.05 * sm and ds < 0.05 * ss, (la_g, la_o, rl, dm / sm, ds / ss)

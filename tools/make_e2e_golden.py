@@ -33,7 +33,15 @@ CASES = {
     # BASELINE configs[2], the headline: phi-four d = 256, 4096 chains, K = 100, --hutch -- one full MALA / flow cycle + 2 iterations
     "phi4_256": dict(example="phi-four", dim=256, num_chain=4096, learning_iter=103, mcmc_per_flow_steps=100.0, step_size=1e-4,
                      eval_iter=1, hutchs=True),
+    # BASELINE configs[1]: the 16-mode mixture, 4096 chains, K = 100, exact trace, eval_step on 409,600 exact samples every iteration
+    # (the LOOP only: its final sampling is 409,600 exact-trace solves, hours of oracle time)
+    "gmm16": dict(example="gaussian-mixture", dim=2, num_chain=4096, learning_iter=103, mcmc_per_flow_steps=100.0, step_size=0.2,
+                  eval_iter=100, hutchs=False),
+    # BASELINE configs[4], one GPU's share: pines 32 x 32 grid (d = 1024), 1024 chains, hidden 1024, K = 100, --hutch
+    "pines": dict(example="pines", dim=1024, num_chain=1024, learning_iter=103, mcmc_per_flow_steps=100.0, step_size=0.01,
+                  eval_iter=1, hutchs=True, hidden_x=[1024, 1024], hidden_t=[1024, 1024], hidden_xt=[1024, 1024]),
 }
+NO_FINAL = ("gmm16",)
 
 
 def make_dist(case):
@@ -43,6 +51,13 @@ def make_dist(case):
         modes, covs, w = 8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4
         d = targets.GaussianMixture(modes, covs, w)
         return d, d.sample_model_rows
+    if case == "gmm16":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "gmm16_params.npz"))
+        d = targets.GaussianMixture(g["modes"], g["covs"], g["weights"])
+        return d, d.sample_model_rows
+    if case == "pines":
+        counts = np.load(os.path.join(ROOT, "mfm_amd", "data", "pines_counts.npz"))["counts_32"]
+        return targets.LogGaussianCoxPines(1024, counts), None
     return targets.PhiFour(CASES[case]["dim"]), None
 
 
@@ -65,8 +80,11 @@ def run_one(job):
                target_loss=np.array(tr["target_loss"]) if tr["target_loss"] else np.zeros(0))
     pos = out["states"].position
     res.update(chain_mean=pos.mean(0), chain_second=(pos[:, :, None] * pos[:, None, :]).mean(0) if pos.shape[1] <= 8 else (pos ** 2).mean(0),
-               chain_logdensity_mean=out["states"].logdensity.mean(), chain_pos=pos.astype(np.float32) if case == "4mode" else pos[:64, :64].astype(np.float32))
+               chain_logdensity_mean=out["states"].logdensity.mean(), chain_pos=pos.astype(np.float32) if pos.shape[1] == 2 else pos[:64, :64].astype(np.float32))
     print(f"[{case} seed {seed}] loop done in {time.time() - t0:.0f} s; final sampling", flush=True)
+    if case in NO_FINAL:
+        res["oracle_seconds"] = time.time() - t0
+        return case, seed, res
     st = {}
     x, ex, info = loop.final_sampling(out["model"], out["state"].params, dist, args, out["keys"]["gen"], stats=st)   # :453-459
     res.update(final_natt_mean=st["n_attempted"].mean(), logpdf=info["samples_logdensity"].mean(),                  # :469
