@@ -21,10 +21,6 @@
 // Differences to the generic tile are float reassociations only (K-split sums of the out / gate layers, FMA of the K = 2
 // layer); the replay instrumentation (mfm_debug_replay) is carried so the same step-for-step parity tests run on both.
 namespace d2 {
-#ifdef MFM_STAMPS
-__device__ unsigned long long d2_dummy;
-#define d2_cyc T.cyc
-#endif
 
 constexpr int NW = 8;
 
@@ -495,7 +491,7 @@ __device__ __forceinline__ void solve(TILE& T, float rtol, float atol, int max_a
 #endif
     T.eval(xin[0], xin[1], ts, kv, dlv, phase);
 #ifdef MFM_STAMPS
-    { const unsigned long long c2_ = __builtin_amdgcn_s_memtime(); d2_cyc[0] += c1_ - c0_; d2_cyc[1] += c2_ - c1_; d2_cyc[2] += 1; if (phase <= 2) d2_cyc[3] += 1; }
+    { const unsigned long long c2_ = __builtin_amdgcn_s_memtime(); T.cyc[0] += c1_ - c0_; T.cyc[1] += c2_ - c1_; T.cyc[2] += 1; if (phase <= 2) T.cyc[3] += 1;      // time batch, evaluation, counts (tools/d2_cycles.py) }
 #endif
     const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
 #pragma unroll
