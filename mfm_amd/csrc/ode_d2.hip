@@ -491,7 +491,7 @@ __device__ __forceinline__ void solve(TILE& T, float rtol, float atol, int max_a
 #endif
     T.eval(xin[0], xin[1], ts, kv, dlv, phase);
 #ifdef MFM_STAMPS
-    { const unsigned long long c2_ = __builtin_amdgcn_s_memtime(); T.cyc[0] += c1_ - c0_; T.cyc[1] += c2_ - c1_; T.cyc[2] += 1; if (phase <= 2) T.cyc[3] += 1;      // time batch, evaluation, counts (tools/d2_cycles.py) }
+    { const unsigned long long c2_ = __builtin_amdgcn_s_memtime(); T.cyc[0] += c1_ - c0_; T.cyc[1] += c2_ - c1_; T.cyc[2] += 1; if (phase <= 2) T.cyc[3] += 1; }      // time batch, evaluation, counts (tools/d2_cycles.py)
 #endif
     const int dst = phase == 0 ? 0 : phase - 1 + (phase == 1 ? 1 : 0);
 #pragma unroll
