@@ -144,3 +144,29 @@ def test_hip_kernels_match_extended_golden_vectors():
     if fin.any():
         assert np.abs(la[fin] - GX["wg_imh_logacc"][fin]).max() < 0.5 + 2e-4 * np.abs(GX["wg_imh_logacc"][fin]).max()
     ctx.close()
+
+
+def test_end_to_end_fixtures_are_complete_and_self_consistent():
+    """tests/golden/e2e_*.npz (tools/make_e2e_golden.py): three oracle seeds per case with every trace the GPU tests compare;
+    learning-rate traces equal the schedule (exe_flow_matching.py:189-198), temperatures are non-decreasing and end at <= 1,
+    the flow iterations carry attempt counts, and the seeds really differ."""
+    import os
+    from oracle import optim
+    from tools.make_e2e_golden import CASES
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for case, cfg in CASES.items():
+        z = np.load(os.path.join(gold, f"e2e_{case}.npz"))
+        assert list(z["seeds"]) == [1, 2, 3]
+        n_it, K = cfg["learning_iter"], int(cfg["mcmc_per_flow_steps"])
+        lr = optim.learning_rate_fn(n_it, 0, 1e-3)
+        for s in (1, 2, 3):
+            for key in ("loss", "learning_rate", "beta", "acc_mean", "acc_std"):
+                assert z[f"s{s}_{key}"].shape == (n_it,), (case, s, key)
+            np.testing.assert_allclose(z[f"s{s}_learning_rate"], [lr(i) for i in range(n_it)], rtol=1e-12)
+            b = z[f"s{s}_beta"]
+            assert (np.diff(b) >= 0).all() and 0 < b[0] and b[-1] <= 1.0
+            assert z[f"s{s}_n_att"].shape == (n_it // (K + 1), 2) and (z[f"s{s}_n_att"] > 1).all()
+            assert np.isfinite(z[f"s{s}_loss"]).all() and np.isfinite(z[f"s{s}_chain_mean"]).all()
+            if cfg["example"] in ("4-mode", "gaussian-mixture"):
+                assert z[f"s{s}_target_loss"].shape == (n_it,)
+        assert abs(z["s1_loss"][0] - z["s2_loss"][0]) > 1e-6 * abs(z["s1_loss"][0])
