@@ -84,6 +84,7 @@ struct mfm_ctx {
   ncclComm_t comm = nullptr; int comm_nranks = 0;
   hipStream_t comm_stream = nullptr; hipEvent_t ev_grads = nullptr, ev_comm = nullptr;
   const float* comm_pending = nullptr;   // gradient buffer whose all-reduce is in flight on comm_stream
+  FmMala fuse_mala = {};                 // on != 0 during a mfm_train_iter whose MALA step rides in the training kernel
 };
 
 struct ProfScope {
@@ -524,6 +525,7 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
     }
     return MFM_OK;
   }
+  if (train && x->fuse_mala.on) a.mala = x->fuse_mala;      // mfm_train_iter: the iteration's MALA step in the same launch
   if (train && x->cfg.cond_flow) {
     const int slot = noise_take(x, key, true);
     if (slot >= 0) {
@@ -708,7 +710,26 @@ extern "C" int mfm_train_iter(mfm_ctx* x, int64_t count, int K, int flow_mode, u
   if (K < 1) return fail(MFM_EINVAL, "mfm_train_iter serves mcmc_per_flow_steps >= 1; compose the other schedules from the separate calls");
   if (count < 0) return fail(MFM_EINVAL, "count must be non-negative");
   int rc;
+  static const bool no_fuse = getenv("MFM_NO_FUSED_MALA") != nullptr;
   if (count % ((int64_t)K + 1) == 0) rc = mfm_flow_step(x, flow_mode, gk0, gk1, beta, d_pos, d_logp, d_grad, d_acc, nullptr, nullptr, d_nsteps);
+  else if (x->has_target && !x->wide && !no_fuse && fm_mala_fusable(x->net)) {
+    // the MALA step rides in the training kernel (fm.hip: fm_fwd_bwd_kernel<.., MALA>): same arithmetic, same draws, one launch less
+    if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
+    if (!(step_size > 0)) return fail(MFM_EINVAL, "step_size must be positive");
+    FmMala m; memset(&m, 0, sizeof m);
+    m.on = 1; m.key = Key2{gk0, gk1}; m.beta = beta; m.eps = step_size; m.logp = d_logp; m.grad = d_grad; m.acc_prob = d_acc;
+    const int slot = noise_take(x, m.key, false);
+    if (slot >= 0) {
+      const size_t B = (size_t)x->cfg.n_chain_local;
+      m.pre_n = x->noise->mala_n + (size_t)slot * B * x->cfg.dim; m.pre_u = x->noise->mala_u + (size_t)slot * B;
+    }
+    x->fuse_mala = m;
+    rc = mfm_fm_loss_grad(x, tk0, tk1, d_pos, d_loss, d_grads);
+    x->fuse_mala.on = 0;
+    if (rc == MFM_OK) { x->ctr[CTR_MALA] += x->cfg.n_chain_local; x->ctr[CTR_MALA_BYTES] += (int64_t)x->cfg.n_chain_local * 4 * (5 * x->cfg.dim + 5); }
+    if (rc || !apply_update) return rc;
+    return mfm_adamw_step(x, d_grads);
+  }
   else rc = mfm_mala_step(x, gk0, gk1, beta, step_size, 0, d_pos, d_logp, d_grad, d_acc, nullptr, nullptr, nullptr);
   if (rc) return rc;
   rc = mfm_fm_loss_grad(x, tk0, tk1, d_pos, d_loss, d_grads);

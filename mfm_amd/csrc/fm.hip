@@ -20,6 +20,16 @@ struct WsLayout {            // tile-row offsets (units: NBB * 256 floats) into 
   int z_t1, z_t2, z_x1, z_x2, z_gate, z_j1, z_j2, z_out, z_tiles;
 };
 
+// The MALA step of the same iteration, run by the training kernel's workgroup on ITS 16 chains before it builds their batch
+// (mfm_train_iter on one rank: exe_flow_matching.py:300-314 directly followed by :362-368; mala.hip: mala_chain_step)
+struct FmMala {
+  int on, textbook;
+  Key2 key;
+  double beta, eps;
+  double* logp; float* grad; float* acc_prob;      // chain state beside `pos` (updated in place), acceptance probability (may be null)
+  const double* pre_n; const double* pre_u;        // draws produced ahead of time (noise.hip), or null
+};
+
 struct FmArgs {
   NetDev net;
   WsLayout ws;
@@ -37,6 +47,7 @@ struct FmArgs {
   double ref_std;        // reference distribution of the flow: x0 = ref_std * normal (IndepGaussian(dim, var), distributions.py:93-97)
   const double* pre_x0; const double* pre_eps; const float* pre_t;   // non-null: the batch's draws, produced ahead of time by noise_kernel
   int stagger_cycles;    // fm_eval_kernel<2, .>: start delay of the second workgroup of every CU (0: none)
+  FmMala mala;           // fm_fwd_bwd_kernel<.., MALA = true> only
 };
 
 struct FmLds {           // float offsets into dynamic LDS
@@ -92,7 +103,10 @@ __device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf
 // with its dimensions, activation and target kind as compile-time constants -- loop bounds, tile counts and the LDS layout fold, the K loops
 // unroll; offsets into the parameter buffers stay the host's.  Same arithmetic as the generic instance (the compiler's multiply-add
 // contraction may differ in the last bits).
-template <int TPW, bool TRAIN, bool STATIC = false, int ACT = -1>      // ACT >= 0: the activation as a compile-time constant (the five-way
+// MALA: the workgroup first advances its 16 chains by one MALA step (two chains per wave, mala_chain_step: the arithmetic of
+// mala_step_kernel, bit for bit) and builds the batch from the new positions left in LDS -- one launch less per iteration, and
+// the positions do not travel through HBM between the two.
+template <int TPW, bool TRAIN, bool STATIC = false, int ACT = -1, bool MALA = false>      // ACT >= 0: the activation as a compile-time constant (the five-way
 __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs a) {      // run-time selection in every epilogue triples the code)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   NetDev nloc = a.net;
@@ -119,30 +133,69 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   FM_STAMP(0);
   // ---------------- prologue: K3 batch construction (exe_flow_matching.py:151-169 / :139-147) ----------------
   for (int i = threadIdx.x; i < 16 * L.ldx; i += (MLP_WAVES_FM * 64)) bX[i] = 0.f;      // pads (incl. x[-1], x[d..])
+  // draws produced ahead of time (noise.hip): every load of the tile is issued here, before the first use -- and before the MALA
+  // step, whose own HBM round trip they then share (behind the per-element `drawn ? load : threefry + erfinv` selection each
+  // load used to wait for the previous one: 24 HBM round trips)
+  const bool drawn = a.cond_flow && a.pre_x0;
+  double x0d[TPW][4], ned[TPW][4]; float x1f[TPW][4], tpre[4] = {0.f, 0.f, 0.f, 0.f};
+  auto issue_batch_loads = [&]() {
+    if (drawn) {
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const int nt = wave + MLP_WAVES_FM * q, col = nt * 16 + c;
+        const bool live = nt * 16 < n.dp && col < d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const size_t po = (size_t)(b0 + 4 * g + i) * d + (live ? col : 0);
+          x0d[q][i] = a.pre_x0[po]; ned[q][i] = a.pre_eps[po];
+          if constexpr (!MALA) x1f[q][i] = a.pos[po];
+        }
+      }
+    }
+    if (a.pre_t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tpre[i] = a.pre_t[b0 + 4 * g + i];
+    }
+  };
+  if constexpr (!MALA) issue_batch_loads();
+  if constexpr (MALA) {
+    // rows `wave` and `wave + 8` of the tile; their LDS rows live in the dv buffer (first written by the output layer's epilogue)
+    MalaArgs m;
+    m.T = n.T; m.T.dim = d; m.key = a.mala.key; m.keys = nullptr; m.n_total = a.n_total; m.chain_offset = a.chain_offset; m.B = a.B;
+    m.beta = a.mala.beta; m.eps = a.mala.eps; m.textbook = a.mala.textbook;
+    m.pos = const_cast<float*>(a.pos); m.logp = a.mala.logp; m.grad = a.mala.grad;
+    m.acc_prob = a.mala.acc_prob; m.accepted = nullptr; m.proposed = nullptr; m.prop_weight = nullptr;
+    m.pre_n = a.mala.pre_n; m.pre_u = a.mala.pre_u;
+    const int bs[2] = {b0 + wave, b0 + wave + 8};
+    float* const xs[2] = {bDV + wave * L.lddv + 4, bDV + (wave + 8) * L.lddv + 4};
+    float* const gsm[2] = {gcs + wave * 8, gcs + (wave + 8) * 8};
+    FM_STAMP(6);
+    mala_chain_step<2 * TPW, 2>(m, bs, xs, gsm, lane, issue_batch_loads);      // the batch's loads queue up behind the step's
+    FM_STAMP(7);
+  }
   __syncthreads();
+  FM_STAMP(8);
+  // x1 of (tile row, column): the chain's position -- from HBM, or what the MALA step above left in LDS
+  auto x1_at = [&](int row, int col) -> float { return MALA ? bDV[row * L.lddv + 4 + col] : a.pos[(size_t)(b0 + row) * d + col]; };
   float tt[4];
   Key2 kref[4];
   uint32_t bglob[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     bglob[i] = a.chain_offset + (uint32_t)(b0 + 4 * g + i);
-    if (a.pre_t) { tt[i] = a.pre_t[b0 + 4 * g + i]; kref[i] = Key2{0, 0}; continue; }
+    if (a.pre_t) { tt[i] = tpre[i]; kref[i] = Key2{0, 0}; continue; }
     tt[i] = (float)uniform01(a.key_time, bglob[i], a.n_total);                  // :154 / :142
     kref[i] = split_at(a.key_ref, a.n_total, bglob[i]);                         // :155
   }
   float tgt[TPW][4];
-  if (a.cond_flow && a.pre_x0) {
-    // draws produced ahead of time: issue every load of the tile before the first use (behind the per-element
-    // `drawn ? load : threefry + erfinv` selection below each load waited for the previous one: 24 HBM round trips)
-    float x1f[TPW][4]; double x0d[TPW][4], ned[TPW][4];
+  if (drawn) {
+    if constexpr (MALA) {
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-      const int nt = wave + MLP_WAVES_FM * q, col = nt * 16 + c;
-      const bool live = nt * 16 < n.dp && col < d;
+      for (int q = 0; q < TPW; ++q) {
+        const int nt = wave + MLP_WAVES_FM * q, col = nt * 16 + c;
+        const bool live = nt * 16 < n.dp && col < d;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const size_t po = (size_t)(b0 + 4 * g + i) * d + (live ? col : 0);
-        x1f[q][i] = a.pos[po]; x0d[q][i] = a.pre_x0[po]; ned[q][i] = a.pre_eps[po];
+        for (int i = 0; i < 4; ++i) x1f[q][i] = x1_at(4 * g + i, live ? col : 0);
       }
     }
 #pragma unroll
@@ -172,7 +225,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
       tgt[q][i] = 0.f;
       if (nt * 16 < n.dp && col < d) {
         const int row = 4 * g + i;
-        const double x1v = a.pos[(size_t)(b0 + row) * d + col];
+        const double x1v = x1_at(row, col);
         const double t = tt[i];
         double cnd, tg;
         if (a.cond_flow) {
@@ -851,6 +904,13 @@ static int fm_eval_rows(const NetDev& n, int B) {      // samples per workgroup 
 }
 int fm_eval_parts(const NetDev& n, int B) { const int r = fm_eval_rows(n, B); return r ? (B + r - 1) / r : B / 16; }
 
+// configurations whose MALA step can ride in the training kernel: the tile family's relu instances, targets whose value and
+// gradient one wave evaluates from its LDS row (phi-four, the mixtures; the Cox process needs the K^-1 GEMM)
+bool fm_mala_fusable(const NetDev& n) {
+  const int tpw = (n.dp / 16 + MLP_WAVES_FM - 1) / MLP_WAVES_FM;
+  return n.act == MFM_ACT_RELU && n.T.kind != MFM_TARGET_LGCP && tpw <= 2 && n.d <= 128 * tpw && (n.T.kind != MFM_TARGET_GMM || n.d <= MALA_MAXD_SMALL);
+}
+
 int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
   if (const int r = train ? 0 : fm_eval_rows(a.net, a.B)) {
     const size_t smr = (size_t)fm_eval_lds_layout(a.net, r).total * sizeof(float);
@@ -879,6 +939,11 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
     hipLaunchKernelGGL((fm_fwd_bwd_kernel<T, TR, false, ACT_>), grid, block, sm, stream, a);              \
   } while (0)
 #define FM_LAUNCH(T, TR) do { if (a.net.act == MFM_ACT_RELU) FM_LAUNCH_A(T, TR, MFM_ACT_RELU); else FM_LAUNCH_A(T, TR, -1); } while (0)
+#define FM_LAUNCH_M(T, STATIC_, ACT_)                                                                      \
+  do {                                                                                                     \
+    (void)hipFuncSetAttribute((const void*)fm_fwd_bwd_kernel<T, true, STATIC_, ACT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+    hipLaunchKernelGGL((fm_fwd_bwd_kernel<T, true, STATIC_, ACT_, true>), grid, block, sm, stream, a);    \
+  } while (0)
   const NetDev& n = a.net;
   bool headline = n.d == 256 && n.dp == 256 && n.F == 128 && n.F2p == 256 && n.ht1 == 128 && n.ht2 == 128 && n.hx1 == 128 &&
                   n.hx2 == 128 && n.hj1 == 128 && n.hj2 == 128 && n.T.kind == MFM_TARGET_PHI4 && n.act == MFM_ACT_RELU && !getenv("MFM_GENERIC_FM");
@@ -889,7 +954,10 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)fm_fwd_bwd_kernel<2, TR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
     hipLaunchKernelGGL((fm_fwd_bwd_kernel<2, TR, true>), grid, block, sm, stream, a);                     \
   } while (0)
-  if (headline) {
+  if (a.mala.on) {      // the iteration's MALA step in the same launch (callers ask fm_mala_fusable first)
+    if (!train || !fm_mala_fusable(n)) return -3;
+    if (headline) FM_LAUNCH_M(2, true, -1); else if (tpw <= 1) FM_LAUNCH_M(1, false, MFM_ACT_RELU); else FM_LAUNCH_M(2, false, MFM_ACT_RELU);
+  } else if (headline) {
     if (train) FM_LAUNCH_S(true); else FM_LAUNCH_S(false);
   } else if (train) {
     if (tpw <= 1) FM_LAUNCH(1, true); else if (tpw <= 2) FM_LAUNCH(2, true); else return -3;
@@ -897,6 +965,7 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
     if (tpw <= 1) FM_LAUNCH(1, false); else if (tpw <= 2) FM_LAUNCH(2, false); else return -3;
   }
 #undef FM_LAUNCH_S
+#undef FM_LAUNCH_M
 #undef FM_LAUNCH
 #undef FM_LAUNCH_A
   return 0;

@@ -130,88 +130,129 @@ __global__ __launch_bounds__(MALA_WAVES * 64) void loglik_kernel(MalaArgs a, dou
   if (lane == 0) out[b] = lp;
 }
 
+// One MALA step of the NCH chains b[0..NCH) by ONE wave (diffusions.py:19-34, mala.py:86-118, proposal.py:104-112,157-159,178-186).
+// xs[c]: the wave's LDS row for chain c (d floats, zero pads at [-1] and [d] written here); on return it holds the chain's NEW
+// position (proposal if accepted, the old position otherwise), which the fused MALA + training kernel (fm.hip) reads instead of
+// going back to HBM.  The chains of a wave are independent: their loads and float64 butterfly sums interleave.  Only the wave's
+// own lanes touch xs[c], so the staging needs no workgroup barrier.
+// `after_loads()` runs once the step's own loads are in flight and before their first use: a caller with loads of its own issues
+// them there, BEHIND these in the (in-order) memory queue, so that the step's data comes first and theirs arrives while it computes.
+struct MalaNoHook { __device__ __forceinline__ void operator()() const {} };
+template <int MAXIT, int NCH, typename Hook = MalaNoHook>
+__device__ __forceinline__ void mala_chain_step(const MalaArgs& a, const int (&b)[NCH], float* const (&xs)[NCH], float* const (&gsm)[NCH], int lane,
+                                                Hook after_loads = Hook()) {
+  // No multiply-add contraction in this function's own arithmetic: it is instantiated in two kernels (stand-alone, and inside the
+  // training kernel where unused outputs fold away), and whether `-(beta * S) + c * t` becomes one fused operation depended on how
+  // many uses beta * S had left -- acceptance probabilities differed in the last bit between the two at beta < 1.
+#pragma clang fp contract(off)
+  const int d = a.T.dim;
+  float x[NCH][MAXIT], g[NCH][MAXIT], xn[NCH][MAXIT];
+  double th1[NCH];                        // |x' - x - eps g|^2 = 2 eps |noise|^2
+  Key2 k_int[NCH], k_rmh[NCH];
+  const double s2e = sqrt(2.0 * a.eps);
+  double nz[NCH][MAXIT];                  // prefetched draws: all loads in flight before the first use
+  double lp0[NCH], u0[NCH];               // the accept step's two scalars: requested here, a whole HBM round trip before their use
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const size_t row = (size_t)b[c] * d;
+    th1[c] = 0.0; k_int[c] = Key2{0, 0}; k_rmh[c] = Key2{0, 0};
+    lp0[c] = a.logp[b[c]];
+    u0[c] = a.pre_u ? a.pre_u[b[c]] : 0.0;
+    if (lane == 0) { xs[c][-1] = 0.f; xs[c][d] = 0.f; }
+    if (!a.pre_n) {
+      const Key2 kb = a.keys ? Key2{a.keys[2 * b[c]], a.keys[2 * b[c] + 1]} : split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b[c]);     // exe_flow_matching.py:303
+      k_int[c] = split_at(kb, 2, 0);                                                 // mala.py:93
+      k_rmh[c] = split_at(kb, 2, 1);
+    } else {
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) { const int j = lane + 64 * it; nz[c][it] = j < d ? a.pre_n[row + j] : 0.0; }
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int j = lane + 64 * it;
+      if (j < d) { x[c][it] = a.pos[row + j]; g[c][it] = a.grad[row + j]; }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  after_loads();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int j = lane + 64 * it;
+      if (j < d) {
+        const double n = a.pre_n ? nz[c][it] : normal64(k_int[c], (uint32_t)j, (uint32_t)d);   // util.py:80-82
+        const double th = s2e * n;
+        th1[c] += th * th;
+        xn[c][it] = (float)((double)x[c][it] + a.eps * (double)g[c][it] + th);     // diffusions.py:25-30
+        xs[c][j] = xn[c][it];
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the stencil reads its neighbours' proposal elements from this wave's row
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  float gn[NCH][MAXIT];
+  double lpn[NCH], th2[NCH];              // th2 = |x - x' - eps g'|^2
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    lpn[c] = row_value_grad<MAXIT>(a.T, a.beta, xs[c], d, lane, gn[c], gsm[c]);    // diffusions.py:32
+    th2[c] = 0.0;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int j = lane + 64 * it;
+      if (j < d) {
+        const double t = (double)x[c][it] - (double)xn[c][it] - a.eps * (double)gn[c][it];
+        th2[c] += t * t;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { th1[c] = wave_sum(th1[c]); th2[c] = wave_sum(th2[c]); }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const size_t row = (size_t)b[c] * d;
+    const double lp = lp0[c];
+    const double inv4e = 0.25 / a.eps;
+    const double new_E = -lp + inv4e * th1[c];                                       // mala.py:68-79, proposal.py:157
+    const double prev_E = -lpn[c] + inv4e * th2[c];                                  // proposal.py:158
+    double delta = prev_E - new_E;                                                   // proposal.py:104
+    if (a.textbook) delta = -delta;
+    if (isnan(delta)) delta = -INFINITY;                                             // proposal.py:105
+    const double p = fmin(exp(delta), 1.0);                                          // proposal.py:178
+    const double u = a.pre_u ? u0[c] : uniform01(k_rmh[c], 0, 1);
+    const bool acc = u < p;                                                          // proposal.py:179
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int j = lane + 64 * it;
+      if (j < d) {
+        if (a.proposed) a.proposed[row + j] = xn[c][it];
+        if (acc) { a.pos[row + j] = xn[c][it]; a.grad[row + j] = gn[c][it]; }
+        else xs[c][j] = x[c][it];
+      }
+    }
+    if (lane == 0) {
+      if (acc) a.logp[b[c]] = lpn[c];
+      if (a.acc_prob) a.acc_prob[b[c]] = (float)p;
+      if (a.accepted) a.accepted[b[c]] = acc ? 1 : 0;
+      if (a.prop_weight) a.prop_weight[b[c]] = (float)exp(lpn[c] + inv4e * th2[c]);   // mala.py:104-113 (diagnostic)
+    }
+  }
+}
+
 template <int MAXIT>
 __global__ __launch_bounds__(MALA_WAVES * 64) void mala_step_kernel(MalaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int d = a.T.dim, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rowlen = d + 2;
-  float* xs = smem + wave * rowlen + 1;
-  float* gsm = smem + MALA_WAVES * rowlen + wave * MALA_MAXD_SMALL;
   const int b = blockIdx.x * MALA_WAVES + wave;
-  const bool live = b < a.B;
-  const size_t row = (size_t)b * d;
-
-  float x[MAXIT], g[MAXIT], xn[MAXIT];
-  double th1 = 0.0;                       // |x' - x - eps g|^2 = 2 eps |noise|^2
-  Key2 k_int = {0, 0}, k_rmh = {0, 0};
-  if (lane == 0) { xs[-1] = 0.f; xs[d] = 0.f; }
-  if (live) {
-    if (!a.pre_n) {
-      const Key2 kb = a.keys ? Key2{a.keys[2 * b], a.keys[2 * b + 1]} : split_at(a.key, a.n_total, a.chain_offset + (uint32_t)b);     // exe_flow_matching.py:303
-      k_int = split_at(kb, 2, 0);                                                    // mala.py:93
-      k_rmh = split_at(kb, 2, 1);
-    }
-    const double s2e = sqrt(2.0 * a.eps);
-    double nz[MAXIT];                      // prefetched draws: all loads in flight before the first use
-    if (a.pre_n) {
-#pragma unroll
-      for (int it = 0; it < MAXIT; ++it) { const int j = lane + 64 * it; nz[it] = j < d ? a.pre_n[row + j] : 0.0; }
-    }
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      int j = lane + 64 * it;
-      if (j < d) {
-        x[it] = a.pos[row + j];
-        g[it] = a.grad[row + j];
-        double n = a.pre_n ? nz[it] : normal64(k_int, (uint32_t)j, (uint32_t)d);   // util.py:80-82
-        double th = s2e * n;
-        th1 += th * th;
-        xn[it] = (float)((double)x[it] + a.eps * (double)g[it] + th);              // diffusions.py:25-30
-        xs[j] = xn[it];
-      }
-    }
-  }
-  __syncthreads();
-  if (!live) return;
-
-  float gn[MAXIT];
-  const double lpn = row_value_grad<MAXIT>(a.T, a.beta, xs, d, lane, gn, gsm);     // diffusions.py:32
-  double th2 = 0.0;                       // |x - x' - eps g'|^2
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    int j = lane + 64 * it;
-    if (j < d) {
-      double t = (double)x[it] - (double)xn[it] - a.eps * (double)gn[it];
-      th2 += t * t;
-    }
-  }
-  th1 = wave_sum(th1);
-  th2 = wave_sum(th2);
-  const double lp = a.logp[b];
-  const double inv4e = 0.25 / a.eps;
-  const double new_E = -lp + inv4e * th1;                                          // mala.py:68-79, proposal.py:157
-  const double prev_E = -lpn + inv4e * th2;                                        // proposal.py:158
-  double delta = prev_E - new_E;                                                   // proposal.py:104
-  if (a.textbook) delta = -delta;
-  if (isnan(delta)) delta = -INFINITY;                                             // proposal.py:105
-  const double p = fmin(exp(delta), 1.0);                                          // proposal.py:178
-  const double u = a.pre_u ? a.pre_u[b] : uniform01(k_rmh, 0, 1);
-  const bool acc = u < p;                                                          // proposal.py:179
-
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    int j = lane + 64 * it;
-    if (j < d) {
-      if (a.proposed) a.proposed[row + j] = xn[it];
-      if (acc) { a.pos[row + j] = xn[it]; a.grad[row + j] = gn[it]; }
-    }
-  }
-  if (lane == 0) {
-    if (acc) a.logp[b] = lpn;
-    if (a.acc_prob) a.acc_prob[b] = (float)p;
-    if (a.accepted) a.accepted[b] = acc ? 1 : 0;
-    if (a.prop_weight) a.prop_weight[b] = (float)exp(lpn + inv4e * th2);           // mala.py:104-113 (diagnostic)
-  }
+  if (b >= a.B) return;
+  const int bs[1] = {b};
+  float* const xs[1] = {smem + wave * rowlen + 1};
+  float* const gsm[1] = {smem + MALA_WAVES * rowlen + wave * MALA_MAXD_SMALL};
+  mala_chain_step<MAXIT, 1>(a, bs, xs, gsm, lane);
 }
 
 // ---- launchers (called from the C ABI in api.hip) ---------------------------------------------------------

@@ -32,19 +32,22 @@ struct TargetDev {
 
 // ---- PhiFour --------------------------------------------------------------------------------------
 // loglik terms of element j (to be summed over j): -beta (coef/2 (x_{j+1}-x_j)^2 [+ left edge] + (1-x^2)^2/(4 coef))
+// The multiply-adds are written as explicit fused operations: left to the compiler's contraction, the SAME source rounded
+// differently in two kernels that inline it (the MALA step stand-alone and inside the training kernel: gradients one float32 ulp
+// apart, acceptance probabilities 1e-6 apart).
 __device__ __forceinline__ float phi4_grad(const TargetDev& T, const float* xs, int j) {
   float x = xs[j];
   float lap = 2.f * x - xs[j - 1] - xs[j + 1];
-  return -T.tbeta * (T.coef * lap - x * (1.f - x * x) / T.coef);
+  return -T.tbeta * __builtin_fmaf(T.coef, lap, -(x * __builtin_fmaf(-x, x, 1.f) / T.coef));
 }
 __device__ __forceinline__ double phi4_term(const TargetDev& T, const float* xs, int j) {
   // each bond (j, j+1) counted once, plus the left boundary bond for j == 0
   double x = xs[j];
   double dr = (double)xs[j + 1] - x;
   double u = dr * dr;
-  if (j == 0) u += x * x;
-  double q = 1.0 - x * x;
-  return -(double)T.tbeta * (0.5 * (double)T.coef * u + q * q / (4.0 * (double)T.coef));
+  if (j == 0) u = __builtin_fma(x, x, u);
+  double q = __builtin_fma(-x, x, 1.0);
+  return -(double)T.tbeta * __builtin_fma(0.5 * (double)T.coef, u, q * q / (4.0 * (double)T.coef));
 }
 __device__ __forceinline__ float phi4_hvp(const TargetDev& T, const float* xs, const float* vs, int j) {
   float x = xs[j], v = vs[j];

@@ -232,6 +232,9 @@ def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
         return MALAState(pos, logp, grad)
 
     train_data_generator.info_buffers = info
+    # what run() needs to issue generator + train_step as ONE library call (mfm_train_iter) where that is the same computation
+    train_data_generator.flow_mode = mode
+    train_data_generator.one_call_ok = n_is <= 0 and args.mcmc_per_flow_steps >= 1 and float(args.mcmc_per_flow_steps).is_integer()
     return train_data_generator, init_fn, transform_and_logdet
 
 
@@ -338,6 +341,8 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     import os
     K_int = int(args.mcmc_per_flow_steps) if args.mcmc_per_flow_steps >= 1 else 0
     prefetch = K_int >= 1 and not use_real_samples and args.num_importance_samples <= 0 and not os.environ.get("MFM_NO_PREFETCH")
+    # one rank: generator + train_step in one call (more ranks keep them apart: the MALA step overlaps the gradient all-reduce)
+    one_call = (not use_real_samples and eng.world == 1 and not eng._split_calls and getattr(train_data_generator, "one_call_ok", False))
     for count in range(1, learning_iter + 1):                                               # :432
         key_sample, key_train_gn, key_train_step = jr.split(key_sample, 3)                  # :433
         if prefetch and count % (K_int + 1) == 0:
@@ -349,9 +354,18 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
                 kg.append(a_); kt.append(b_)
             if kg:
                 prefetch = eng.ctx.noise_prefetch(np.stack(kg), np.stack(kt))               # False: not served for this configuration
-        train_states, infos = train_data_generator(key_train_gn, train_states, count, state.params, beta)    # :438
         row = metrics[count - 1]                                                            # loss | sum acc | sum acc^2 | target loss
-        eng.train_step(key_train_step, train_states.position, loss_out=row[0:1])            # :439 (:362-368)
+        if one_call:
+            # :438-439 as one library call: on a MALA iteration the step runs inside the training kernel's workgroups (fm.hip)
+            _maybe_upload(eng, state.params)
+            ib = train_data_generator.info_buffers
+            eng.train_iter(count, K_int, train_data_generator.flow_mode, key_train_gn, key_train_step, beta, args.step_size,
+                           train_states.position, train_states.logdensity, train_states.logdensity_grad, acc=ib["acc"], nsteps=ib["nsteps"],
+                           loss_out=row[0:1])
+            infos = MALAInfo(ib["acc"], None, None, None)
+        else:
+            train_states, infos = train_data_generator(key_train_gn, train_states, count, state.params, beta)    # :438
+            eng.train_step(key_train_step, train_states.position, loss_out=row[0:1])        # :439 (:362-368)
         lrs.append(learning_rate_fn(count - 1))                                             # :367 (pre-increment step)
         if not use_real_samples and count % iter_per_temp == 0 and beta < 1.0:              # :440-441, :417
             beta = eng.ctx.beta_update(beta, eng.all_logliks(train_states.position), args.alpha)              # :413

@@ -61,11 +61,14 @@ def test_phi4_loop_matches_oracle():
     np.testing.assert_allclose(g[same].mean(0), o[same].mean(0), atol=5e-3)
     np.testing.assert_allclose((g[same] ** 2).mean(), (o[same] ** 2).mean(), rtol=2e-3)
     np.testing.assert_allclose(ex["states"].logdensity.cpu().numpy()[same].mean(), out["states"].logdensity[same].mean(), rtol=2e-3)
-    # parameters after 12 AdamW steps (a flipped chain changes 1/64 of the later batches: looser bound then)
+    # parameters after 12 AdamW steps (a flipped chain changes 1/64 of the later batches: looser bound then).  Adam's first
+    # updates are lr * g / |g|: a parameter whose gradient is within float32 rounding of zero moves by up to +- lr per step in
+    # either run, so the bound is a fraction of 12 lr, not a rounding bound (observed 3e-4 .. 6e-4 over builds whose target
+    # gradient differs in the last bit)
     from tests import gpu_util as gu
     po = gu.flat_params(out["state"].params)
     pg = ex["engine"].ctx.get_params()
-    assert np.abs(pg - po).max() < (5e-4 if not flipped.any() else 3e-3) * max(1.0, np.abs(po).max())
+    assert np.abs(pg - po).max() < (1e-3 if not flipped.any() else 3e-3) * max(1.0, np.abs(po).max())
     s = ex["engine"].ctx.opt_state()
     assert (s["step"], s["count"]) == (out["state"].step, out["state"].count)
     assert np.isfinite(res[0])
@@ -141,17 +144,55 @@ def test_run_with_noise_prefetch_is_bit_identical(monkeypatch):
     np.testing.assert_array_equal(out[0][2], out[1][2])
 
 
-def test_train_iter_equals_the_separate_calls():
-    """mfm_train_iter (generator :300-314 + train_step :362-368 in one call) against the same iterations composed from
-    mfm_mala_step / mfm_flow_step / mfm_fm_loss_grad / mfm_adamw_step: bit-identical chains, losses and parameters over a
-    schedule with a flow iteration in it (K = 3: counts 4 and 8 are flow steps)."""
+@pytest.mark.parametrize("example", ["phi-four", "4-mode"])
+def test_run_one_call_iterations_equal_the_separate_calls(monkeypatch, example):
+    """run() on one rank issues generator + train_step as one library call per iteration (mfm_train_iter: the MALA step inside the
+    training kernel); MFM_SPLIT_CALLS=1 keeps the multi-rank call sequence (mfm_mala_step / mfm_flow_step, mfm_fm_loss_grad,
+    mfm_adamw_step).  Same traces, chains and parameters, bit for bit -- with the draws prefetched by the flow step (phi-four,
+    headline shape) and drawn in line (4-mode)."""
+    from mfm_amd import distributions as D, exe_flow_matching as E
+    if example == "phi-four":
+        dist = D.PhiFour(256)
+        common = dict(example="phi-four", dim=256, num_chain=64, learning_iter=11, mcmc_per_flow_steps=3.0, hutchs=True, seed=7, eval_iter=1, step_size=1e-4)
+    else:
+        dist = D.GaussianMixture(8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4)
+        common = dict(example="4-mode", dim=2, num_chain=64, learning_iter=11, mcmc_per_flow_steps=3.0, hutchs=False, seed=7, eval_iter=2, step_size=0.2)
+    out = []
+    for split in (True, False):
+        if split:
+            monkeypatch.setenv("MFM_SPLIT_CALLS", "1")
+        else:
+            monkeypatch.delenv("MFM_SPLIT_CALLS")
+        res, res_, ex = E.run(dist, _args(**common), dist.sample_model if example == "4-mode" else None, log_every=1000, return_extras=True)
+        out.append((ex["metrics"].copy(), ex["states"].position.cpu().numpy().copy(), ex["engine"].ctx.get_params()))
+        ex["engine"].close()
+    assert np.isfinite(out[0][0][:, :3]).all()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("case", ["phi4_64", "phi4_256_headline", "gmm4", "gmm16"])
+def test_train_iter_equals_the_separate_calls(case):
+    """mfm_train_iter (generator :300-314 + train_step :362-368 in one call; its MALA step rides in the training kernel's
+    workgroups, fm.hip: fm_fwd_bwd_kernel<.., MALA>) against the same iterations composed from mfm_mala_step / mfm_flow_step /
+    mfm_fm_loss_grad / mfm_adamw_step: bit-identical chains, acceptance probabilities, losses and parameters over a schedule with
+    a flow iteration in it (K = 3: counts 4 and 8 are flow steps) -- on the generic tile, the headline's shape-specialised
+    instance and the 2-d mixtures (one mode per lane)."""
     import torch
     from oracle import prng
     from tests import gpu_util as gu
     from mfm_amd._lib import FLOW_RWMH, MfmError
-    args, dist, k, model, state = gu.phi4_setup(d=64, B=64, hidden=32, F=16, learning_iter=20)
+    if case == "phi4_64":
+        args, dist, k, model, state = gu.phi4_setup(d=64, B=64, hidden=32, F=16, learning_iter=20)
+    elif case == "phi4_256_headline":
+        args, dist, k, model, state = gu.phi4_setup(d=256, B=64, learning_iter=20)
+    elif case == "gmm4":
+        args, dist, k, model, state = gu.gmm4_setup(B=64, learning_iter=20)
+    else:
+        args, dist, k, model, state = gu.gmm16_setup(B=64, learning_iter=20)
     params = gu.rand_params(model, seed=3, out_scale=0.05)
-    x0 = dist.init_params.astype(np.float32)
+    x0 = dist.init_params.astype(np.float32) if hasattr(dist, "init_params") else np.random.default_rng(4).normal(size=(64, dist.dim)).astype(np.float32)
     K = 3
     out = []
     for fused in (False, True):
@@ -173,7 +214,8 @@ def test_train_iter_equals_the_separate_calls():
                 ctx.fm_loss_grad(kt, pos, loss, grads)
                 ctx.adamw_step(grads)
             losses.append(loss.item())
-        out.append((pos.cpu().numpy(), logp.cpu().numpy(), np.array(losses), ctx.get_params(), ctx.opt_state(), nst.cpu().numpy()))
+        out.append((pos.cpu().numpy(), logp.cpu().numpy(), np.array(losses), ctx.get_params(), ctx.opt_state(), nst.cpu().numpy(), grad.cpu().numpy(),
+                    acc.cpu().numpy()))
         if fused:
             with pytest.raises(MfmError, match="mcmc_per_flow_steps >= 1"):
                 ctx.train_iter(1, 0, FLOW_RWMH, kg, kt, 1.0, args.step_size, pos, logp, grad, loss, grads)

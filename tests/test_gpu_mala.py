@@ -137,7 +137,7 @@ def test_noise_prefetch_is_bit_identical_to_inline_draws():
     x32 = dist.init_params.astype(np.float32)
     keys = np.stack([prng.split(prng.PRNGKey(100 + i), 2) for i in range(6)]).astype(np.uint32)      # [6, 2, 2]: (gn, step) per iteration
     res = []
-    for prefetch in (False, True):
+    for prefetch, one_call in ((False, False), (True, False), (True, True), (False, True)):      # one_call: mfm_train_iter, its MALA step inside the training kernel
         ctx = gu.make_ctx(dist, args, n_local=B // 2, n_total=B, offset=B // 2, fourier=model.f, params=params)
         n = B // 2
         pos = torch.as_tensor(x32[n:]).cuda(); logp = torch.empty(n, dtype=torch.float64, device="cuda"); grad = torch.empty(n, d, device="cuda")
@@ -149,14 +149,18 @@ def test_noise_prefetch_is_bit_identical_to_inline_draws():
         loss = torch.zeros(1, dtype=torch.float64, device="cuda"); g = torch.zeros(ctx.n_params, device="cuda")
         tr = []
         for i in range(1, 6):
-            ctx.mala_step(keys[i, 0], 1.0, 1e-4, pos, logp, grad, acc)
-            ctx.fm_loss_grad(keys[i, 1], pos, loss, g)
+            if one_call:
+                ctx.train_iter(i, 100, _lib.FLOW_RWMH, keys[i, 0], keys[i, 1], 1.0, 1e-4, pos, logp, grad, loss, g, acc=acc, apply_update=False)
+            else:
+                ctx.mala_step(keys[i, 0], 1.0, 1e-4, pos, logp, grad, acc)
+                ctx.fm_loss_grad(keys[i, 1], pos, loss, g)
             tr.append((loss.item(), g.clone(), acc.clone()))
-        res.append((pos.clone(), logp.clone(), tr))
+        res.append((pos.clone(), logp.clone(), grad.clone(), tr))
         ctx.close()
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-    for (l0, g0, a0), (l1, g1, a1) in zip(res[0][2], res[1][2]):
-        assert l0 == l1 and torch.equal(g0, g1) and torch.equal(a0, a1)
+    for r in res[1:]:
+        assert torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) and torch.equal(res[0][2], r[2])
+        for (l0, g0, a0), (l1, g1, a1) in zip(res[0][3], r[3]):
+            assert l0 == l1 and torch.equal(g0, g1) and torch.equal(a0, a1)
 
 
 def test_acc_stats_kernel():

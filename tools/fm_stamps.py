@@ -14,9 +14,46 @@ loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(c
 buf = torch.zeros(256 * 32, dtype=torch.int64, device="cuda")
 ctx.lib.mfm_debug_fm_buffer.argtypes = [C.c_void_p]
 assert ctx.lib.mfm_debug_fm_buffer(C.c_void_p(buf.data_ptr())) == 0
+from mfm_amd import _lib
+key = prng.PRNGKey(1)
+if "--prefetch" in sys.argv:      # the benchmarked regime: the draws come from the buffer the preceding flow step filled (noise.hip)
+    logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+    ctx.mala_init(pos, 1.0, logp, grad)
+    acc = torch.empty(B, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
+    assert ctx.noise_prefetch(np.stack([prng.PRNGKey(7)]), np.stack([key]))
+    p2 = pos.clone()
+    ctx.flow_step(_lib.FLOW_RWMH, prng.PRNGKey(100), 1.0, p2, logp, grad, acc, None, None, ns)
+if "--mala" in sys.argv:            # mfm_train_iter: the MALA step inside the training kernel (stamps 6 / 7 / 8 around it)
+    if "--prefetch" not in sys.argv:
+        logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+        ctx.mala_init(pos, 1.0, logp, grad)
+        acc = torch.empty(B, device="cuda")
+    for _ in range(1 if "--prefetch" in sys.argv else 3):
+        ctx.train_iter(1, 100, _lib.FLOW_RWMH, prng.PRNGKey(7), key, 1.0, 1e-4, pos, logp, grad, loss, grads, acc=acc, apply_update=False)
+    torch.cuda.synchronize()
+    if "--fine" in sys.argv:       # a build with stamps 10..13 inside mala_chain_step
+        s = buf.cpu().numpy().reshape(256, 32).astype(np.float64)[:, [6, 10, 11, 12, 13, 7]]
+        for n, v in zip(["issue loads, keys", "proposal (waits for the loads)", "value + gradient at the proposal", "two float64 wave sums per chain", "accept + stores"], np.diff(s, axis=1).mean(0)):
+            print(f"{n:36s} {v:10.0f}")
+        sys.exit(0)
+    s = buf.cpu().numpy().reshape(256, 32).astype(np.float64)[:, [0, 6, 7, 8, 1, 2, 3, 4, 5]]
+    for n, v in zip(["zero pads + issue loads", "MALA step (wave 0)", "barrier", "batch construction", "fourier", "forward 7 layers", "out layer+loss", "backward 6 dgrads"],
+                    np.diff(s, axis=1).mean(0)):
+        print(f"{n:26s} {v:10.0f}")
+    print("total", (s[:, -1] - s[:, 0]).mean())
+    sys.exit(0)
 for _ in range(3):
-    ctx.fm_loss_grad(prng.PRNGKey(1), pos, loss, grads)
+    ctx.fm_loss_grad(key, pos, loss, grads)
 torch.cuda.synchronize()
+if "--fine" in sys.argv:           # a build whose every layer_gemm call and barrier is followed by a stamp (ids in program order below)
+    order = [0, 1, 2, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 3, 18, 19, 4, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 5]
+    what = ["prologue", "fourier", "-", "t1", "x1", "barrier", "t2", "x2", "barrier", "gate", "j1", "barrier", "j2", "barrier", "-", "out+loss",
+            "wave_sum+barrier", "loss write", "d j2", "barrier", "d j1", "barrier", "d cat", "barrier", "d st (gate)", "barrier", "d x1", "d t1", "-"]
+    s = buf.cpu().numpy().reshape(256, 32).astype(np.float64)[:, order]
+    for n, v in zip(what, np.diff(s, axis=1).mean(0)):
+        print(f"{n:20s} {v:9.0f}")
+    print("total", (s[:, -1] - s[:, 0]).mean())
+    sys.exit(0)
 s = buf.cpu().numpy().reshape(256, 32)[:, :6].astype(np.float64)
 dlt = np.diff(s, axis=1)
 names = ["prologue draws+cond", "fourier+gmm", "forward 7 layers", "out layer+loss", "backward 6 dgrads"]
