@@ -85,9 +85,30 @@ __host__ __device__ inline FmLds fm_lds_layout(const NetDev& n, bool train) {
   return L;
 }
 
+// Streaming stores: the packed activations (44 MB per training step at the headline shape) are read next by ANOTHER kernel; written
+// with the default policy they push the network's weights out of the XCD's 4 MB L2 while this kernel is still reading them.
 __device__ __forceinline__ void store_packed(float* base, int tile_row, int nbb, int bb, int lane, f32x4 v) {
-  reinterpret_cast<f32x4*>(base)[((size_t)tile_row * nbb + bb) * 64 + lane] = v;
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base) + ((size_t)tile_row * nbb + bb) * 64 + lane);
 }
+
+// Pull the network's packed weights (forward and transposed copies) into this XCD's L2 ahead of the layers.  The training kernel
+// reads every weight fragment exactly once per workgroup, all workgroups at about the same time, right after the optimizer
+// rewrote the weights: without this every tile's FIRST fragment group is an L2 miss the whole XCD waits for (1.5 - 2.3 k cycles
+// per tile, 17 tiles: tools/fm_stamps.py --lg).  Workgroup b runs on XCD b % 8; the workgroups of an XCD share out the 128-byte
+// lines, one dword load per line and thread, issued behind the prologue's own loads and never waited for on their own.
+struct L2Warm { float v[4]; };
+__device__ __forceinline__ L2Warm l2_warm_issue(const NetDev& n) {
+  L2Warm w = {{0.f, 0.f, 0.f, 0.f}};
+  const int slot = blockIdx.x >> 3, nslots = (gridDim.x + 7) >> 3, lines = (n.n_packed * 4 + 127) >> 7;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {          // two lines of each copy per thread: the whole network once the XCD has >= 13 workgroups
+    const int l = (u * nslots + slot) * (MLP_WAVES_FM * 64) + threadIdx.x;
+    if (l < lines) { w.v[2 * u] = n.Wp[(size_t)l * 32]; w.v[2 * u + 1] = n.WpT[(size_t)l * 32]; }
+  }
+  return w;
+}
+// the loads only have to have been ISSUED; this keeps them alive until a point where the wave waits for memory anyway
+__device__ __forceinline__ void l2_warm_retire(const L2Warm& w) { asm volatile("" :: "v"(w.v[0]), "v"(w.v[1]), "v"(w.v[2]), "v"(w.v[3])); }
 
 // grad log pi(x)[row][col], clipped, for the tile whose positions sit in LDS `xrow0` (row stride ldx, data at +4)
 __device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf, int ldx, const float* gcs, const float* gcl, int ldg,
@@ -130,6 +151,16 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   float* bDV = lds + L.dv;  float* bD1 = lds + L.d1; float* bD2 = lds + L.d2; float* bDC = lds + L.dcat;
   float* gcs = lds + L.gcs; double* red = reinterpret_cast<double*>(lds + L.red); float* bGC = lds + L.gc;
 
+  WChain wch; wch.have = false;
+#ifndef MFM_NO_CHAIN
+  if constexpr (STATIC) {      // the first tile's first fragment group: requested before everything else, it arrives under the prologue
+    const __amdgpu_buffer_rsrc_t w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(n.Wp + n.L[0].w_off) + (size_t)wave * (n.L[0].Kp / 16) * 256, 0,
+                                                                        (n.L[0].Kp / 16) * 1024, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wch.b[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w0, lane * 16, u * 1024, 0));
+    wch.have = true;
+  }
+#endif
   FM_STAMP(0);
   // ---------------- prologue: K3 batch construction (exe_flow_matching.py:151-169 / :139-147) ----------------
   for (int i = threadIdx.x; i < 16 * L.ldx; i += (MLP_WAVES_FM * 64)) bX[i] = 0.f;      // pads (incl. x[-1], x[d..])
@@ -138,6 +169,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   // load used to wait for the previous one: 24 HBM round trips)
   const bool drawn = a.cond_flow && a.pre_x0;
   double x0d[TPW][4], ned[TPW][4]; float x1f[TPW][4], tpre[4] = {0.f, 0.f, 0.f, 0.f};
+  L2Warm warm = {{0.f, 0.f, 0.f, 0.f}};
   auto issue_batch_loads = [&]() {
     if (drawn) {
 #pragma unroll
@@ -156,6 +188,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
 #pragma unroll
       for (int i = 0; i < 4; ++i) tpre[i] = a.pre_t[b0 + 4 * g + i];
     }
+    if (TRAIN) warm = l2_warm_issue(n);
   };
   if constexpr (!MALA) issue_batch_loads();
   if constexpr (MALA) {
@@ -247,6 +280,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     }
     if (TRAIN && nt * 16 < n.dp) store_packed(a.acts, a.ws.a_cond + nt, nbb, bb, lane, cv);
   }
+  if (TRAIN) l2_warm_retire(warm);
   FM_STAMP(1);
   // Fourier features of t (:70-71): cos block then sin block
   if (n.F % 16 == 0) {          // tile-aligned halves: one sincos per (row, frequency) feeds both
@@ -320,6 +354,17 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
       }
     };
   };
+  // the network's 14 layer GEMMs: on the headline shape with the weight stream chained from tile to tile (mlp.cuh: layer_gemm_chain)
+  auto LG = [&](const float* A, int lda, const float* W, const float* bias, int KB, int NT, auto epi, const float* Wnext, int KBnext) {
+#ifdef MFM_NO_CHAIN
+    if constexpr (false)
+#else
+    if constexpr (STATIC)
+#endif
+      layer_gemm_chain<1, MLP_WAVES_FM>(A, lda, W, bias, KB, NT, wave, lane, epi, wch, WNext{Wnext ? Wnext + (size_t)wave * KBnext * 256 : nullptr, KBnext});
+    else
+      layer_gemm<1, MLP_WAVES_FM>(A, lda, W, bias, KB, NT, wave, lane, epi);
+  };
   if (n.T.kind == MFM_TARGET_LGCP)      // grad log pi(cond) = c - a exp(cond) - K^-1 (cond - mu)
     layer_gemm<1, MLP_WAVES_FM>(bX + 4, L.ldx, n.T.KinvP, n.T.kbias, n.dp / 16, n.dp / 16, wave, lane,
                                 [&](int q, int nt, int m, f32x4 acc, float kb) {
@@ -331,31 +376,31 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                                     bGC[row * L.ldg + col] = col < d ? n.T.counts[col] - n.T.poisson_a * expf(xv) - (acc[i] + kb) : 0.f;
                                   }
                                 });
-  layer_gemm<1, MLP_WAVES_FM>(bFF, L.ldff, n.Wp + n.L[0].w_off, n.bias + n.L[0].b_off, n.L[0].Kp / 16, n.L[0].Np / 16, wave, lane,
-                   relu_store(n.L[0], bT1, L.ldt1, 0, a.ws.a_t1));
-  layer_gemm<1, MLP_WAVES_FM>(bX + 4, L.ldx, n.Wp + n.L[2].w_off, n.bias + n.L[2].b_off, n.L[2].Kp / 16, n.L[2].Np / 16, wave, lane,
-                   relu_store(n.L[2], bX1, L.ldx1, 0, a.ws.a_x1));
+  LG(bFF, L.ldff, n.Wp + n.L[0].w_off, n.bias + n.L[0].b_off, n.L[0].Kp / 16, n.L[0].Np / 16,
+                   relu_store(n.L[0], bT1, L.ldt1, 0, a.ws.a_t1), n.Wp + n.L[2].w_off, n.L[2].Kp / 16);
+  LG(bX + 4, L.ldx, n.Wp + n.L[2].w_off, n.bias + n.L[2].b_off, n.L[2].Kp / 16, n.L[2].Np / 16,
+                   relu_store(n.L[2], bX1, L.ldx1, 0, a.ws.a_x1), n.Wp + n.L[1].w_off, n.L[1].Kp / 16);
   __syncthreads();
-  layer_gemm<1, MLP_WAVES_FM>(bT1, L.ldt1, n.Wp + n.L[1].w_off, n.bias + n.L[1].b_off, n.L[1].Kp / 16, n.L[1].Np / 16, wave, lane,
-                   relu_store(n.L[1], bCat, L.ldcat, n.hx2, a.ws.a_st));
-  layer_gemm<1, MLP_WAVES_FM>(bX1, L.ldx1, n.Wp + n.L[3].w_off, n.bias + n.L[3].b_off, n.L[3].Kp / 16, n.L[3].Np / 16, wave, lane,
-                   relu_store(n.L[3], bCat, L.ldcat, 0, a.ws.a_sx));
+  LG(bT1, L.ldt1, n.Wp + n.L[1].w_off, n.bias + n.L[1].b_off, n.L[1].Kp / 16, n.L[1].Np / 16,
+                   relu_store(n.L[1], bCat, L.ldcat, n.hx2, a.ws.a_st), n.Wp + n.L[3].w_off, n.L[3].Kp / 16);
+  LG(bX1, L.ldx1, n.Wp + n.L[3].w_off, n.bias + n.L[3].b_off, n.L[3].Kp / 16, n.L[3].Np / 16,
+                   relu_store(n.L[3], bCat, L.ldcat, 0, a.ws.a_sx), n.Wp + n.L[4].w_off, n.L[4].Kp / 16);
   __syncthreads();
-  layer_gemm<1, MLP_WAVES_FM>(bCat + n.hx2, L.ldcat, n.Wp + n.L[4].w_off, n.bias + n.L[4].b_off, n.L[4].Kp / 16, n.L[4].Np / 16, wave, lane,
+  LG(bCat + n.hx2, L.ldcat, n.Wp + n.L[4].w_off, n.bias + n.L[4].b_off, n.L[4].Kp / 16, n.L[4].Np / 16,
                    [&](int q, int nt, int m, f32x4 acc, float bias) {
 #pragma unroll
                      for (int i = 0; i < 4; ++i) bG[(4 * g + i) * L.ldg + nt * 16 + c] = acc[i] + bias;
-                   });
-  layer_gemm<1, MLP_WAVES_FM>(bCat, L.ldcat, n.Wp + n.L[5].w_off, n.bias + n.L[5].b_off, n.L[5].Kp / 16, n.L[5].Np / 16, wave, lane,
-                   relu_store(n.L[5], bJ1, L.ldj1, 0, a.ws.a_j1));
+                   }, n.Wp + n.L[5].w_off, n.L[5].Kp / 16);
+  LG(bCat, L.ldcat, n.Wp + n.L[5].w_off, n.bias + n.L[5].b_off, n.L[5].Kp / 16, n.L[5].Np / 16,
+                   relu_store(n.L[5], bJ1, L.ldj1, 0, a.ws.a_j1), n.Wp + n.L[6].w_off, n.L[6].Kp / 16);
   __syncthreads();
-  layer_gemm<1, MLP_WAVES_FM>(bJ1, L.ldj1, n.Wp + n.L[6].w_off, n.bias + n.L[6].b_off, n.L[6].Kp / 16, n.L[6].Np / 16, wave, lane,
-                   relu_store(n.L[6], bJ2, L.ldj2, 0, a.ws.a_j2));
+  LG(bJ1, L.ldj1, n.Wp + n.L[6].w_off, n.bias + n.L[6].b_off, n.L[6].Kp / 16, n.L[6].Np / 16,
+                   relu_store(n.L[6], bJ2, L.ldj2, 0, a.ws.a_j2), n.Wp + n.L[7].w_off, n.L[7].Kp / 16);
   __syncthreads();
   FM_STAMP(3);
   // output layer + loss (:88-90, :177-178); dv = 2 (v - target), dgate = dv * clip(grad log pi)
   float loss_loc = 0.f;
-  layer_gemm<1, MLP_WAVES_FM>(bJ2, L.ldj2, n.Wp + n.L[7].w_off, n.bias + n.L[7].b_off, n.L[7].Kp / 16, n.L[7].Np / 16, wave, lane,
+  LG(bJ2, L.ldj2, n.Wp + n.L[7].w_off, n.bias + n.L[7].b_off, n.L[7].Kp / 16, n.L[7].Np / 16,
                    [&](int q, int nt, int m, f32x4 acc, float bias) {
                      const int col = nt * 16 + c;
                      f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f};
@@ -380,7 +425,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                        store_packed(a.dzs, a.ws.z_out + nt, nbb, bb, lane, dv);
                        store_packed(a.dzs, a.ws.z_gate + nt, nbb, bb, lane, dg);
                      }
-                   });
+                   }, TRAIN ? n.WpT + n.L[7].w_off : nullptr, n.L[7].Np / 16);
   {
     double lw = wave_sum((double)loss_loc);
     if (lane == 0) red[wave] = lw;
@@ -402,7 +447,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     return n.act >= MFM_ACT_GELU ? reinterpret_cast<const f32x4*>(a.dacts)[((size_t)(a_tile + nt) * nbb + bb) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   // d j2
-  layer_gemm<1, MLP_WAVES_FM>(bDV, L.lddv, n.WpT + n.L[7].w_off, nullptr, n.L[7].Np / 16, n.L[7].Kp / 16, wave, lane,
+  LG(bDV, L.lddv, n.WpT + n.L[7].w_off, nullptr, n.L[7].Np / 16, n.L[7].Kp / 16,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
                      const f32x4 dd = dload(a.ws.a_j2, nt);
@@ -413,10 +458,10 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                        bD1[row * L.ldd1 + col] = z[i];
                      }
                      store_packed(a.dzs, a.ws.z_j2 + nt, nbb, bb, lane, z);
-                   });
+                   }, n.WpT + n.L[6].w_off, n.L[6].Np / 16);
   __syncthreads();
   // d j1
-  layer_gemm<1, MLP_WAVES_FM>(bD1, L.ldd1, n.WpT + n.L[6].w_off, nullptr, n.L[6].Np / 16, n.L[6].Kp / 16, wave, lane,
+  LG(bD1, L.ldd1, n.WpT + n.L[6].w_off, nullptr, n.L[6].Np / 16, n.L[6].Kp / 16,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
                      const f32x4 dd = dload(a.ws.a_j1, nt);
@@ -427,10 +472,10 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                        bD2[row * L.ldd2 + col] = z[i];
                      }
                      store_packed(a.dzs, a.ws.z_j1 + nt, nbb, bb, lane, z);
-                   });
+                   }, n.WpT + n.L[5].w_off, n.L[5].Np / 16);
   __syncthreads();
   // d [sx | st] through j1; the sx half is finished here (-> dz of x2), the st half waits for the gate path
-  layer_gemm<1, MLP_WAVES_FM>(bD2, L.ldd2, n.WpT + n.L[5].w_off, nullptr, n.L[5].Np / 16, n.L[5].Kp / 16, wave, lane,
+  LG(bD2, L.ldd2, n.WpT + n.L[5].w_off, nullptr, n.L[5].Np / 16, n.L[5].Kp / 16,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      const int col = nt * 16 + c;
                      const bool is_sx = col < n.hx2;
@@ -443,10 +488,10 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                        bDC[row * L.ldcat + col] = z[i];
                      }
                      if (is_sx) store_packed(a.dzs, a.ws.z_x2 + nt, nbb, bb, lane, z);
-                   });
+                   }, n.WpT + n.L[4].w_off, n.L[4].Np / 16);
   __syncthreads();
   // d st += dgate . W_gate^T ; then relu mask -> dz of t2
-  layer_gemm<1, MLP_WAVES_FM>(bG, L.ldg, n.WpT + n.L[4].w_off, nullptr, n.L[4].Np / 16, n.L[4].Kp / 16, wave, lane,
+  LG(bG, L.ldg, n.WpT + n.L[4].w_off, nullptr, n.L[4].Np / 16, n.L[4].Kp / 16,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
                      const f32x4 dd = dload(a.ws.a_st, nt);
@@ -458,25 +503,25 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                        bDC[row * L.ldcat + col] = z[i];
                      }
                      store_packed(a.dzs, a.ws.z_t2 + nt, nbb, bb, lane, z);
-                   });
+                   }, n.WpT + n.L[3].w_off, n.L[3].Np / 16);
   __syncthreads();
   // d x1 (only needed by wgrad) and d t1
-  layer_gemm<1, MLP_WAVES_FM>(bDC, L.ldcat, n.WpT + n.L[3].w_off, nullptr, n.L[3].Np / 16, n.L[3].Kp / 16, wave, lane,
+  LG(bDC, L.ldcat, n.WpT + n.L[3].w_off, nullptr, n.L[3].Np / 16, n.L[3].Kp / 16,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
                      const f32x4 dd = dload(a.ws.a_x1, nt);
 #pragma unroll
                      for (int i = 0; i < 4; ++i) z[i] = dmask(bX1[(4 * g + i) * L.ldx1 + nt * 16 + c], acc[i], dd, i);
                      store_packed(a.dzs, a.ws.z_x1 + nt, nbb, bb, lane, z);
-                   });
-  layer_gemm<1, MLP_WAVES_FM>(bDC + n.hx2, L.ldcat, n.WpT + n.L[1].w_off, nullptr, n.L[1].Np / 16, n.L[1].Kp / 16, wave, lane,
+                   }, n.WpT + n.L[1].w_off, n.L[1].Np / 16);
+  LG(bDC + n.hx2, L.ldcat, n.WpT + n.L[1].w_off, nullptr, n.L[1].Np / 16, n.L[1].Kp / 16,
                    [&](int q, int nt, int m, f32x4 acc, float) {
                      f32x4 z;
                      const f32x4 dd = dload(a.ws.a_t1, nt);
 #pragma unroll
                      for (int i = 0; i < 4; ++i) z[i] = dmask(bT1[(4 * g + i) * L.ldt1 + nt * 16 + c], acc[i], dd, i);
                      store_packed(a.dzs, a.ws.z_t1 + nt, nbb, bb, lane, z);
-                   });
+                   }, nullptr, 0);
   FM_STAMP(5);
 }
 

@@ -205,5 +205,75 @@ __device__ __forceinline__ void layer_gemm(const float* A, int lda, const float*
   }
 }
 
+// ---- the same tile GEMM with the weight stream CHAINED across tiles, layers and barriers -------------------------------------
+// A workgroup's eight waves start every tile together, right after a barrier, and each asks for its first two fragment groups
+// (8 KB per wave, 64 KB per CU) at once: the CU's 64 B/clk vector L1 needs ~1,000 cycles to deliver them, on top of the L2
+// latency, and nothing can be multiplied meanwhile -- 1.3 - 1.6 k cycles per tile against 2.0 - 4.1 k cycles of MFMAs
+// (tools/fm_stamps.py --lg).  Here the first group of the NEXT tile is requested while the LAST group of the current tile is
+// being multiplied (its register set is free by then), so it streams in under those MFMAs, the epilogue and the barrier.
+// Requires an even number of 4-k-block groups per tile (K a multiple of 128) and NT >= NW.  `nx`: the packed fragments of the
+// tile this wave processes after the call (null: none); `ch` carries the requested group from call to call.
+struct WNext { const float* tile; int KB; };
+struct WChain { f32x4 b[4]; bool have; };
+template <int MT, int NW, typename Epi>
+__device__ __forceinline__ void layer_gemm_chain(const float* A, int lda, const float* __restrict__ Wp_, const float* __restrict__ bias,
+                                                 int KB, int NT, int wave, int lane, Epi epi, WChain& ch, WNext nx) {
+  const int r = lane & 15, g = lane >> 4;
+  const float* arow = A + r * lda + 4 * g;
+  const int wvo = lane * 16;
+  auto desc = [](const float* base, int kb) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, __builtin_amdgcn_readfirstlane(kb) * 1024, 0x00020000);
+  };
+  for (int q = 0; wave + NW * q < NT; ++q) {
+    const int nt = __builtin_amdgcn_readfirstlane(wave + NW * q), kb_s = __builtin_amdgcn_readfirstlane(KB);
+    const bool more = nt + NW < NT;
+    const float* ntile = more ? Wp_ + (size_t)(nt + NW) * kb_s * 256 : nx.tile;
+    const __amdgpu_buffer_rsrc_t wr = desc(Wp_ + (size_t)nt * kb_s * 256, kb_s);
+    const __amdgpu_buffer_rsrc_t wn = desc(ntile ? ntile : Wp_, more ? kb_s : nx.KB);
+    auto wload = [&](__amdgpu_buffer_rsrc_t d, int kb) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d, wvo, kb * 1024, 0)); };
+    const float bv = bias ? bias[nt * 16 + (lane & 15)] : 0.f;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto group = [&](const f32x4 (&bf)[4], int kb0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(arow + m * 16 * lda + (kb0 + u) * 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], bf[u][s], acc[m], 0, 0, 0);
+      }
+    };
+    const int KG = KB >> 2;                 // even
+    f32x4 bb[4];
+    if (!ch.have) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ch.b[u] = wload(wr, u);
+    }
+    for (int gi = 0; gi < KG; gi += 2) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bb[u] = wload(wr, 4 * gi + 4 + u);
+      __builtin_amdgcn_sched_barrier(0);
+      group(ch.b, 4 * gi);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gi + 2 < KG) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ch.b[u] = wload(wr, 4 * gi + 8 + u);
+      } else if (ntile) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ch.b[u] = wload(wn, u);      // the next tile's first group
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      group(bb, 4 * gi + 4);
+    }
+    ch.have = ntile != nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) epi(q, nt, m, acc[m], bv);
+  }
+}
+
 // ---- grad log pi of the (untempered) target on an LDS row with zero pads, clipped ----------------------------
 __device__ __forceinline__ float clipf(float v, float c) { return c > 0.f ? fminf(fmaxf(v, -c), c) : v; }
