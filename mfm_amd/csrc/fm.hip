@@ -86,29 +86,13 @@ __host__ __device__ inline FmLds fm_lds_layout(const NetDev& n, bool train) {
 }
 
 // Streaming stores: the packed activations (44 MB per training step at the headline shape) are read next by ANOTHER kernel; written
-// with the default policy they push the network's weights out of the XCD's 4 MB L2 while this kernel is still reading them.
+// with the default policy they push the network's weights out of the XCD's 4 MB L2 while this kernel is still reading them
+// (rocprofv3, 440 launches each: training kernel 46.8 -> 45.0 us, the weight-gradient kernel that reads them 26.0 -> 26.5 us).
+// Measured and dropped next to it: pulling the weights into each XCD's L2 at kernel start (one dword per 128-byte line, shared
+// out over the XCD's workgroups): 44.6 us without against 45.0 with.
 __device__ __forceinline__ void store_packed(float* base, int tile_row, int nbb, int bb, int lane, f32x4 v) {
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base) + ((size_t)tile_row * nbb + bb) * 64 + lane);
 }
-
-// Pull the network's packed weights (forward and transposed copies) into this XCD's L2 ahead of the layers.  The training kernel
-// reads every weight fragment exactly once per workgroup, all workgroups at about the same time, right after the optimizer
-// rewrote the weights: without this every tile's FIRST fragment group is an L2 miss the whole XCD waits for (1.5 - 2.3 k cycles
-// per tile, 17 tiles: tools/fm_stamps.py --lg).  Workgroup b runs on XCD b % 8; the workgroups of an XCD share out the 128-byte
-// lines, one dword load per line and thread, issued behind the prologue's own loads and never waited for on their own.
-struct L2Warm { float v[4]; };
-__device__ __forceinline__ L2Warm l2_warm_issue(const NetDev& n) {
-  L2Warm w = {{0.f, 0.f, 0.f, 0.f}};
-  const int slot = blockIdx.x >> 3, nslots = (gridDim.x + 7) >> 3, lines = (n.n_packed * 4 + 127) >> 7;
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {          // two lines of each copy per thread: the whole network once the XCD has >= 13 workgroups
-    const int l = (u * nslots + slot) * (MLP_WAVES_FM * 64) + threadIdx.x;
-    if (l < lines) { w.v[2 * u] = n.Wp[(size_t)l * 32]; w.v[2 * u + 1] = n.WpT[(size_t)l * 32]; }
-  }
-  return w;
-}
-// the loads only have to have been ISSUED; this keeps them alive until a point where the wave waits for memory anyway
-__device__ __forceinline__ void l2_warm_retire(const L2Warm& w) { asm volatile("" :: "v"(w.v[0]), "v"(w.v[1]), "v"(w.v[2]), "v"(w.v[3])); }
 
 // grad log pi(x)[row][col], clipped, for the tile whose positions sit in LDS `xrow0` (row stride ldx, data at +4)
 __device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf, int ldx, const float* gcs, const float* gcl, int ldg,
@@ -152,7 +136,6 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   float* gcs = lds + L.gcs; double* red = reinterpret_cast<double*>(lds + L.red); float* bGC = lds + L.gc;
 
   WChain wch; wch.have = false;
-#ifndef MFM_NO_CHAIN
   if constexpr (STATIC) {      // the first tile's first fragment group: requested before everything else, it arrives under the prologue
     const __amdgpu_buffer_rsrc_t w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(n.Wp + n.L[0].w_off) + (size_t)wave * (n.L[0].Kp / 16) * 256, 0,
                                                                         (n.L[0].Kp / 16) * 1024, 0x00020000);
@@ -160,7 +143,6 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     for (int u = 0; u < 4; ++u) wch.b[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w0, lane * 16, u * 1024, 0));
     wch.have = true;
   }
-#endif
   FM_STAMP(0);
   // ---------------- prologue: K3 batch construction (exe_flow_matching.py:151-169 / :139-147) ----------------
   for (int i = threadIdx.x; i < 16 * L.ldx; i += (MLP_WAVES_FM * 64)) bX[i] = 0.f;      // pads (incl. x[-1], x[d..])
@@ -169,7 +151,6 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   // load used to wait for the previous one: 24 HBM round trips)
   const bool drawn = a.cond_flow && a.pre_x0;
   double x0d[TPW][4], ned[TPW][4]; float x1f[TPW][4], tpre[4] = {0.f, 0.f, 0.f, 0.f};
-  L2Warm warm = {{0.f, 0.f, 0.f, 0.f}};
   auto issue_batch_loads = [&]() {
     if (drawn) {
 #pragma unroll
@@ -188,7 +169,6 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
 #pragma unroll
       for (int i = 0; i < 4; ++i) tpre[i] = a.pre_t[b0 + 4 * g + i];
     }
-    if (TRAIN) warm = l2_warm_issue(n);
   };
   if constexpr (!MALA) issue_batch_loads();
   if constexpr (MALA) {
@@ -280,7 +260,6 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     }
     if (TRAIN && nt * 16 < n.dp) store_packed(a.acts, a.ws.a_cond + nt, nbb, bb, lane, cv);
   }
-  if (TRAIN) l2_warm_retire(warm);
   FM_STAMP(1);
   // Fourier features of t (:70-71): cos block then sin block
   if (n.F % 16 == 0) {          // tile-aligned halves: one sincos per (row, frequency) feeds both
@@ -356,11 +335,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   };
   // the network's 14 layer GEMMs: on the headline shape with the weight stream chained from tile to tile (mlp.cuh: layer_gemm_chain)
   auto LG = [&](const float* A, int lda, const float* W, const float* bias, int KB, int NT, auto epi, const float* Wnext, int KBnext) {
-#ifdef MFM_NO_CHAIN
-    if constexpr (false)
-#else
     if constexpr (STATIC)
-#endif
       layer_gemm_chain<1, MLP_WAVES_FM>(A, lda, W, bias, KB, NT, wave, lane, epi, wch, WNext{Wnext ? Wnext + (size_t)wave * KBnext * 256 : nullptr, KBnext});
     else
       layer_gemm<1, MLP_WAVES_FM>(A, lda, W, bias, KB, NT, wave, lane, epi);
