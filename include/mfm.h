@@ -166,7 +166,10 @@ int mfm_flow_step(mfm_ctx* ctx, int mode, uint32_t key0, uint32_t key1, double b
  * (mcmc_per_flow_steps >= 1; the fractional / negative schedules of :304-310 are composed by the host from the separate
  * entry points), then loss and gradient on the NEW positions and, with apply_update != 0, the optimizer step.  A
  * multi-GPU host passes apply_update = 0, all-reduces d_grads (SUM) and calls mfm_adamw_step itself.  d_acceptance_rate
- * and d_nsteps may be NULL; d_nsteps is written by flow iterations only.  Returns MFM_OK or the first failing step's status. */
+ * and d_nsteps may be NULL; d_nsteps is written by flow iterations only.  Returns MFM_OK or the first failing step's status.
+ * On a MALA iteration of a phi-four target (relu network on the tile family) the step runs INSIDE the training kernel's workgroups
+ * -- the arithmetic and draws of mfm_mala_step, bit for bit, one launch less (MFM_NO_FUSED_MALA=1 in the environment keeps the
+ * two launches). */
 int mfm_train_iter(mfm_ctx* ctx, int64_t count, int mcmc_per_flow_steps, int flow_mode,
                    uint32_t gen_key0, uint32_t gen_key1, uint32_t train_key0, uint32_t train_key1,
                    double beta, double step_size, float* d_pos, double* d_logp, float* d_grad,

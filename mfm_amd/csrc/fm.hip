@@ -924,11 +924,14 @@ static int fm_eval_rows(const NetDev& n, int B) {      // samples per workgroup 
 }
 int fm_eval_parts(const NetDev& n, int B) { const int r = fm_eval_rows(n, B); return r ? (B + r - 1) / r : B / 16; }
 
-// configurations whose MALA step can ride in the training kernel: the tile family's relu instances, targets whose value and
-// gradient one wave evaluates from its LDS row (phi-four, the mixtures; the Cox process needs the K^-1 GEMM)
+// configurations whose MALA step rides in the training kernel: the tile family's relu instances on the phi-four target, whose
+// value and gradient one wave evaluates from its LDS row (rocprofv3 at the headline shape: 42.6 + 9.3 us as two kernels, 45.0 us
+// as one).  The 2-d mixtures could (one mode per lane; tests/test_gpu_loop.py ran them bit-identical) but gain nothing: two
+// chains per wave on 2 of 64 lanes each, in-line draws -- 44.1 + 10.2 -> 53.4 us at 4096 chains, 39.0 + 6.6 -> 47.1 us at 512;
+// the Cox process needs the K^-1 GEMM.
 bool fm_mala_fusable(const NetDev& n) {
   const int tpw = (n.dp / 16 + MLP_WAVES_FM - 1) / MLP_WAVES_FM;
-  return n.act == MFM_ACT_RELU && n.T.kind != MFM_TARGET_LGCP && tpw <= 2 && n.d <= 128 * tpw && (n.T.kind != MFM_TARGET_GMM || n.d <= MALA_MAXD_SMALL);
+  return n.act == MFM_ACT_RELU && n.T.kind == MFM_TARGET_PHI4 && tpw <= 2 && n.d <= 128 * tpw;
 }
 
 int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
