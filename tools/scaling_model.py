@@ -6,7 +6,7 @@ as the slowest of N x 4096 chains.  Model: t_flow(N) = a + b * E[max attempts ov
 measured launches of this GPU (one launch per key on the saved benchmark state, tools/flow_ab.py prepare), the expectation
 taken over the pooled empirical distribution of attempts (chains x keys; attempts of a chain are nearly independent of its
 position, tools/att_corr.py), plus the measured per-iteration cost of the other 100 iterations and the all-reduce exposure
-given on the command line.  Usage (GPU box): python tools/scaling_model.py [--keys 48] [--iter_us 90] [--allreduce_us 20]
+given on the command line.  Usage (GPU box): python tools/scaling_model.py [--keys 48] [--iter_us 90.8] [--iter1_us 86.8] [--allreduce_us 20]
 """
 import argparse
 import json
@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--keys", type=int, default=48)
-    ap.add_argument("--iter_us", type=float, default=90.0, help="MALA + training iteration on one rank (bench: iteration_ms_excluding_flow_kernel)")
+    ap.add_argument("--iter_us", type=float, default=90.8, help="MALA + training iteration as separate launches, the call sequence of N > 1 ranks (bench with MFM_NO_FUSED_MALA=1: iteration_ms_excluding_flow_kernel)")
+    ap.add_argument("--iter1_us", type=float, default=86.8, help="the same iteration on ONE rank, MALA step inside the training kernel (bench: iteration_ms_excluding_flow_kernel)")
     ap.add_argument("--allreduce_us", type=float, default=20.0, help="exposed all-reduce time per iteration at N > 1 (857 KB over xGMI)")
     a = ap.parse_args()
     import torch
@@ -60,7 +61,7 @@ def main():
         n = N * B
         emax = float(np.mean([rng.choice(pool, n).max() for _ in range(400)]))
         t_flow = a0 + b * emax
-        t_iter = a.iter_us * 1e-3 + (a.allreduce_us * 1e-3 if N > 1 else 0.0)
+        t_iter = a.iter1_us * 1e-3 if N == 1 else (a.iter_us + a.allreduce_us) * 1e-3
         cyc = K * t_iter + t_flow + t_iter            # K MALA iterations + the flow step and its iteration's training step
         rate = N * B * (K + 1) / (cyc * 1e-3)
         if N == 1:
