@@ -527,7 +527,7 @@ __host__ __device__ inline FmEvalLds fm_eval_lds_layout(const NetDev& n, int R =
 // (137 KB of LDS).  MT = 2: half the LDS and <= 128 registers, so TWO workgroups share a CU and one's batch construction
 // (threefry + erfinv draws, sincos, the mixture's gradient: 15 % of a workgroup's cycles, all vector ALU), epilogues and
 // barriers run under the other's MFMAs -- the measured section stamps of the MT = 4 kernel put its matrix pipe at 52 %.
-template <int MT, int ACT>       // ACT: the hidden non-linearity as a compile-time constant (MFM_ACT_*), or -1: read from the network
+template <int MT, int ACT, bool CHAIN = false>       // ACT: the hidden non-linearity as a compile-time constant (MFM_ACT_*), or -1: read from the network
 __global__ __launch_bounds__((MLP_WAVES_FM * 64), (MT == 2 ? 4 : 2)) void fm_eval_kernel(FmArgs a) {      // (threads, waves per SIMD)
   constexpr int R = 16 * MT;
   const int act = ACT >= 0 ? ACT : a.net.act;
@@ -663,7 +663,20 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64), (MT == 2 ? 4 : 2)) void fm_eva
     };
   };
   auto L_ = [&](int l) -> const LayerDesc& { return n.L[l]; };
-  layer_gemm<MT, MLP_WAVES_FM>(bA, L.lda, n.Wp + L_(0).w_off, n.bias + L_(0).b_off, L_(0).Kp / 16, L_(0).Np / 16, wave, lane, relu_store(bB, L.ldb, 0));       // t1
+  // the five full-width layers with the weight stream chained from tile to tile (mlp.cuh: layer_gemm_chain) where every K is a
+  // multiple of 128 (an even number of fragment groups per tile) and each wave owns exactly one column tile per layer
+  const bool chain_ok = CHAIN;
+  WChain wch; wch.have = false;
+  auto LGE = [&](const float* A, int lda, int l, auto epi, int lnext) {
+    const LayerDesc& ld = n.L[l];
+    if (chain_ok)
+      layer_gemm_chain<MT, MLP_WAVES_FM>(A, lda, n.Wp + ld.w_off, n.bias + ld.b_off, ld.Kp / 16, ld.Np / 16, wave, lane, epi, wch,
+                                         WNext{lnext >= 0 ? n.Wp + n.L[lnext < 0 ? 0 : lnext].w_off + (size_t)wave * (n.L[lnext < 0 ? 0 : lnext].Kp / 16) * 256 : nullptr,
+                                               lnext >= 0 ? n.L[lnext].Kp / 16 : 0});
+    else
+      layer_gemm<MT, MLP_WAVES_FM>(A, lda, n.Wp + ld.w_off, n.bias + ld.b_off, ld.Kp / 16, ld.Np / 16, wave, lane, epi);
+  };
+  LGE(bA, L.lda, 0, relu_store(bB, L.ldb, 0), 1);       // t1
   FM_STAMP(4);
   if (d == 2) {        // x1 with K = 2: two multiply-adds per output on the vector ALU (as a GEMM job its 16-deep padded K and the
                        // wait of seven idle waves cost 7 k cycles per workgroup)
@@ -683,8 +696,8 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64), (MT == 2 ? 4 : 2)) void fm_eva
   layer_gemm<MT, MLP_WAVES_FM>(bX + 4, L.ldx, n.Wp + L_(2).w_off, n.bias + L_(2).b_off, L_(2).Kp / 16, L_(2).Np / 16, wave, lane, relu_store(bC, L.ldc, 0));   // x1
   __syncthreads();
   FM_STAMP(5);
-  layer_gemm<MT, MLP_WAVES_FM>(bB, L.ldb, n.Wp + L_(1).w_off, n.bias + L_(1).b_off, L_(1).Kp / 16, L_(1).Np / 16, wave, lane, relu_store(bA, L.lda, n.hx2));   // st
-  layer_gemm<MT, MLP_WAVES_FM>(bC, L.ldc, n.Wp + L_(3).w_off, n.bias + L_(3).b_off, L_(3).Kp / 16, L_(3).Np / 16, wave, lane, relu_store(bA, L.lda, 0));       // sx
+  LGE(bB, L.ldb, 1, relu_store(bA, L.lda, n.hx2), 3);   // st
+  LGE(bC, L.ldc, 3, relu_store(bA, L.lda, 0), 5);       // sx
   __syncthreads();
   FM_STAMP(6);
   // gate and out have dp / 16 = 1 column tile: instead of ONE wave pushing the four row tiles through it (the other seven
@@ -703,10 +716,10 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64), (MT == 2 ? 4 : 2)) void fm_eva
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) bG[(16 * m + 4 * g + i) * L.ldg + nt * 16 + c] = acc[i] + bias;
                               });
-  layer_gemm<MT, MLP_WAVES_FM>(bA, L.lda, n.Wp + L_(5).w_off, n.bias + L_(5).b_off, L_(5).Kp / 16, L_(5).Np / 16, wave, lane, relu_store(bB, L.ldb, 0));       // j1
+  LGE(bA, L.lda, 5, relu_store(bB, L.ldb, 0), 6);       // j1
   __syncthreads();
   FM_STAMP(7);
-  layer_gemm<MT, MLP_WAVES_FM>(bB, L.ldb, n.Wp + L_(6).w_off, n.bias + L_(6).b_off, L_(6).Kp / 16, L_(6).Np / 16, wave, lane, relu_store(bC, L.ldc, 0));       // j2
+  LGE(bB, L.ldb, 6, relu_store(bC, L.ldc, 0), -1);      // j2
   __syncthreads();
   FM_STAMP(8);
   float loss_loc = 0.f;        // out + loss (:88-90, :177-178)
@@ -946,6 +959,13 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
     { const char* e = getenv("MFM_EVAL_STAGGER"); a2.stagger_cycles = e ? atoi(e) : 30000; }       // measured: 1.023 -> 0.994 ms on 409,600 samples (any delay of 20 k .. 70 k cycles)
     const FmArgs& a = a2;
     const bool relu = a.net.act == MFM_ACT_RELU;
+    // the 32-sample relu instance with its five full-width layers chained (0.997 -> 0.985 ms on 409,600 samples; same arithmetic)
+    bool chain = a.net.d == 2 && a.net.dp == 16 && getenv("MFM_EVAL_NO_CHAIN") == nullptr;
+    for (int l : {0, 1, 3, 5, 6}) chain &= a.net.L[l].Kp % 128 == 0 && a.net.L[l].Np == 16 * MLP_WAVES_FM;
+    if (r == 32 && relu && chain) {
+      (void)hipFuncSetAttribute((const void*)fm_eval_kernel<2, MFM_ACT_RELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr);
+      hipLaunchKernelGGL((fm_eval_kernel<2, MFM_ACT_RELU, true>), dim3((a.B + 31) / 32), dim3(MLP_WAVES_FM * 64), smr, stream, a);
+    } else
     if (r == 32) { if (relu) FM_EVAL_LAUNCH(2, MFM_ACT_RELU); else FM_EVAL_LAUNCH(2, -1); }
     else { if (relu) FM_EVAL_LAUNCH(4, MFM_ACT_RELU); else FM_EVAL_LAUNCH(4, -1); }
 #undef FM_EVAL_LAUNCH
