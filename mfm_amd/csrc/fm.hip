@@ -807,12 +807,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   __shared__ f32x4 sh[2][WG_BB][8][64];                   // [stage][chain tile][A0..A3, Z0..Z3][lane]: 32 KB
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
   const int wk = wave >> 1, wn = wave & 1;
-  if (a.flag_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.flag_reset = 0;
-  const WgradJob J = a.jobs[blockIdx.x];
+  if (a.flag_reset && blockIdx.x == 0 && threadIdx.x == 0) *a.flag_reset = 0;
+  // Workgroup -> (block, chain slice), XCD-aware: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.
+  // id % split = slice puts (with split = 8) ALL blocks of one chain slice on one XCD, where they run concurrently and walk the
+  // slice's chain tiles together: an operand tile that 2 - 4 blocks of its layer need is then fetched into that L2 once.  With
+  // (block, slice) = (blockIdx.x, blockIdx.y) the blocks of a layer were spread over all XCDs: 90 % of the kernel's L2 requests
+  // missed (TCC_MISS 0.87 M of 0.97 M per launch, 111 MB from beyond L2 -- its bound, not the MFMAs: profiles/r03_pmc_summary.json).
+  const int lin = blockIdx.x, sp = lin % a.split;
+  const WgradJob J = a.jobs[lin / a.split];
   const NetDev& n = a.net;
   const LayerDesc& ld = n.L[J.layer];
   const int KT = ld.Kp / 16, NT = ld.Np / 16;
-  const int sp = blockIdx.y;
   const int bb_lo = (int)((long long)a.nbb * sp / a.split), bb_hi = (int)((long long)a.nbb * (sp + 1) / a.split);
   // this wave FETCHES tiles `wave` (an A tile) and 4 + `wave` (a dZ tile) of the block; tiles past the layer's edge are
   // clamped to a valid one (fetched, never used)
@@ -1015,7 +1020,7 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
 }
 
 int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
-  dim3 grid(a.n_jobs, a.split), block(256);
+  dim3 grid(a.n_jobs * a.split), block(256);
   hipLaunchKernelGGL(wgrad_kernel, grid, block, 0, stream, a);
   return 0;
 }
