@@ -70,7 +70,8 @@ struct mfm_ctx {
   float *acts, *dzs, *slabs, *dacts;
   double* loss_part; int loss_cap;
   WgradJob* jobs; int n_jobs, split;
-  OptState* opt; int* flag;
+  OptState* opt; int* flag;      // opt: the CURRENT optimizer scalars (opt_alt: the buffer the one-launch reduction + optimizer writes next)
+  OptState* opt_alt;
   const float* checked_grads = nullptr;   // gradient whose finite check already sits in flag[0] (single-rank mfm_fm_loss_grad)
   float *gmm_mode, *gmm_std, *gmm_logw, *counts, *Kinv, *kbias;
   OdeWs ode;
@@ -243,13 +244,13 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
     ALLOC(x->slabs, (size_t)x->split * n.n_params);
   }
   ALLOC(x->loss_part, x->loss_cap);
-  ALLOC(x->jobs, x->n_jobs); ALLOC(x->opt, 1); ALLOC(x->flag, 4); ALLOC(x->beta_out, 4);
+  ALLOC(x->jobs, x->n_jobs); ALLOC(x->opt, 1); ALLOC(x->opt_alt, 1); ALLOC(x->flag, 8); ALLOC(x->beta_out, 4);
   ALLOC(x->d_att, 1); HIPCHK(hipMemset(x->d_att, 0, sizeof(unsigned long long)));
   HIPCHK(hipMemcpy(x->jobs, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(x->master, 0, n.n_params * 4)); HIPCHK(hipMemset(x->mu, 0, n.n_params * 4));
   HIPCHK(hipMemset(x->nu, 0, n.n_params * 4)); HIPCHK(hipMemset(x->Wp, 0, n.n_packed * 4));
   HIPCHK(hipMemset(x->WpT, 0, n.n_packed * 4)); HIPCHK(hipMemset(x->bias, 0, n.n_bias * 4));
-  HIPCHK(hipMemset(x->opt, 0, sizeof(OptState))); HIPCHK(hipMemset(x->flag, 0, 16));
+  HIPCHK(hipMemset(x->opt, 0, sizeof(OptState))); HIPCHK(hipMemset(x->opt_alt, 0, sizeof(OptState))); HIPCHK(hipMemset(x->flag, 0, 32));
   n.Wp = x->Wp; n.WpT = x->WpT; n.bias = x->bias; n.fourier = x->fourier;
   int rc = ode_ws_alloc(n, c, x->ode);
   if (rc) return fail(rc, "ODE workspace allocation failed");
@@ -264,7 +265,7 @@ extern "C" int mfm_destroy(mfm_ctx* x) {
   if (!x) return MFM_OK;
   hipDeviceSynchronize();
   void* ps[] = {x->master, x->mu, x->nu, x->Wp, x->WpT, x->bias, x->fourier, x->acts, x->dzs, x->dacts, x->slabs, x->loss_part,
-                x->jobs, x->opt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->beta_out,
+                x->jobs, x->opt, x->opt_alt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->beta_out,
                 x->d_att, x->att_buf};
   for (void* p : ps) if (p) hipFree(p);
   (void)mfm_comm_destroy(x);
@@ -526,6 +527,7 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
     return MFM_OK;
   }
   if (train && x->fuse_mala.on) a.mala = x->fuse_mala;      // mfm_train_iter: the iteration's MALA step in the same launch
+  if (train) a.flags_clear = x->flag;
   if (train && x->cfg.cond_flow) {
     const int slot = noise_take(x, key, true);
     if (slot >= 0) {
@@ -545,7 +547,26 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
   return MFM_OK;
 }
 
-extern "C" int mfm_fm_loss_grad(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_pos, double* d_loss, float* d_grads) {
+static AdamArgs adam_args(mfm_ctx* x, const float* grads, int n_slabs) {
+  const mfm_config& c = x->cfg;
+  AdamArgs a; memset(&a, 0, sizeof a);
+  a.net = x->net; a.grads = grads; a.n_slabs = n_slabs;
+  a.master = x->master; a.mu = x->mu; a.nu = x->nu; a.Wp = x->Wp; a.WpT = x->WpT; a.bias = x->bias;
+  a.st = x->opt; a.flag = x->flag;
+  a.lr0 = c.learning_rate; a.learning_iter = c.learning_iter; a.warmup = c.warmup_steps;
+  a.b1 = c.adam_b1; a.b2 = c.adam_b2; a.eps = (float)c.adam_eps; a.wd = (float)c.weight_decay; a.clip = (float)c.update_clip;
+  a.max_err = 10;
+  return a;
+}
+
+// one rank, tile family: slab reduction + apply_if_finite + AdamW as ONE launch behind the weight-gradient kernel (optim.hip:
+// reduce_adamw_kernel; every workgroup of its grid must be resident at once, hence the bound on the parameter count)
+static bool opt_fusable(mfm_ctx* x) {
+  const bool off = getenv("MFM_NO_FUSED_OPT") != nullptr;
+  return !off && !x->wide && !x->comm && x->cfg.n_chain_total == x->cfg.n_chain_local && x->net.n_params <= 400000;
+}
+
+static int fm_loss_grad_impl(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_pos, double* d_loss, float* d_grads, bool with_optimizer) {
   NEED_TARGET();
   if (!d_pos || !d_loss || !d_grads) return fail(MFM_EINVAL, "null device pointer");
   x->checked_grads = nullptr;
@@ -557,6 +578,18 @@ extern "C" int mfm_fm_loss_grad(mfm_ctx* x, uint32_t k0, uint32_t k1, const floa
   // One rank: this sum is the gradient the optimizer will see, so its finite check rides in the reduction and
   // mfm_adamw_step(d_grads) skips its check kernel.  With more ranks the check has to follow the all-reduce.
   const bool single = x->cfg.n_chain_total == x->cfg.n_chain_local;
+  if (with_optimizer) {
+    w.flag_partial = x->flag;                  // cleared by the training kernel (FmArgs::flags_clear)
+    { ProfScope ps_(x, PROF_WGRAD); launch_wgrad(w, x->stream); }
+    LAUNCHCHK();
+    const int force = getenv("MFM_DEBUG_FORCE_EXCHANGE") ? 1 : 0;      // tests: the grid-wide decision path on ordinary gradients
+    ProfScope ps2_(x, PROF_ADAM);
+    launch_reduce_adamw(adam_args(x, x->slabs, x->split), x->opt_alt, d_grads, x->loss_part, x->cfg.n_chain_local / 16, d_loss, force, x->stream);
+    LAUNCHCHK();
+    OptState* t = x->opt; x->opt = x->opt_alt; x->opt_alt = t;
+    x->ctr[CTR_OPT_STEPS] += 1;
+    return MFM_OK;
+  }
   w.flag_reset = single ? x->flag : nullptr;
   { ProfScope ps_(x, PROF_WGRAD); launch_wgrad(w, x->stream); }
   LAUNCHCHK();
@@ -565,6 +598,9 @@ extern "C" int mfm_fm_loss_grad(mfm_ctx* x, uint32_t k0, uint32_t k1, const floa
   LAUNCHCHK();
   x->checked_grads = single ? d_grads : nullptr;
   return MFM_OK;
+}
+extern "C" int mfm_fm_loss_grad(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_pos, double* d_loss, float* d_grads) {
+  return fm_loss_grad_impl(x, k0, k1, d_pos, d_loss, d_grads, false);
 }
 
 extern "C" int mfm_fm_loss(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_samples, int n, int n_total, int offset, double* d_loss) {
@@ -670,14 +706,7 @@ extern "C" int mfm_grad_allreduce_begin(mfm_ctx* x, float* d_grads) {
 
 extern "C" int mfm_adamw_step(mfm_ctx* x, const float* d_grads) {
   if (!x || !d_grads) return fail(MFM_EINVAL, "null argument");
-  const mfm_config& c = x->cfg;
-  AdamArgs a; memset(&a, 0, sizeof a);
-  a.net = x->net; a.grads = d_grads; a.n_slabs = 1;
-  a.master = x->master; a.mu = x->mu; a.nu = x->nu; a.Wp = x->Wp; a.WpT = x->WpT; a.bias = x->bias;
-  a.st = x->opt; a.flag = x->flag;
-  a.lr0 = c.learning_rate; a.learning_iter = c.learning_iter; a.warmup = c.warmup_steps;
-  a.b1 = c.adam_b1; a.b2 = c.adam_b2; a.eps = (float)c.adam_eps; a.wd = (float)c.weight_decay; a.clip = (float)c.update_clip;
-  a.max_err = 10;
+  AdamArgs a = adam_args(x, d_grads, 1);
   a.inline_decide = (x->checked_grads == d_grads) ? 1 : 0;
   x->checked_grads = nullptr;
   if (x->comm) {
@@ -724,16 +753,18 @@ extern "C" int mfm_train_iter(mfm_ctx* x, int64_t count, int K, int flow_mode, u
       m.pre_n = x->noise->mala_n + (size_t)slot * B * x->cfg.dim; m.pre_u = x->noise->mala_u + (size_t)slot * B;
     }
     x->fuse_mala = m;
-    rc = mfm_fm_loss_grad(x, tk0, tk1, d_pos, d_loss, d_grads);
+    const bool with_opt = apply_update && opt_fusable(x);
+    rc = fm_loss_grad_impl(x, tk0, tk1, d_pos, d_loss, d_grads, with_opt);
     x->fuse_mala.on = 0;
     if (rc == MFM_OK) { x->ctr[CTR_MALA] += x->cfg.n_chain_local; x->ctr[CTR_MALA_BYTES] += (int64_t)x->cfg.n_chain_local * 4 * (5 * x->cfg.dim + 5); }
-    if (rc || !apply_update) return rc;
+    if (rc || !apply_update || with_opt) return rc;
     return mfm_adamw_step(x, d_grads);
   }
   else rc = mfm_mala_step(x, gk0, gk1, beta, step_size, 0, d_pos, d_logp, d_grad, d_acc, nullptr, nullptr, nullptr);
   if (rc) return rc;
-  rc = mfm_fm_loss_grad(x, tk0, tk1, d_pos, d_loss, d_grads);
-  if (rc || !apply_update) return rc;
+  const bool with_opt = apply_update && x->has_target && opt_fusable(x);
+  rc = fm_loss_grad_impl(x, tk0, tk1, d_pos, d_loss, d_grads, with_opt);
+  if (rc || !apply_update || with_opt) return rc;
   return mfm_adamw_step(x, d_grads);
 }
 

@@ -48,6 +48,8 @@ struct FmArgs {
   const double* pre_x0; const double* pre_eps; const float* pre_t;   // non-null: the batch's draws, produced ahead of time by noise_kernel
   int stagger_cycles;    // fm_eval_kernel<2, .>: start delay of the second workgroup of every CU (0: none)
   FmMala mala;           // fm_fwd_bwd_kernel<.., MALA = true> only
+  int* flags_clear;      // non-null (TRAIN): flag words [0], [3], [4] of the optimizer's scratch, cleared here for the weight-gradient kernel
+                         // and the one-launch reduction + optimizer that follow (optim.hip: reduce_adamw_kernel)
 };
 
 struct FmLds {           // float offsets into dynamic LDS
@@ -135,6 +137,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   float* bDV = lds + L.dv;  float* bD1 = lds + L.d1; float* bD2 = lds + L.d2; float* bDC = lds + L.dcat;
   float* gcs = lds + L.gcs; double* red = reinterpret_cast<double*>(lds + L.red); float* bGC = lds + L.gc;
 
+  if (TRAIN && a.flags_clear && blockIdx.x == 0 && threadIdx.x == 0) { a.flags_clear[0] = 0; a.flags_clear[3] = 0; a.flags_clear[4] = 0; }
   WChain wch; wch.have = false;
   if constexpr (STATIC) {      // the first tile's first fragment group: requested before everything else, it arrives under the prologue
     const __amdgpu_buffer_rsrc_t w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(n.Wp + n.L[0].w_off) + (size_t)wave * (n.L[0].Kp / 16) * 256, 0,
@@ -768,6 +771,8 @@ struct WgradArgs {
   int nbb, split;
   float* slabs;            // [split][n_params]
   int* flag_reset;         // non-null: the non-finite flag reduce_slabs_kernel will raise for THIS gradient (cleared here)
+  int* flag_partial;       // non-null (one launch for reduction + optimizer, optim.hip: reduce_adamw_kernel): raised when a partial sum
+                           // is non-finite or so large that the sum over the slices could overflow; cleared by the training kernel
 };
 
 __device__ __forceinline__ int wgrad_a_tile(const NetDev& n, const WsLayout& w, int layer, int kt) {
@@ -864,11 +869,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     __syncthreads();
   }
   float* slab = a.slabs + (size_t)sp * n.n_params;
+  const float big = 3.0e38f / (float)a.split;      // |partial| <= big for every slice: the sum over the slices cannot overflow
+  bool suspicious = false;
   auto put = [&](f32x4 acc, int kt, int nt) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = kt * 16 + 4 * g + i, nn = nt * 16 + c;
-      if (k < ld.K && nn < ld.N) slab[ld.m_w + k * ld.N + nn] = acc[i];
+      if (k < ld.K && nn < ld.N) { slab[ld.m_w + k * ld.N + nn] = acc[i]; suspicious |= !(fabsf(acc[i]) <= big); }
     }
   };
   if (k0 && n0) put(acc00, kq, nq);
@@ -881,10 +888,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
     if (g == 0) {
       const int nn0 = nq * 16 + c, nn1 = (nq + 1) * 16 + c;
-      if (n0 && nn0 < ld.N) slab[ld.m_b + nn0] = s0;
-      if (n1 && nn1 < ld.N) slab[ld.m_b + nn1] = s1;
+      if (n0 && nn0 < ld.N) { slab[ld.m_b + nn0] = s0; suspicious |= !(fabsf(s0) <= big); }
+      if (n1 && nn1 < ld.N) { slab[ld.m_b + nn1] = s1; suspicious |= !(fabsf(s1) <= big); }
     }
   }
+  if (a.flag_partial && __ballot(suspicious) != 0ull && lane == 0) atomicOr(a.flag_partial, 1);
 }
 
 // grads[p] = sum_s slabs[s][p]; the last workgroup of the grid also totals the per-tile loss partials of the forward

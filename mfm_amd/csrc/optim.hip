@@ -93,6 +93,19 @@ __global__ void finite_decide_kernel(const float* grads, int n_slabs, int n, Opt
 
 __device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool apply, float bc1, float bc2, float lr);
 
+// One parameter's AdamW + clip update (optax 0.1.9: scale_by_adam, add_decayed_weights on kernels, scale by -lr, clip).  Every
+// multiply-add is an explicit fused operation: the three update kernels (scalar, 4 x 4 blocks, reduction + update) inline this
+// one function and must round alike -- left to the compiler's contraction they need not (targets.cuh: phi4_grad, round 3).
+__device__ __forceinline__ float adam_update(float w, float g, float& m, float& v, float b1, float b2, float bc1, float bc2, float eps, float wd,
+                                             bool decay, float lr, float clip) {
+  m = __builtin_fmaf(b1, m, (1.f - b1) * g);
+  v = __builtin_fmaf(b2, v, (1.f - b2) * g * g);
+  float u = (m / bc1) / (sqrtf(v / bc2) + eps);
+  if (decay) u = __builtin_fmaf(wd, w, u);
+  u = fminf(fmaxf(-lr * u, -clip), clip);
+  return w + u;
+}
+
 // Last workgroup of an update kernel: advance the inner count, and with inline_decide the bookkeeping finite_decide_kernel
 // would have done (every workgroup has read the old state by the time the last ticket is drawn).
 __device__ __forceinline__ void adam_commit(const AdamArgs& a, const AdamDecision& d) {
@@ -122,7 +135,9 @@ __global__ void adamw_kernel(AdamArgs a) {
   if (threadIdx.x == 0) adam_commit(a, dec);
 }
 
-__device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool apply, float bc1, float bc2, float lr) {
+// `gsum_in`: the element's (summed) gradient when the caller already holds it; otherwise it is summed from a.grads here
+template <bool HAVE_G>
+__device__ __forceinline__ void adamw_element_t(const AdamArgs& a, int p, bool apply, float bc1, float bc2, float lr, float gsum_in) {
   const NetDev& n = a.net;
   float w = a.master[p];
   // locate (layer, kernel/bias, k, nn)
@@ -132,17 +147,14 @@ __device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool app
   const LayerDesc& ld = n.L[layer];
   const bool is_bias = p >= ld.m_b;
   if (apply) {
-    float gsum = 0.f;
-    for (int k = 0; k < a.n_slabs; ++k) gsum += a.grads[(size_t)k * n.n_params + p];
-    const float b1 = (float)a.b1, b2 = (float)a.b2;
-    const float m = b1 * a.mu[p] + (1.f - b1) * gsum;
-    const float v = b2 * a.nu[p] + (1.f - b2) * gsum * gsum;
+    float gsum = gsum_in;
+    if constexpr (!HAVE_G) {
+      gsum = 0.f;
+      for (int k = 0; k < a.n_slabs; ++k) gsum += a.grads[(size_t)k * n.n_params + p];
+    }
+    float m = a.mu[p], v = a.nu[p];
+    w = adam_update(w, gsum, m, v, (float)a.b1, (float)a.b2, bc1, bc2, a.eps, a.wd, !is_bias, lr, a.clip);
     a.mu[p] = m; a.nu[p] = v;
-    float u = (m / bc1) / (sqrtf(v / bc2) + a.eps);
-    if (!is_bias) u += a.wd * w;
-    u = -lr * u;
-    u = fminf(fmaxf(u, -a.clip), a.clip);
-    w += u;
     a.master[p] = w;
   }
   // re-emit packed copies (also on rejected updates: cheap, keeps the kernel branch-free for the packer)
@@ -154,6 +166,79 @@ __device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool app
     a.Wp[ld.w_off + pack_index(kk, nn, ld.Kp / 16)] = w;
     a.WpT[ld.w_off + pack_index_T(kk, nn, ld.Np / 16)] = w;
   }
+}
+
+__device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool apply, float bc1, float bc2, float lr) {
+  adamw_element_t<false>(a, p, apply, bc1, bc2, lr, 0.f);
+}
+
+// ---- one rank, one launch: slab reduction + apply_if_finite decision + AdamW (mfm_train_iter) ---------------------------------
+// reduce_slabs_kernel and the update kernel as ONE kernel, one parameter per thread.  What kept them apart is the decision:
+// apply_if_finite skips the WHOLE update when ANY element of the gradient is non-finite, which a kernel that sums and updates
+// element by element only knows after a grid-wide exchange (tried in round 3 as an arrival ticket inside the update kernel: 26 us
+// against 11.7 + 7.1).  Here the weight-gradient kernel raises flag[0] when one of its PARTIAL sums (one of `n_slabs` slices of
+// the chain axis) is non-finite or exceeds FLT_MAX / n_slabs in magnitude: with flag[0] == 0 every total is a sum of n_slabs
+// finite terms that cannot overflow, i.e. finite, and the update is applied without any exchange.  With flag[0] != 0 (gradients
+// beyond 1e37: practically a diverged run) the kernel decides on the TOTALS exactly as before, through a grid-wide arrival
+// counter -- every workgroup of this grid is resident at once (one parameter per thread: a few hundred workgroups), so the
+// wait cannot deadlock.  The optimizer state is double-buffered (read `st`, block 0 writes `st_next`): no workgroup has to be the
+// last to read it.  Also totals the loss partials of the training kernel (last block), like reduce_slabs_kernel.
+__global__ __launch_bounds__(256) void reduce_adamw_kernel(AdamArgs a, OptState* st_next, float* out, const double* loss_part, int n_part, double* loss_out,
+                                                           int force_exchange) {
+  __shared__ int sh_finite;
+  const int n = a.net.n_params, p = blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < n;
+  const OptState st = *a.st;
+  const int suspicious = a.flag[0] | force_exchange;
+  float s = 0.f;
+  if (live) {
+    for (int k = 0; k < a.n_slabs; ++k) s += a.grads[(size_t)k * n + p];
+    out[p] = s;
+  }
+  bool finite = true;
+  if (suspicious) {                            // uniform over the grid
+    const int any = __syncthreads_or(live && !isfinite(s) ? 1 : 0);
+    if (threadIdx.x == 0) {
+      // the arrival is counted only after this workgroup's flag update has RETURNED (data dependence), and device-scope
+      // atomics are performed at the memory side: the last arrival sees every update
+      const unsigned int dep = any ? (unsigned int)atomicOr(a.flag + 3, 1) : 0u;
+      atomicAdd(a.flag + 4, 1 + (int)(dep & 0x40000000u));
+      while (atomicAdd(a.flag + 4, 0) < (int)gridDim.x) __builtin_amdgcn_s_sleep(8);
+      sh_finite = atomicOr(a.flag + 3, 0) == 0;
+    }
+    __syncthreads();
+    finite = sh_finite != 0;
+  }
+  const int nf_new = finite ? 0 : st.notfinite_count + 1;
+  const bool apply = finite || nf_new > a.max_err;
+  const int count = st.count, c1 = count + 1;
+  const float bc1 = (float)(1.0 - pow(a.b1, (double)c1)), bc2 = (float)(1.0 - pow(a.b2, (double)c1));
+  const float lr = lr_schedule(a.lr0, a.learning_iter, a.warmup, count);
+  if (live) adamw_element_t<true>(a, p, apply, bc1, bc2, lr, s);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    OptState nx;
+    nx.notfinite_count = nf_new;
+    nx.last_lr = lr_schedule(a.lr0, a.learning_iter, a.warmup, st.step);
+    nx.step = st.step + 1;
+    nx.last_applied = apply ? 1 : 0;
+    nx.count = apply ? count + 1 : count;
+    *st_next = nx;
+  }
+  if (loss_part && blockIdx.x == gridDim.x - 1) {
+    __shared__ double sm[256];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += 256) t += loss_part[i];
+    sm[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_out = sm[0];
+  }
+}
+void launch_reduce_adamw(const AdamArgs& a, OptState* st_next, float* out, const double* loss_part, int n_part, double* loss_out, int force_exchange, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_adamw_kernel, dim3((a.net.n_params + 255) / 256), dim3(256), 0, stream, a, st_next, out, loss_part, n_part, loss_out, force_exchange);
 }
 
 // The same update for networks whose every kernel has in / out widths that are multiples of 4 (all of the reference's
@@ -209,11 +294,9 @@ __global__ __launch_bounds__(256) void adamw_vec_kernel(AdamArgs a, AdamBlocks b
         f32x4 m = m4[r], v = v4[r];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          m[j] = b1 * m[j] + (1.f - b1) * g[j];
-          v[j] = b2 * v[j] + (1.f - b2) * g[j] * g[j];
-          float u = (m[j] / bc1) / (sqrtf(v[j] / bc2) + a.eps) + a.wd * w[r][j];
-          u = fminf(fmaxf(-lr * u, -a.clip), a.clip);
-          w[r][j] += u;
+          float mj = m[j], vj = v[j];
+          w[r][j] = adam_update(w[r][j], g[j], mj, vj, b1, b2, bc1, bc2, a.eps, a.wd, true, lr, a.clip);
+          m[j] = mj; v[j] = vj;
         }
         *reinterpret_cast<f32x4*>(a.mu + p) = m; *reinterpret_cast<f32x4*>(a.nu + p) = v;
         *reinterpret_cast<f32x4*>(a.master + p) = w[r];

@@ -172,6 +172,51 @@ def test_run_one_call_iterations_equal_the_separate_calls(monkeypatch, example):
     np.testing.assert_array_equal(out[0][2], out[1][2])
 
 
+@pytest.mark.parametrize("force_exchange", [False, True])
+def test_train_iter_with_a_non_finite_gradient_equals_the_separate_calls(monkeypatch, force_exchange):
+    """apply_if_finite through mfm_train_iter's one-launch reduction + optimizer (optim.hip: reduce_adamw_kernel): a NaN position
+    in iteration 3 makes that iteration's gradient non-finite -- the update is skipped, notfinite_count advances and is reset by
+    the next finite gradient, exactly as with mfm_fm_loss_grad + mfm_adamw_step.  force_exchange runs EVERY iteration through the
+    grid-wide decision on the totals (the path taken when a partial sum is huge or non-finite)."""
+    import torch
+    from oracle import prng
+    from tests import gpu_util as gu
+    from mfm_amd._lib import FLOW_RWMH
+    if force_exchange:
+        monkeypatch.setenv("MFM_DEBUG_FORCE_EXCHANGE", "1")
+    args, dist, k, model, state = gu.phi4_setup(d=256, B=64, learning_iter=20)
+    params = gu.rand_params(model, seed=3, out_scale=0.05)
+    x0 = dist.init_params.astype(np.float32)
+    out = []
+    for one_call in (False, True):
+        ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+        pos = torch.from_numpy(x0).cuda(); logp = torch.empty(64, device="cuda", dtype=torch.float64); grad = torch.empty_like(pos)
+        acc = torch.empty(64, device="cuda"); loss = torch.zeros(1, device="cuda", dtype=torch.float64); grads = torch.zeros(ctx.n_params, device="cuda")
+        ctx.mala_init(pos, 1.0, logp, grad)
+        ks, tr = prng.PRNGKey(5), []
+        for count in range(1, 6):
+            ks, kg, kt = prng.split(ks, 3)
+            if count == 3:
+                saved = pos[5, 7].item(); pos[5, 7] = float("nan")
+            if one_call:
+                ctx.train_iter(count, 100, FLOW_RWMH, kg, kt, 1.0, args.step_size, pos, logp, grad, loss, grads, acc=acc)
+            else:
+                ctx.mala_step(kg, 1.0, args.step_size, pos, logp, grad, acc); ctx.fm_loss_grad(kt, pos, loss, grads); ctx.adamw_step(grads)
+            tr.append((ctx.opt_state(), ctx.get_params().copy(), loss.item()))
+            if count == 3:
+                pos[5, 7] = saved
+                ctx.mala_init(pos, 1.0, logp, grad)
+        out.append(tr); ctx.close()
+    for i, ((s0, p0, l0), (s1, p1, l1)) in enumerate(zip(*out)):
+        assert s0 == s1, (i, s0, s1)
+        np.testing.assert_array_equal(p0, p1)
+        assert (np.isnan(l0) and np.isnan(l1)) or l0 == l1
+    s3, s4 = out[1][2][0], out[1][3][0]
+    assert s3["notfinite_count"] == 1 and s3["last_applied"] == 0 and s3["count"] == 2 and s3["step"] == 3
+    assert s4["notfinite_count"] == 0 and s4["last_applied"] == 1 and s4["count"] == 3
+    np.testing.assert_array_equal(out[1][1][1], out[1][2][1])          # the skipped update left the parameters alone
+
+
 @pytest.mark.parametrize("case", ["phi4_64", "phi4_256_headline", "gmm4", "gmm16"])
 def test_train_iter_equals_the_separate_calls(case):
     """mfm_train_iter (generator :300-314 + train_step :362-368 in one call; its MALA step rides in the training kernel's
