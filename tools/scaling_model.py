@@ -6,7 +6,7 @@ as the slowest of N x 4096 chains.  Model: t_flow(N) = a + b * E[max attempts ov
 measured launches of this GPU (one launch per key on the saved benchmark state, tools/flow_ab.py prepare), the expectation
 taken over the pooled empirical distribution of attempts (chains x keys; attempts of a chain are nearly independent of its
 position, tools/att_corr.py), plus the measured per-iteration cost of the other 100 iterations and the all-reduce exposure
-given on the command line.  Usage (GPU box): python tools/scaling_model.py [--keys 48] [--iter_us 90.8] [--iter1_us 86.8] [--allreduce_us 20]
+given on the command line.  Usage (GPU box): python tools/scaling_model.py [--keys 48] [--iter_us 90.8] [--iter1_us 82.1] [--allreduce_us 20]
 """
 import argparse
 import json
@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--keys", type=int, default=48)
     ap.add_argument("--iter_us", type=float, default=90.8, help="MALA + training iteration as separate launches, the call sequence of N > 1 ranks (bench with MFM_NO_FUSED_MALA=1: iteration_ms_excluding_flow_kernel)")
-    ap.add_argument("--iter1_us", type=float, default=86.8, help="the same iteration on ONE rank, MALA step inside the training kernel (bench: iteration_ms_excluding_flow_kernel)")
+    ap.add_argument("--iter1_us", type=float, default=82.1, help="the same iteration on ONE rank, MALA step inside the training kernel, reduction + optimizer in one launch (bench: iteration_ms_excluding_flow_kernel)")
     ap.add_argument("--allreduce_us", type=float, default=20.0, help="exposed all-reduce time per iteration at N > 1 (857 KB over xGMI)")
     a = ap.parse_args()
     import torch
