@@ -316,8 +316,8 @@ def main():
 
     def step(i, count):
         flow = count % (wl_K + 1) == 0                                           # :311
-        if flow and not os.environ.get("MFM_NO_PREFETCH"):   # draws of the next K iterations, in the flow step's tail (noise.hip)
-            ctx.noise_prefetch(keys[i + 1:i + 1 + wl_K, 0], keys[i + 1:i + 1 + wl_K, 1])
+        if flow and not os.environ.get("MFM_NO_PREFETCH"):   # draws of this iteration's training batch and of the next K iterations, in the flow step's tail (noise.hip)
+            ctx.noise_prefetch(keys[i:i + 1 + wl_K, 0], keys[i:i + 1 + wl_K, 1])
         # generator (:300-314) + loss/grad + [all-reduce] + AdamW (:362-368): mfm_train_iter on one rank
         eng.train_iter(count, wl_K, FLOW_RWMH, keys[i, 0], keys[i, 1], beta, args.step_size, pos, logp, grad, acc=acc, nsteps=nst)
         if d2:                                               # eval_step (:370-374, :444-446): same key, same exact samples, every iteration

@@ -347,8 +347,9 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
         key_sample, key_train_gn, key_train_step = jr.split(key_sample, 3)                  # :433
         if prefetch and count % (K_int + 1) == 0:
             # a flow step comes: let the workgroups of its kernel that finish early produce the random draws of the K
-            # MALA + training iterations that follow (noise.hip); their keys are the next K splits of key_sample
-            ks, kg, kt = key_sample, [], []
+            # MALA + training iterations that follow (noise.hip); their keys are the next K splits of key_sample.  Slot 0 is
+            # this iteration's own training batch (its generator key is the flow step's: those MALA draws are never asked for)
+            ks, kg, kt = key_sample, [key_train_gn], [key_train_step]
             for _ in range(min(K_int, learning_iter - count)):
                 ks, a_, b_ = jr.split(ks, 3)
                 kg.append(a_); kt.append(b_)
