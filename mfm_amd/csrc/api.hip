@@ -563,7 +563,7 @@ static AdamArgs adam_args(mfm_ctx* x, const float* grads, int n_slabs) {
 // reduce_adamw_kernel; every workgroup of its grid must be resident at once, hence the bound on the parameter count)
 static bool opt_fusable(mfm_ctx* x) {
   const bool off = getenv("MFM_NO_FUSED_OPT") != nullptr;
-  return !off && !x->wide && !x->comm && x->cfg.n_chain_total == x->cfg.n_chain_local && x->net.n_params <= 400000;
+  return !off && !x->wide && !x->comm && x->cfg.n_chain_total == x->cfg.n_chain_local && x->net.n_params <= 300000;      // <= 1172 workgroups of 256: 57 % of the 2048 the chip holds at once (45 VGPRs, 8 waves per SIMD)
 }
 
 static int fm_loss_grad_impl(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_pos, double* d_loss, float* d_grads, bool with_optimizer) {
