@@ -512,6 +512,9 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
 // t1 / j1, x1 / j2) so that 64 rows fit in LDS.  Same per-sample arithmetic as fm_fwd_bwd_kernel<.., TRAIN = false> (same
 // k-order per accumulator); the per-workgroup loss partial covers 64 samples instead of 16.  For dp <= 16 (the mixtures).
 struct FmEvalLds { int a, lda, b, ldb, c, ldc, x, ldx, g, ldg, tgt, tt, gcs, red, gmm, total; };
+// the same draw as a CALL: for paths that are compiled into a kernel but do not carry its time (the eval kernel's general batch
+// construction beside the two-threads-per-element one the mixtures take), so that they do not carry its code size either
+__device__ __attribute__((noinline)) double normal64_call(Key2 key, uint32_t idx, uint32_t size) { return normal64(key, idx, size); }
 __host__ __device__ inline FmEvalLds fm_eval_lds_layout(const NetDev& n, int R = 64) {      // R: samples per workgroup
   FmEvalLds L; int o = 0;
   auto take = [&](int cnt) { int r = o; o += cnt; return r; };
@@ -578,9 +581,14 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64), (MT == 2 ? 4 : 2)) void fm_eva
       const int row = e / d, col = e - row * d;
       const uint32_t bg = a.chain_offset + (uint32_t)(b0 + row);
       double v = 0.0;
-      if (b0 + row < a.B)
-        v = which == 0 ? a.ref_std * normal64(split_at(a.key_ref, a.n_total, bg), (uint32_t)col, (uint32_t)d)                  // :155
-                       : normal64(a.key_gauss, bg * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);                     // :166
+      if (b0 + row < a.B) {
+        // ONE inlined threefry + erfinv chain for both kinds of draw (key / counter / scale selected first): two copies made the
+        // prologue 7.6 k instructions of a kernel whose code then exceeded the 64 KB instruction cache two CUs share
+        const Key2 kr = split_at(a.key_ref, a.n_total, bg);
+        const Key2 kk = which == 0 ? kr : a.key_gauss;
+        const uint32_t idx = which == 0 ? (uint32_t)col : bg * (uint32_t)d + (uint32_t)col, size = which == 0 ? (uint32_t)d : a.n_total * (uint32_t)d;
+        v = (which == 0 ? a.ref_std : 1.0) * normal64(kk, idx, size);                                                         // :155 / :166
+      }
       stage[2 * e + which] = v;
     }
     __syncthreads();
@@ -600,11 +608,11 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64), (MT == 2 ? 4 : 2)) void fm_eva
       const double x1v = a.pos[(size_t)(b0 + row) * d + col], t = btt[row];
       double cnd, tgd;
       if (a.cond_flow) {
-        const double x0 = a.ref_std * normal64(split_at(a.key_ref, a.n_total, bg), (uint32_t)col, (uint32_t)d);                 // :155
-        const double ne = normal64(a.key_gauss, bg * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);                    // :166
+        const double x0 = a.ref_std * normal64_call(split_at(a.key_ref, a.n_total, bg), (uint32_t)col, (uint32_t)d);            // :155
+        const double ne = normal64_call(a.key_gauss, bg * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);               // :166
         cnd = (double)a.sigma * ne + t * x1v + (1.0 - t) * x0; tgd = x1v - x0;                                                  // :167-168
       } else {
-        const double x0 = normal64(a.key_ref, bg * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);                      // :143
+        const double x0 = normal64_call(a.key_ref, bg * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);                 // :143
         cnd = t * x1v + (1.0 - (1.0 - (double)a.sigma) * t) * x0; tgd = x1v - (1.0 - (double)a.sigma) * x0;                      // :144-146
       }
       bX[row * L.ldx + 4 + col] = (float)cnd; bT[row * n.dp + col] = (float)tgd;
