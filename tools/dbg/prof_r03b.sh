@@ -2,7 +2,7 @@
 # passes of tools/prof_round.sh / prof_workload.sh concern kernels that did not change).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for wl in headline gaussian-mixture 4-mode; do
+for wl in gaussian-mixture 4-mode; do
   OUT=$R/gpurun_out/prof_r03b_$wl; rm -rf $OUT; mkdir -p $OUT
   if [ $wl = headline ]; then W=""; else W="--workload $wl"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $W --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
