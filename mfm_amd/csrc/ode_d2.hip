@@ -343,14 +343,20 @@ struct TileR {
 #pragma unroll
         for (int s = 0; s < 4; ++s) ag[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wg[s], ag[m], 0, 0, 0);
       }
+      // the eight (m, i) stores of each kind from ONE base per kind + immediate offsets; the bases are made opaque here, inside the
+      // solver loop: as loop invariants the sixteen full addresses were hoisted out of it, spilled, and came back through ten
+      // serialized scratch reloads per attempt (each with its own vmcnt(0))
+      float* pct = lds + L.ct + (4 * g) * 128 + col;
+      float* pgp = lds + L.gp + (wave * 32 + 4 * g) * 2 + c;
+      asm volatile("" : "+v"(pct), "+v"(pgp));
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int R = 16 * m + 4 * g + i;
           if (R < 20) {
-            lds[L.ct + R * 128 + col] = acc[m][i] + b5;
-            if (c < 2) lds[L.gp + (wave * 32 + R) * 2 + c] = ag[m][i];
+            pct[(16 * m + i) * 128] = acc[m][i] + b5;
+            if (c < 2) pgp[(16 * m + i) * 2] = ag[m][i];
           }
         }
     }
