@@ -152,6 +152,45 @@ def cpu_baseline_d2(workload, params_flat, fourier, chains, n_eval, K, seed=1):
                        f"composed into a {K + 1}-iteration cycle; float64 numpy oracle")
 
 
+def cpu_baseline_pines(params_flat, fourier, dim, hidden, chains, K, seed=1):
+    """Oracle on a bounded sample of the pines iteration (LGCP 32 x 32, hidden 1024): ONE MALA + train iteration on 256 chains
+    (scaled to `chains`) and one Hutchinson flow-MH step + train step on 32 chains (scaled), with the network the GPU run has
+    after its warm-up; composed into one (K + 1)-iteration cycle."""
+    import numpy as np
+    from oracle import flow, fm, loop, mala, optim, prng, targets
+    from oracle.vfield import VectorFieldNet
+    from tests import gpu_util as gu
+    n = int(round(dim ** 0.5))
+    counts = np.load(os.path.join(ROOT, "mfm_amd", "data", "pines_counts.npz"))[f"counts_{n}"]
+    nm, nf = min(256, chains), min(32, chains)
+    args = loop.default_args(example="pines", dim=dim, num_chain=nm, hutchs=True, step_size=0.01, seed=seed, mcmc_per_flow_steps=float(K),
+                             learning_iter=10000, hidden_x=[hidden] * 2, hidden_t=[hidden] * 2, hidden_xt=[hidden] * 2)
+    dist = targets.LogGaussianCoxPines(dim, counts)
+    dist.initialize_model(prng.PRNGKey(seed), nm)
+    model = VectorFieldNet(fourier, dist, args.hidden_x, args.hidden_t, args.hidden_xt, "relu", 1.0)
+    params = gu.unflat_params(model, params_flat)
+    state = optim.TrainState(params, optim.learning_rate_fn(10000, 0, 1e-3))
+    vg = targets.Tempered(dist, 1.0).value_and_grad
+    st = mala.init(dist.init_params, vg)
+    key = prng.PRNGKey(seed + 1)
+    key, k1, k2 = prng.split(key, 3)
+    t0 = time.perf_counter()
+    st, _, _ = mala.kernel(prng.split(k1, nm), st, vg, args.step_size)
+    loss, grads = fm.loss_and_grad(model, state.params, k2, st.position, args.sigma)
+    state.apply_gradients(grads)
+    t_mala = (time.perf_counter() - t0) * chains / nm
+    sub = mala.MALAState(st.position[:nf], st.logdensity[:nf], st.logdensity_grad[:nf])
+    stats = {}
+    t0 = time.perf_counter()
+    flow.rwmh_step(prng.split(key, nf), sub, vg, model, state.params, args, stats)
+    t_flow = (time.perf_counter() - t0) * chains / nf
+    cycle = K * t_mala + (t_flow + t_mala)
+    return dict(value=chains * (K + 1) / cycle,
+                sample=f"one MALA+train iteration on {nm} of {chains} chains (scaled: {t_mala:.2f}s), one Hutchinson flow-MH step on {nf} chains "
+                       f"(scaled: {t_flow:.1f}s, mean {float(stats['n_att_inv'].mean() + stats['n_att_fwd'].mean()):.1f} Dopri5 attempts), same network as the GPU "
+                       f"after warm-up; composed into a {K + 1}-iteration cycle; float64 numpy oracle")
+
+
 def usable_cores():
     """Host threads this process may actually use: CPU affinity capped by the cgroup CPU quota (a GPU box hands a job a share
     of its cores), not the machine's core count."""
@@ -180,14 +219,22 @@ def pmc_traffic(kernel_class, workload="phi-four"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc passes of this
     same command, tools/prof_round.sh): 2 * FETCH_SIZE + WRITE_SIZE, both reported in KB; the factor 2 is the gfx950
     correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section).  None when no summary is present."""
-    files = {"phi-four": ("profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"),    # newest committed summary first
-             "gaussian-mixture": ("profiles/r03_gmm_pmc_summary.json", "profiles/r02_gmm_pmc_summary.json"),
-             "4-mode": ("profiles/r03_4mode_pmc_summary.json", "profiles/r02_4mode_pmc_summary.json"),
+    files = {"phi-four": ("profiles/r04_pmc_summary.json", "profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"),    # newest committed summary first
+             "gaussian-mixture": ("profiles/r04_gmm_pmc_summary.json", "profiles/r03_gmm_pmc_summary.json", "profiles/r02_gmm_pmc_summary.json"),
+             "4-mode": ("profiles/r04_4mode_pmc_summary.json", "profiles/r03_4mode_pmc_summary.json", "profiles/r02_4mode_pmc_summary.json"),
              "pines": ("profiles/r03_pines_pmc_summary.json", "profiles/r02_pines_pmc_summary.json")}.get(workload, ())
     # kernel class -> what its kernel is called in the summaries (the d = 2 flow step runs d2::flow_kernel since round 3)
     patterns = {"fm_eval": ("fm_eval_kernel", "fm_eval64"), "flow_step": ("flow_step", "d2::flow_kernel")}.get(kernel_class, (kernel_class,))
     if workload == "pines":
-        return None, None      # its roofline entry is the whole training step (many launches): per-kernel traffic is in the summary file
+        # its roofline entry is the whole training step (many launches): the summary's `_fm_train_step` entry sums FETCH / WRITE
+        # over the dispatches from fm_prologue_kernel to adamw_vec_kernel of every training step of the PMC passes (tools/prof_workload.sh)
+        for rel in ("profiles/r04_pines_pmc_summary.json",):
+            try:
+                c = json.load(open(os.path.join(ROOT, rel)))["_fm_train_step"]
+                return int((2.0 * c["FETCH_SIZE"]["mean_per_step"] + c["WRITE_SIZE"]["mean_per_step"]) * 1024), rel
+            except Exception:
+                continue
+        return None, None
     for rel in files:
         try:
             d = json.load(open(os.path.join(ROOT, rel)))
@@ -377,6 +424,17 @@ def main():
     fence()
     prof_all = ctx.profile_read()
     ctx.profile(False)
+    # proof of what the collectives spanned (a SCALE record must show that RCCL saw N ranks, not N one-rank jobs): the process
+    # group's own size, and an all-reduce(SUM) of the rank ids, which is world (world - 1) / 2 only if every rank took part
+    comm = {"world": world, "backend": backend, "group_size": 1, "rank_id_sum": 0, "rank_id_sum_expected": 0, "ok": world == 1}
+    if td is not None:
+        ids = torch.tensor([float(rank), 1.0], device=eng.dev, dtype=torch.float64)
+        td.all_reduce(ids, op=td.ReduceOp.SUM)
+        comm.update(group_size=td.get_world_size(), rank_id_sum=int(ids[0].item()), ranks_counted=int(ids[1].item()),
+                    rank_id_sum_expected=world * (world - 1) // 2)
+        comm["ok"] = comm["group_size"] == world and comm["rank_id_sum"] == comm["rank_id_sum_expected"] and comm["ranks_counted"] == world
+        if getattr(eng, "rccl_in_lib", False):
+            comm["in_library_comm_ranks"] = eng.ctx.comm_count()
     if td is not None:
         tmax = torch.tensor([dt], device=eng.dev, dtype=torch.float64)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
@@ -448,14 +506,18 @@ def main():
             "kernels_ms_total": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in prof.items() if v["launches"]},
             "kernels_avg_us_instrumented_pass": {k: round(v["ms"] / v["launches"] * 1e3, 2) for k, v in prof_all.items() if v["launches"]},
             "counters": ctx.counters(),
+            "comm": comm,
         }
-        if world == 1 and not a.no_cpu_baseline and a.workload != "pines":
+        if world == 1 and not a.no_cpu_baseline:
             try:
                 from threadpoolctl import threadpool_limits
                 cores = usable_cores()
                 params_flat = ctx.get_params()
                 with threadpool_limits(limits=cores):
-                    if d2:
+                    if a.workload == "pines":
+                        cb = cpu_baseline_pines(params_flat, fourier, wl_dim, wl_h, chains=a.chains_per_gpu, K=wl_K)
+                        sample = cb.pop("sample")
+                    elif d2:
                         cb = cpu_baseline_d2(a.workload, params_flat, fourier, chains=a.chains_per_gpu, n_eval=n_eval, K=wl_K)
                         sample = cb.pop("sample")
                     else:

@@ -142,6 +142,8 @@ int mfm_adamw_step(mfm_ctx* ctx, const float* d_grads);
 int mfm_comm_unique_id(uint8_t out[MFM_COMM_ID_BYTES]);
 int mfm_comm_init(mfm_ctx* ctx, int nranks, int rank, const uint8_t id[MFM_COMM_ID_BYTES]);
 int mfm_comm_destroy(mfm_ctx* ctx);
+/* ranks of the context's communicator as RCCL reports them (ncclCommCount); 0 when the context owns none */
+int mfm_comm_count(mfm_ctx* ctx, int32_t* h_out);
 int mfm_grad_allreduce_begin(mfm_ctx* ctx, float* d_grads);
 /* host copies of {step, count, notfinite_count, last_applied} and the learning rate logged at :367 */
 int mfm_opt_state(mfm_ctx* ctx, int32_t h_out[4], float* h_last_lr);

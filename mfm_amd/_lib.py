@@ -66,6 +66,7 @@ _SIGS = {
     "mfm_comm_unique_id": (C.c_int, [_P]),
     "mfm_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "mfm_comm_destroy": (C.c_int, [_P]),
+    "mfm_comm_count": (C.c_int, [_P, _P]),
     "mfm_grad_allreduce_begin": (C.c_int, [_P, _P]),
     "mfm_opt_state": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "mfm_vf_apply": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
@@ -286,6 +287,12 @@ class Context:
     def comm_destroy(self):
         _chk(self.lib.mfm_comm_destroy(self.h))
         self.has_comm = False
+
+    def comm_count(self):
+        """Ranks of the context's communicator as RCCL reports them (ncclCommCount); 0 without one."""
+        n = C.c_int32(0)
+        _chk(self.lib.mfm_comm_count(self.h, C.byref(n)))
+        return int(n.value)
 
     def grad_allreduce_begin(self, grads):
         """Asynchronous SUM all-reduce of the gradient on the context's communication stream; the next adamw_step(grads) waits."""

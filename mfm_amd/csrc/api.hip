@@ -86,6 +86,7 @@ struct mfm_ctx {
   hipStream_t comm_stream = nullptr; hipEvent_t ev_grads = nullptr, ev_comm = nullptr;
   const float* comm_pending = nullptr;   // gradient buffer whose all-reduce is in flight on comm_stream
   FmMala fuse_mala = {};                 // on != 0 during a mfm_train_iter whose MALA step rides in the training kernel
+  int opt_resident_wgs = 0;              // workgroups of reduce_adamw_kernel this device holds at once (occupancy query at create)
 };
 
 struct ProfScope {
@@ -203,6 +204,17 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
                 c.chain_offset + c.n_chain_local, c.n_chain_total);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MFM_EHIP, "no HIP device available");
+  switches_read();                     // development / A-B switches: fixed from here until the next mfm_create (common.cuh)
+  {
+    // reduce_adamw_kernel's grid-wide exchange (taken when a gradient partial is huge or non-finite) spins until every workgroup
+    // of its grid has arrived: all of them must be RESIDENT at once.  Ask the runtime what this device (a full MI355X, a CPX
+    // partition, a CU-masked queue ...) and this build of the kernel actually hold, instead of assuming 256 CUs x 8 blocks.
+    int dev = 0, per_cu = 0, cus = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reduce_adamw_kernel, 256, 0));
+    x->opt_resident_wgs = per_cu * cus;
+  }
   x->cfg = c;
   build_net(c, x->net);
   build_ws(x->net, x->ws);
@@ -562,8 +574,11 @@ static AdamArgs adam_args(mfm_ctx* x, const float* grads, int n_slabs) {
 // one rank, tile family: slab reduction + apply_if_finite + AdamW as ONE launch behind the weight-gradient kernel (optim.hip:
 // reduce_adamw_kernel; every workgroup of its grid must be resident at once, hence the bound on the parameter count)
 static bool opt_fusable(mfm_ctx* x) {
-  const bool off = getenv("MFM_NO_FUSED_OPT") != nullptr;
-  return !off && !x->wide && !x->comm && x->cfg.n_chain_total == x->cfg.n_chain_local && x->net.n_params <= 300000;      // <= 1172 workgroups of 256: 57 % of the 2048 the chip holds at once (45 VGPRs, 8 waves per SIMD)
+  // the grid (one parameter per thread) may take at most HALF of the workgroup slots the occupancy query reported at create:
+  // margin for other queues' kernels and for a CU mask narrower than the device (headline: 837 of 2048 on a full MI355X; a
+  // 32-CU partition holds 256 and falls back to reduce_slabs + adamw)
+  const int grid = (x->net.n_params + 255) / 256;
+  return !g_sw.no_fused_opt && !x->wide && !x->comm && x->cfg.n_chain_total == x->cfg.n_chain_local && 2 * grid <= x->opt_resident_wgs;
 }
 
 static int fm_loss_grad_impl(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_pos, double* d_loss, float* d_grads, bool with_optimizer) {
@@ -582,7 +597,7 @@ static int fm_loss_grad_impl(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* 
     w.flag_partial = x->flag;                  // cleared by the training kernel (FmArgs::flags_clear)
     { ProfScope ps_(x, PROF_WGRAD); launch_wgrad(w, x->stream); }
     LAUNCHCHK();
-    const int force = getenv("MFM_DEBUG_FORCE_EXCHANGE") ? 1 : 0;      // tests: the grid-wide decision path on ordinary gradients
+    const int force = g_sw.force_exchange ? 1 : 0;      // tests: the grid-wide decision path on ordinary gradients
     ProfScope ps2_(x, PROF_ADAM);
     launch_reduce_adamw(adam_args(x, x->slabs, x->split), x->opt_alt, d_grads, x->loss_part, x->cfg.n_chain_local / 16, d_loss, force, x->stream);
     LAUNCHCHK();
@@ -616,6 +631,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*);
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
   ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*CommCount)(const ncclComm_t, int*);
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
   const char* (*GetErrorString)(ncclResult_t);
 };
@@ -631,9 +647,10 @@ static RcclApi* rccl_api() {
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+    api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
     api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
-    ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString;
+    ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.CommCount && api.AllReduce && api.GetErrorString;
     if (!ok) snprintf(why, sizeof why, "librccl.so.1 lacks an expected symbol");
   });
   g_rccl_why = why;
@@ -684,6 +701,19 @@ extern "C" int mfm_comm_init(mfm_ctx* x, int nranks, int rank, const uint8_t id_
   }
   if (rc != MFM_OK) { (void)mfm_comm_destroy(x); return rc; }      // nothing of a failed init survives: a retry starts clean
   x->comm_nranks = nranks;
+  return MFM_OK;
+}
+
+// Ranks of the context's communicator AS RCCL REPORTS THEM (ncclCommCount), 0 without a communicator: what a scaling record
+// cites to show that the all-reduce spanned N ranks.
+extern "C" int mfm_comm_count(mfm_ctx* x, int32_t* out) {
+  if (!x || !out) return fail(MFM_EINVAL, "null argument");
+  *out = 0;
+  if (!x->comm) return MFM_OK;
+  RcclApi* R = rccl_api();
+  int n = 0;
+  RCCLCHK(R->CommCount(x->comm, &n));
+  *out = n;
   return MFM_OK;
 }
 
@@ -739,12 +769,16 @@ extern "C" int mfm_train_iter(mfm_ctx* x, int64_t count, int K, int flow_mode, u
   if (K < 1) return fail(MFM_EINVAL, "mfm_train_iter serves mcmc_per_flow_steps >= 1; compose the other schedules from the separate calls");
   if (count < 0) return fail(MFM_EINVAL, "count must be non-negative");
   int rc;
-  static const bool no_fuse = getenv("MFM_NO_FUSED_MALA") != nullptr;
+  const bool no_fuse = g_sw.no_fused_mala;
   if (count % ((int64_t)K + 1) == 0) rc = mfm_flow_step(x, flow_mode, gk0, gk1, beta, d_pos, d_logp, d_grad, d_acc, nullptr, nullptr, d_nsteps);
   else if (x->has_target && !x->wide && !no_fuse && fm_mala_fusable(x->net)) {
     // the MALA step rides in the training kernel (fm.hip: fm_fwd_bwd_kernel<.., MALA>): same arithmetic, same draws, one launch less
     if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
     if (!(step_size > 0)) return fail(MFM_EINVAL, "step_size must be positive");
+    // everything fm_loss_grad_impl / fm_common would reject is rejected HERE, before the prefetched slot of this MALA step is
+    // consumed: an early error must leave the prefetch cursor where it was (a retry then finds its draws)
+    if (!d_loss || !d_grads) return fail(MFM_EINVAL, "null device pointer");
+    if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
     FmMala m; memset(&m, 0, sizeof m);
     m.on = 1; m.key = Key2{gk0, gk1}; m.beta = beta; m.eps = step_size; m.logp = d_logp; m.grad = d_grad; m.acc_prob = d_acc;
     const int slot = noise_take(x, m.key, false);
@@ -756,7 +790,8 @@ extern "C" int mfm_train_iter(mfm_ctx* x, int64_t count, int K, int flow_mode, u
     const bool with_opt = apply_update && opt_fusable(x);
     rc = fm_loss_grad_impl(x, tk0, tk1, d_pos, d_loss, d_grads, with_opt);
     x->fuse_mala.on = 0;
-    if (rc == MFM_OK) { x->ctr[CTR_MALA] += x->cfg.n_chain_local; x->ctr[CTR_MALA_BYTES] += (int64_t)x->cfg.n_chain_local * 4 * (5 * x->cfg.dim + 5); }
+    // the fused step reads x, g, logp and writes x, g, logp, acc: the proposed position never leaves the workgroup (4 (4d + 4) B)
+    if (rc == MFM_OK) { x->ctr[CTR_MALA] += x->cfg.n_chain_local; x->ctr[CTR_MALA_BYTES] += (int64_t)x->cfg.n_chain_local * 4 * (4 * x->cfg.dim + 4); }
     if (rc || !apply_update || with_opt) return rc;
     return mfm_adamw_step(x, d_grads);
   }
@@ -892,7 +927,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
   if (x->noise) {
     NoiseWs* w = x->noise;
     w->n_valid = 0;
-    const bool fast_path = !x->wide && fast::shape_ok(x->net, x->cfg.hutch) && !getenv("MFM_GENERIC_ODE");
+    const bool fast_path = !x->wide && fast::shape_ok(x->net, x->cfg.hutch) && !g_sw.generic_ode;
     if (w->n_armed > 0 && fast_path) {
       const int B = x->cfg.n_chain_local;
       nz.gn = w->d_keys; nz.st = w->d_keys + 2 * (size_t)w->n_armed; nz.n_slots = w->n_armed;

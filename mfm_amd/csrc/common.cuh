@@ -7,6 +7,36 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- development / A-B switches (environment) -----------------------------------------------------------------------------
+// Read ONCE PER mfm_create (api.hip: create_impl) and fixed from then until the next context is created: a switch flipped in
+// the environment between two calls on the same context has no effect, one flipped before mfm_create always does.  (They used
+// to be a mix of per-call getenv and function-local statics latched by the first call of the process, so an in-process A/B
+// could silently run the same arm twice.)  One context per process and GPU is the deployment model (include/mfm.h).
+#include <cstdlib>
+struct Switches {
+  bool no_fused_opt = false, force_exchange = false, no_fused_mala = false, generic_ode = false, generic_fm = false;
+  bool eval16 = false, eval_no_chain = false;
+  int eval_rows = 32, eval_stagger = 30000;
+  int d2_tile = 0;          // 0: automatic; 16: generic tile; 4: 4-chain tiles; 5: "4s", the streamed 4-chain tile
+  bool wide_nolds = false, wide_no_small_tiles = false, wide_wm1 = false, wide_ring8 = false, wide_wgrad_nosplit = false;
+  bool wide_nocompact = false, wide_no_tbatch = false;
+};
+static Switches g_sw;
+static void switches_read() {
+  Switches s;
+  auto on = [](const char* k) { return getenv(k) != nullptr; };
+  s.no_fused_opt = on("MFM_NO_FUSED_OPT"); s.force_exchange = on("MFM_DEBUG_FORCE_EXCHANGE"); s.no_fused_mala = on("MFM_NO_FUSED_MALA");
+  s.generic_ode = on("MFM_GENERIC_ODE"); s.generic_fm = on("MFM_GENERIC_FM");
+  s.eval16 = on("MFM_EVAL16"); s.eval_no_chain = on("MFM_EVAL_NO_CHAIN");
+  if (const char* e = getenv("MFM_EVAL_ROWS")) s.eval_rows = atoi(e);
+  if (const char* e = getenv("MFM_EVAL_STAGGER")) s.eval_stagger = atoi(e);
+  if (const char* e = getenv("MFM_D2_TILE")) s.d2_tile = (e[0] == '4' && e[1] == 's') ? 5 : atoi(e);
+  s.wide_nolds = on("MFM_WIDE_NOLDS"); s.wide_no_small_tiles = on("MFM_WIDE_NO_SMALL_TILES"); s.wide_wm1 = on("MFM_WIDE_WM1");
+  s.wide_ring8 = on("MFM_WIDE_RING8"); s.wide_wgrad_nosplit = on("MFM_WIDE_WGRAD_NOSPLIT");
+  s.wide_nocompact = on("MFM_WIDE_NOCOMPACT"); s.wide_no_tbatch = on("MFM_WIDE_NO_TBATCH");
+  g_sw = s;
+}
+
 // ---- wave-level reductions (64 lanes) -----------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

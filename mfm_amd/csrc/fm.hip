@@ -950,9 +950,8 @@ __global__ void reduce_loss_kernel(const double* part, int n, double* out, int a
 // ---- launchers ---------------------------------------------------------------------------------------------
 // number of per-workgroup loss partials the forward-only launch of `n` samples leaves in loss_part
 static int fm_eval_rows(const NetDev& n, int B) {      // samples per workgroup of the forward-only kernel (0: the 16-chain training tile)
-  if (n.dp > 16 || n.T.kind == MFM_TARGET_LGCP || B < 64 * 256 || getenv("MFM_EVAL16")) return 0;
-  const char* e = getenv("MFM_EVAL_ROWS");
-  const int r = e ? atoi(e) : 32;
+  if (n.dp > 16 || n.T.kind == MFM_TARGET_LGCP || B < 64 * 256 || g_sw.eval16) return 0;
+  const int r = g_sw.eval_rows;
   if ((r != 32 && r != 64) || (size_t)fm_eval_lds_layout(n, r).total * sizeof(float) > (r == 32 ? 80 : 160) * 1024) return 0;
   return r;
 }
@@ -977,11 +976,11 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
     hipLaunchKernelGGL((fm_eval_kernel<MT_, ACT_>), dim3((a.B + 16 * MT_ - 1) / (16 * MT_)), dim3(MLP_WAVES_FM * 64), smr, stream, a); \
   } while (0)
     FmArgs a2 = a;
-    { const char* e = getenv("MFM_EVAL_STAGGER"); a2.stagger_cycles = e ? atoi(e) : 30000; }       // measured: 1.023 -> 0.994 ms on 409,600 samples (any delay of 20 k .. 70 k cycles)
+    a2.stagger_cycles = g_sw.eval_stagger;       // measured: 1.023 -> 0.994 ms on 409,600 samples (any delay of 20 k .. 70 k cycles)
     const FmArgs& a = a2;
     const bool relu = a.net.act == MFM_ACT_RELU;
     // the 32-sample relu instance with its five full-width layers chained (0.997 -> 0.985 ms on 409,600 samples; same arithmetic)
-    bool chain = a.net.d == 2 && a.net.dp == 16 && getenv("MFM_EVAL_NO_CHAIN") == nullptr;
+    bool chain = a.net.d == 2 && a.net.dp == 16 && !g_sw.eval_no_chain;
     for (int l : {0, 1, 3, 5, 6}) chain &= a.net.L[l].Kp % 128 == 0 && a.net.L[l].Np == 16 * MLP_WAVES_FM;
     if (r == 32 && relu && chain) {
       (void)hipFuncSetAttribute((const void*)fm_eval_kernel<2, MFM_ACT_RELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr);
@@ -1010,7 +1009,7 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
   } while (0)
   const NetDev& n = a.net;
   bool headline = n.d == 256 && n.dp == 256 && n.F == 128 && n.F2p == 256 && n.ht1 == 128 && n.ht2 == 128 && n.hx1 == 128 &&
-                  n.hx2 == 128 && n.hj1 == 128 && n.hj2 == 128 && n.T.kind == MFM_TARGET_PHI4 && n.act == MFM_ACT_RELU && !getenv("MFM_GENERIC_FM");
+                  n.hx2 == 128 && n.hj1 == 128 && n.hj2 == 128 && n.T.kind == MFM_TARGET_PHI4 && n.act == MFM_ACT_RELU && !g_sw.generic_fm;
   static const int Kh[MLP_NLAYER] = {256, 128, 256, 128, 128, 256, 128, 128}, Nh[MLP_NLAYER] = {128, 128, 128, 128, 256, 128, 128, 256};
   for (int l = 0; l < MLP_NLAYER; ++l) headline &= n.L[l].K == Kh[l] && n.L[l].Kp == Kh[l] && n.L[l].N == Nh[l] && n.L[l].Np == Nh[l];
 #define FM_LAUNCH_S(TR)                                                                                    \

@@ -1252,7 +1252,7 @@ int launch_ode_transform(const OdeArgs& a, hipStream_t stream) {
   if (ode_check(a.net, sm, tpw)) return -3;
   if (a.hutch) launch_probe(a.per_chain_keys ? 0 : 1, a.keys, a.key, 0, 0, 0, a.n, a.net.d, const_cast<float*>(a.z1), stream);
   if (d2::use_for(a.net, a.hutch, a.n)) return d2::launch_transform(a, stream);
-  if (fast::shape_ok(a.net, a.hutch) && !getenv("MFM_GENERIC_ODE"))
+  if (fast::shape_ok(a.net, a.hutch) && !g_sw.generic_ode)
     return a.net.d == 256 ? fast::launch_transform_t<256>(a, a.fast_scr, stream) : fast::launch_transform_t<128>(a, a.fast_scr, stream);
   ODE_LAUNCH(ode_transform_kernel, dim3(a.n / 16), a);
   return 0;
@@ -1272,7 +1272,7 @@ int launch_flow_step(const OdeArgs& a, const FlowArgs& f, const NoiseArgs& nz, h
     launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 2, a.n, a.net.d, const_cast<float*>(a.z2), stream);     // key_hutch1
   }
   if (d2::use_for(a.net, a.hutch, a.n)) return d2::launch_flow(a, f, stream);
-  if (fast::shape_ok(a.net, a.hutch) && !getenv("MFM_GENERIC_ODE"))
+  if (fast::shape_ok(a.net, a.hutch) && !g_sw.generic_ode)
     return a.net.d == 256 ? fast::launch_flow_t<256>(a, f, nz, a.fast_scr, stream) : fast::launch_flow_t<128>(a, f, nz, a.fast_scr, stream);
   ODE_LAUNCH(flow_step_kernel, dim3(a.n / 16), a, f);
   return 0;

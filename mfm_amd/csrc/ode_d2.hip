@@ -707,9 +707,9 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(OdeArgs a, FlowArgs f) {
 // 4-chain tiles, 4s the streamed instance of them even where the resident one fits.
 static int pick(const NetDev& n, int hutch, int rows) {       // 0: generic 16-chain tile, 1: streamed 4-chain, 2: resident 4-chain
   if (!shape_ok(n, hutch)) return 0;
-  const char* e = getenv("MFM_D2_TILE");
-  if (e && atoi(e) == 16) return 0;
-  if (e && e[0] == '4' && e[1] == 's') return 1;
+  const int e = g_sw.d2_tile;
+  if (e == 16) return 0;
+  if (e == 5) return 1;
   if (shape_ok_r(n, hutch)) return 2;
   return (e || rows / 16 < 256) ? 1 : 0;
 }

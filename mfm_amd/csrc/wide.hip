@@ -366,12 +366,12 @@ static void launch_gemm(const Gemm& a, hipStream_t s) {
   // tall launches (the batched time branch: 5 x rows) without whole 128-wide K steps keep round 1's 128 x 64 register-only tile;
   // wherever the LDS-staged kernel applies it is the faster one at every height (pines flow step 54.4 -> 51.8 ms when the batched
   // time-branch GEMMs moved to it)
-  static const bool no_lds_any = getenv("MFM_WIDE_NOLDS") != nullptr;
+  const bool no_lds_any = g_sw.wide_nolds;
   const bool big = (long long)MT * a.NT >= 4 * 4096 && !dual && (no_lds_any || (a.KB & 7) != 0);
   if (big) {
     dim3 grid((a.NT + 3) / 4, (MT + 7) / 8);
     hipLaunchKernelGGL((gemm_kernel<4, 2, false>), grid, dim3(256), 0, s, a);
-  } else if (a.rows <= 512 && !getenv("MFM_WIDE_NO_SMALL_TILES")) {
+  } else if (a.rows <= 512 && !g_sw.wide_no_small_tiles) {
     // few rows (the compacted attempts of a solve's tail, small batches): with 64 x 64 workgroup tiles a 256-row layer is 64
     // workgroups on 256 CUs and lasts as long as the 1024-row one.  Smaller tiles of the register-only kernel keep the chip
     // covered: 32 rows x 64 features up to 512 rows, 32 x 32 up to 256.
@@ -388,9 +388,9 @@ static void launch_gemm(const Gemm& a, hipStream_t s) {
     dim3 grid((a.NT + 3) / 4, (MT + 3) / 4);
     // the LDS-staged kernel needs an even number of whole 64-wide K steps (every width of the reference's pines networks); MFM_WIDE_NOLDS=1
     // keeps the register-only kernel for A/B measurements
-    static const bool no_lds = getenv("MFM_WIDE_NOLDS") != nullptr;
+    const bool no_lds = g_sw.wide_nolds;
     const bool lds = !no_lds && (a.KB & 7) == 0 && (!dual || ((a.KBT & 3) == 0 && a.KBT >= 4));
-    static const bool wm2 = getenv("MFM_WIDE_WM1") == nullptr;    // eight waves (two per SIMD) by default: 37.0 k vs 40.6 k cycles on 1024^3
+    const bool wm2 = !g_sw.wide_wm1;    // eight waves (two per SIMD) by default: 37.0 k vs 40.6 k cycles on 1024^3
     if (lds && wm2) {
       if (dual) hipLaunchKernelGGL((gemm_lds_kernel<true, 2>), grid, dim3(512), 0, s, a);
       else hipLaunchKernelGGL((gemm_lds_kernel<false, 2>), grid, dim3(512), 0, s, a);
@@ -398,10 +398,10 @@ static void launch_gemm(const Gemm& a, hipStream_t s) {
       if (dual) hipLaunchKernelGGL((gemm_lds_kernel<true, 1>), grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL((gemm_lds_kernel<false, 1>), grid, dim3(256), 0, s, a);
     } else if (dual) {
-      if (a.KB % 8 == 0 && a.KBT % 8 == 0 && getenv("MFM_WIDE_RING8")) hipLaunchKernelGGL((gemm_kernel<2, 2, true, 8>), grid, dim3(256), 0, s, a);
+      if (a.KB % 8 == 0 && a.KBT % 8 == 0 && g_sw.wide_ring8) hipLaunchKernelGGL((gemm_kernel<2, 2, true, 8>), grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL((gemm_kernel<2, 2, true>), grid, dim3(256), 0, s, a);
     } else {
-      if (a.KB % 8 == 0 && getenv("MFM_WIDE_RING8")) hipLaunchKernelGGL((gemm_kernel<2, 2, false, 8>), grid, dim3(256), 0, s, a);
+      if (a.KB % 8 == 0 && g_sw.wide_ring8) hipLaunchKernelGGL((gemm_kernel<2, 2, false, 8>), grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL((gemm_kernel<2, 2, false>), grid, dim3(256), 0, s, a);
     }
   }
@@ -1381,7 +1381,7 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
   a.jobs = w->jobs; a.n_jobs = w->n_jobs; a.rows = rows; a.grads = d_grads; a.bad = c.bad;
   // what does not fill the chip's 2048 wave slots a whole number of times, if it is a tail of at most one workgroup per CU
   const int rem = w->n_jobs % 2048;
-  const bool tail = w->n_jobs > 2048 && rem > 0 && rem <= 256 && rows % 64 == 0 && !getenv("MFM_WIDE_WGRAD_NOSPLIT");
+  const bool tail = w->n_jobs > 2048 && rem > 0 && rem <= 256 && rows % 64 == 0 && !g_sw.wide_wgrad_nosplit;
   a.n_full = tail ? w->n_jobs - rem : (w->n_jobs + 3) / 4 * 4;
   hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_full / 4 + (tail ? rem : 0)), dim3(256), 0, s, a);
   return 0;
@@ -1438,8 +1438,8 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
   // ceil16(active) rows, stage_finish reads chain b's results from row cpos[b]; per-solve constants the GEMMs take per row
   // (z W_x1) are gathered once per attempt, the element-wise target kernel follows the map.  The number of rows is the
   // read-back the loop already makes.
-  static const bool no_compact = getenv("MFM_WIDE_NOCOMPACT") != nullptr;
-  static const bool no_tbatch = getenv("MFM_WIDE_NO_TBATCH") != nullptr;
+  const bool no_compact = g_sw.wide_nocompact;
+  const bool no_tbatch = g_sw.wide_no_tbatch;
   for (int it = 0; active > 0 && it < c.max_attempts; ++it) {
     if (hipMemsetAsync(w->n_active, 0, sizeof(int), s) != hipSuccess) return -4;
     int rc = rows;

@@ -29,6 +29,26 @@ tot = collections.defaultdict(float)
 for k, cs in acc.items():
     for c, v in cs.items(): tot[c] += v
 res["_all_kernels_total"] = {c: v for c, v in tot.items()}
+# the wide family's training step is many launches (bench.py's roofline entry for pines is the whole step): sum the counters over the
+# dispatches from fm_prologue_kernel to adamw_vec_kernel, in dispatch order, per PMC pass
+seg = collections.defaultdict(float); nseg = 0
+for f in glob.glob(out + "/p*/*/*counter_collection.csv"):
+    disp = collections.OrderedDict()
+    for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"])):
+        d = disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "c": collections.defaultdict(float)})
+        d["c"][r["Counter_Name"]] += float(r["Counter_Value"])
+    inside, cur, nst = False, None, 0
+    for d in disp.values():
+        k = d["name"]
+        if k.startswith("void at::") or k.startswith("__amd"): continue
+        if "fm_prologue_kernel" in k: inside, cur = True, collections.defaultdict(float)
+        if inside:
+            for c, v in d["c"].items(): cur[c] += v
+        if inside and "adamw_vec_kernel" in k:
+            inside = False; nst += 1
+            for c, v in cur.items(): seg[c] += v
+    for c in set(c for d in disp.values() for c in d["c"]): res.setdefault("_fm_train_step", {}).setdefault(c, {"steps": 0})["steps"] += nst
+for c, v in seg.items(): res["_fm_train_step"][c]["mean_per_step"] = v / max(1, res["_fm_train_step"][c]["steps"])
 res["_run"] = {"bench_steps": steps, "bench_warmup": warm, "note": "totals cover every launch of the run (bench priming + state preparation + warm-up + timed + instrumented iterations)"}
 json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1)
 for k, cs in sorted(res.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", {}).get("total", 0) if isinstance(kv[1].get("FETCH_SIZE"), dict) else 0)[:6]:
