@@ -73,7 +73,7 @@ struct mfm_ctx {
   OptState* opt; int* flag;      // opt: the CURRENT optimizer scalars (opt_alt: the buffer the one-launch reduction + optimizer writes next)
   OptState* opt_alt;
   const float* checked_grads = nullptr;   // gradient whose finite check already sits in flag[0] (single-rank mfm_fm_loss_grad)
-  float *gmm_mode, *gmm_std, *gmm_logw, *counts, *Kinv, *kbias;
+  float *gmm_mode, *gmm_std, *gmm_logw, *counts, *Kinv, *kbias, *kdiag;
   OdeWs ode;
   Replay replay;               // armed by mfm_debug_replay for the NEXT mfm_ode_transform / mfm_flow_step (dt == nullptr: off)
   int64_t ctr[8];              // mfm_get_counters: host-side tallies (slot 4, the attempted Dopri5 steps, is summed on the device)
@@ -232,10 +232,6 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
     if (!fits) use_wide = true;
   }
   if (c.kernel_family < 0 || c.kernel_family > MFM_FAMILY_WIDE) return fail(MFM_EINVAL, "unknown kernel_family %d", c.kernel_family);
-  if (use_wide && !c.hutch) {
-    return fail(MFM_EUNSUPPORTED, "the wide kernel family integrates the log-det with the Hutchinson estimator only (--hutch); "
-                                  "the exact trace needs dim tangent passes per evaluation");
-  }
   const int nbb = c.n_chain_local / 16;
   x->split = nbb < 8 ? nbb : 8;
   if (const char* e = getenv("MFM_WGRAD_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= nbb) x->split = v; }      // development: A/B
@@ -269,6 +265,8 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
   if (use_wide) {
     rc = wide::create(n, c.n_chain_local, &x->wide);
     if (rc) return fail(rc, "workspace allocation of the wide kernel family failed");
+    x->wide->exact = !c.hutch;           // exact-trace log-det (exe_flow_matching.py:216-217,236-237): wide.hip, exact_trace()
+    x->wide->master = x->master;         // ... which reads two kernels in their canonical [in][out] layout
   }
   return MFM_OK;
 }
@@ -277,7 +275,7 @@ extern "C" int mfm_destroy(mfm_ctx* x) {
   if (!x) return MFM_OK;
   hipDeviceSynchronize();
   void* ps[] = {x->master, x->mu, x->nu, x->Wp, x->WpT, x->bias, x->fourier, x->acts, x->dzs, x->dacts, x->slabs, x->loss_part,
-                x->jobs, x->opt, x->opt_alt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->beta_out,
+                x->jobs, x->opt, x->opt_alt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->kdiag, x->beta_out,
                 x->d_att, x->att_buf};
   for (void* p : ps) if (p) hipFree(p);
   (void)mfm_comm_destroy(x);
@@ -339,12 +337,17 @@ extern "C" int mfm_set_target(mfm_ctx* x, int kind, const double* p, size_t np) 
       for (int k = 0; k < d; ++k) rs += Kinv[(size_t)k * d + j];
       kb[j] = (float)(-mu * rs);
     }
-    for (float** q : {&x->counts, &x->Kinv, &x->kbias}) if (*q) { hipFree(*q); *q = nullptr; }
-    ALLOC(x->counts, dp); ALLOC(x->kbias, dp); ALLOC(x->Kinv, (size_t)dp * dp);
+    for (float** q : {&x->counts, &x->Kinv, &x->kbias, &x->kdiag}) if (*q) { hipFree(*q); *q = nullptr; }
+    ALLOC(x->counts, dp); ALLOC(x->kbias, dp); ALLOC(x->kdiag, dp); ALLOC(x->Kinv, (size_t)dp * dp);
+    {
+      std::vector<float> kd(dp, 0.f);
+      for (int j = 0; j < d; ++j) kd[j] = (float)Kinv[(size_t)j * d + j];
+      HIPCHK(hipMemcpy(x->kdiag, kd.data(), dp * 4, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(x->counts, cnt.data(), dp * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(x->kbias, kb.data(), dp * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(x->Kinv, kp.data(), (size_t)dp * dp * 4, hipMemcpyHostToDevice));
-    T.counts = x->counts; T.KinvP = x->Kinv; T.kbias = x->kbias;
+    T.counts = x->counts; T.KinvP = x->Kinv; T.kbias = x->kbias; T.kdiag = x->kdiag;
     T.mu = (float)mu; T.poisson_a = (float)p[1]; T.log_norm = (float)p[2];
     // the K^-1 tile buffers must fit next to the MLP tiles
     const FmLds Lf = fm_lds_layout(x->net, true);

@@ -27,6 +27,7 @@ struct TargetDev {
   const float* counts;     // [dp] (zero padded)
   const float* KinvP;      // K^-1 packed like an MLP layer (K = N = d; symmetric, so one packing serves both uses)
   const float* kbias;      // [dp]: -mu * rowsum(K^-1), so that x . K^-1 + kbias = K^-1 (x - mu)
+  const float* kdiag;      // [dp]: diag(K^-1) (the Hessian diagonal of the exact-trace log-det, wide.hip)
   float mu, poisson_a, log_norm;
 };
 

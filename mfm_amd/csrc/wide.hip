@@ -44,6 +44,9 @@ struct Gemm {
   const float* mask; int ldm, mcol;      // backward: y = pre * act'(.) with act' from the stored OUTPUT (relu / tanh / elu)
   int mask_kind, mask_is_pre;            // ... or from the stored PRE-ACTIVATION (mask_is_pre)
   const float* add; int lda, acol;       // backward: pre += add (second contribution to the same activation)
+  int KBW;                               // k-blocks per N tile in the PACKED weights when the product spans only the first KB of them
+                                         // (the sx half of the joint layer's input); 0: = KB
+  int mask_rdiv;                         // > 1: mask row = row / mask_rdiv (exact trace: hx1 tangent rows per chain share the chain's mask row)
 };
 
 // Epilogue shared by the GEMM kernels: lane (g, c) holds features 16 nt + 4 g .. + 3 of row 16 mt + c.
@@ -63,7 +66,8 @@ __device__ __forceinline__ void gemm_epilogue(const Gemm& a, f32x4 (&acc)[NTW][M
       f32x4 pre = acc[j][m] + bv;
       if (a.add) pre += *reinterpret_cast<const f32x4*>(a.add + row * a.lda + a.acol + f0);
       if (a.mask) {
-        const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + row * a.ldm + a.mcol + f0);
+        const size_t mrow = a.mask_rdiv > 1 ? row / (size_t)a.mask_rdiv : row;
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + mrow * a.ldm + a.mcol + f0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) pre[i] = a.mask_is_pre ? mask_pre(mk[i], pre[i], a.mask_kind) : mask_out(mk[i], pre[i], a.mask_kind);
       }
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm a) {
   const float* xp[MTW];
   const float* xtp[MTW];
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) wp[j] = reinterpret_cast<const f32x4*>(a.W) + (size_t)(nt0 + j < a.NT ? nt0 + j : nt0) * a.KB * 64 + lane;
+  for (int j = 0; j < NTW; ++j) wp[j] = reinterpret_cast<const f32x4*>(a.W) + (size_t)(nt0 + j < a.NT ? nt0 + j : nt0) * (a.KBW ? a.KBW : a.KB) * 64 + lane;
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
     const size_t row = (size_t)(mt0 + m < MT ? mt0 + m : mt0) * 16 + c;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256 * WM) void gemm_lds_kernel(Gemm a) {
   // Operands through buffer descriptors: per-lane offsets are loop constants, the k position is a SCALAR offset (no vector
   // address arithmetic between the MFMAs) and reads past the end of a descriptor return zeros (no clamps)
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.W) + (size_t)(nt < a.NT ? nt : a.NT - 1) * a.KB * 256, 0, a.KB * 1024, 0x00020000);
+      const_cast<float*>(a.W) + (size_t)(nt < a.NT ? nt : a.NT - 1) * (a.KBW ? a.KBW : a.KB) * 256, 0, a.KB * 1024, 0x00020000);
   const int wvo = lane * 16;
   // staging role of this thread: rows sr + 16 WM p (p = 0..NP-1), 4 floats at column sc of the step's 64
   const int sr = tid >> 4, sc = (tid & 15) * 4;
@@ -593,6 +597,7 @@ struct TgtArgs {
   const float* X; const float* Z; const float* KV; const float* KZ;
   float* GC; float* HZ;
   const int* cmap;          // non-null: X / KV / GC / HZ rows are COMPACT (row j = chain cmap[j]); Z / KZ stay indexed by chain
+  int diag;                 // exact trace: HZ = 1[|g| <= clip] * H_ii, the DIAGONAL of the target's Hessian (Z, KZ unused)
 };
 __global__ __launch_bounds__(256) void target_kernel(TgtArgs a) {
   const size_t n = (size_t)a.rows * a.dp;
@@ -607,14 +612,16 @@ __global__ __launch_bounds__(256) void target_kernel(TgtArgs a) {
       if (a.T.kind == MFM_TARGET_PHI4) {
         const float xl = col > 0 ? a.X[idx - 1] : 0.f, xr = col + 1 < a.d ? a.X[idx + 1] : 0.f;
         graw = -a.T.tbeta * (a.T.coef * (2.f * x - xl - xr) - x * (1.f - x * x) / a.T.coef);
-        if (a.Z) {
+        if (a.diag) hraw = -a.T.tbeta * (a.T.coef * 2.f - (1.f - 3.f * x * x) / a.T.coef);
+        else if (a.Z) {
           const float v = a.Z[zi], vl = col > 0 ? a.Z[zi - 1] : 0.f, vr = col + 1 < a.d ? a.Z[zi + 1] : 0.f;
           hraw = -a.T.tbeta * (a.T.coef * (2.f * v - vl - vr) - (1.f - 3.f * x * x) * v / a.T.coef);
         }
       } else {
         const float ex = a.T.poisson_a * expf(x);
         graw = a.T.counts[col] - ex - a.KV[idx];
-        if (a.Z) hraw = -ex * a.Z[zi] - a.KZ[zi];
+        if (a.diag) hraw = -ex - a.T.kdiag[col];
+        else if (a.Z) hraw = -ex * a.Z[zi] - a.KZ[zi];
       }
       gc = clipf(graw, a.clip);
       const bool inside = !(a.clip > 0.f) || fabsf(graw) <= a.clip;
@@ -695,6 +702,7 @@ struct WReplay {
   __device__ __forceinline__ size_t at(int row, int j) const { return ((size_t)solve * n + row0 + row) * cap + j; }
 };
 
+constexpr int JT_SLICES = 8;          // partial sums per chain of the exact Jacobian trace (jt_trace_kernel), added in index order
 struct OdeBuf {
   int rows, d, dp, F, F2p, sign;
   float rtol, atol; int max_attempts;
@@ -708,6 +716,8 @@ struct OdeBuf {
   const float* out; const float* outT; const float* gate; const float* gc; const float* hz;   // results of the evaluation
   int* n_active;
   const int* cpos;     // non-null: chain b's row in the COMPACT evaluation buffers (X, ffat, out, outT, gate, gc, hz), -1: not integrating
+  const float* trp;    // non-null: EXACT trace (exe_flow_matching.py:216-217) -- trp[cp * JT_SLICES + s] = partial sums of trace(d nn_xt / d x)
+                       // of compact row cp (jt_trace_kernel), hz = the masked Hessian DIAGONAL; Z is null
   int tb_rows;         // > 0: time-branch batching -- at phase 2 stage_prep writes the Fourier rows of the attempt's FIVE distinct stage
                        // times to ffat[(s * tb_rows + row)] (slot s), and no Fourier rows in the other phases
   WReplay rp;
@@ -801,8 +811,13 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(OdeBuf a, int phase) 
     const T v = V::ld(a.out + e) + gt * V::ld(a.gc + e);
     V::st(a.K + dst * ks + o, a.sign > 0 ? v : -v);
     if (a.Z) dpart += V::sum(V::ld(a.Z + o) * (V::ld(a.outT + e) + gt * V::ld(a.hz + e)));
+    else if (a.trp) dpart += V::sum(gt * V::ld(a.hz + e));      // d/dx_i [gate_i clip(g_i(x))] = gate_i 1[|g_i| <= clip] H_ii
   }
   dpart = wave_sum(dpart);
+  if (a.trp) {
+#pragma unroll
+    for (int sl = 0; sl < JT_SLICES; ++sl) dpart += a.trp[(size_t)cp * JT_SLICES + sl];      // fixed order: deterministic
+  }
   const float dl = a.sign > 0 ? -dpart : dpart;                 // :218 / :239
   if (lane == 0) a.rs.kl[dst * R + b] = dl;
   const float atol = a.atol, rtol = a.rtol;
@@ -1160,6 +1175,61 @@ __global__ __launch_bounds__(256) void lgcp_accept_kernel(LgcpMala a) {
   if (lane == 0 && acc) a.logp[b] = lpn;
 }
 
+// ---- EXACT trace of the Jacobian (exe_flow_matching.py:216-217, :236-237: jnp.trace(jax.jacfwd(v)(x))) --------------------------
+// The reference pushes the d basis vectors through the network.  With row vectors, d nn_xt / d x = W_x1 D1 W_x2 D2 W_j1x D3 W_j2 D4
+// W_out (D_l = diag act'(pre-activation of layer l) of the chain, W_j1x = the sx rows of the joint layer), and the trace is cyclic:
+//     trace = tr( D1 W_x2 D2 W_j1x D3 W_j2 D4 E ),   E = W_out W_x1  [hj2 x hx1], computed once per solve,
+// i.e. hx1 tangent rows per chain instead of d, none of them through the two d-wide layers: row i starts as D1[i] W_x2[i, :] D2
+// (jt_seed_kernel: element-wise), takes two GEMMs with the chain's masks in the epilogue (the layer GEMM kernels; mask_rdiv maps
+// the hx1 rows of a chain to its mask row) and is contracted with column i of E (jt_trace_kernel).  Per chain and evaluation
+// 2 hx1 (hx2 hj1 + hj1 hj2) flop -- 4.3 GFLOP at hidden 1024, whatever d is (d-tangent form: 10 GFLOP at d = 1600).  The gate term
+// of the field, gate_i clip(g_i(x)), adds gate_i 1[|g_i| <= clip] H_ii (target_kernel's diag mode; stage_finish sums it).
+struct JtSeed { int chains, hx1, hx2, row0; const float* W; const float* m1; int ld1; const float* m2; int ld2; int kind, is_pre; float* X; };
+__global__ __launch_bounds__(256) void jt_seed_kernel(JtSeed a) {
+  const int c4 = a.hx2 / 4;
+  const size_t tot = (size_t)a.chains * a.hx1 * c4;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * 256) {
+    const int j4 = (int)(idx % c4);
+    const size_t r = idx / c4;
+    const int i = (int)(r % a.hx1), b = (int)(r / a.hx1);
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.W + (size_t)i * a.hx2 + 4 * j4);
+    const float s1 = a.m1[(size_t)(a.row0 + b) * a.ld1 + i];
+    const f32x4 s2 = *reinterpret_cast<const f32x4*>(a.m2 + (size_t)(a.row0 + b) * a.ld2 + 4 * j4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = a.is_pre ? mask_pre(s1, v[j], a.kind) : mask_out(s1, v[j], a.kind);
+      v[j] = a.is_pre ? mask_pre(s2[j], v[j], a.kind) : mask_out(s2[j], v[j], a.kind);
+    }
+    *reinterpret_cast<f32x4*>(a.X + r * a.hx2 + 4 * j4) = v;
+  }
+}
+struct JtTrace { int hx1, hj2, row0; const float* Y; const float* ET; float* trp; };
+__global__ __launch_bounds__(256) void jt_trace_kernel(JtTrace a) {      // grid (JT_SLICES, chains of the chunk)
+  __shared__ double sm[4];
+  const int b = blockIdx.y, sl = blockIdx.x, c4 = a.hj2 / 4;
+  const int i0 = (int)((long long)a.hx1 * sl / JT_SLICES), i1 = (int)((long long)a.hx1 * (sl + 1) / JT_SLICES);
+  float acc = 0.f;
+  for (size_t idx = threadIdx.x; idx < (size_t)(i1 - i0) * c4; idx += 256) {
+    const int i = i0 + (int)(idx / c4), k4 = (int)(idx % c4);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(a.Y + ((size_t)b * a.hx1 + i) * a.hj2 + 4 * k4);
+    const f32x4 e = *reinterpret_cast<const f32x4*>(a.ET + (size_t)i * a.hj2 + 4 * k4);
+    acc += (y[0] * e[0] + y[1] * e[1]) + (y[2] * e[2] + y[3] * e[3]);
+  }
+  const double s = wave_sum((double)acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) a.trp[(size_t)(a.row0 + b) * JT_SLICES + sl] = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
+}
+__global__ void transpose_kernel(const float* src, int R, int C, float* dst) {      // dst[c][r] = src[r][c]
+  __shared__ float t[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+    if (r0 + j < R && c0 + tx < C) t[j][tx] = src[(size_t)(r0 + j) * C + c0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < C && r0 + tx < R) dst[(size_t)(c0 + j) * R + r0 + tx] = t[tx][j];
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1185,6 +1255,9 @@ struct Ctx {
   int *cmap = nullptr, *cpos = nullptr; float* tz1c = nullptr; const float* tz1_use = nullptr; const int* cmap_use = nullptr;
   // time-branch batch of an attempt (five stage times): Fourier rows, t1, [sx | st], gate, each 5 R rows
   float *ffat5 = nullptr, *t15 = nullptr, *cat5 = nullptr, *gate5 = nullptr;
+  // exact-trace log-det (no --hutch): set by mfm_create; buffers allocated by the first solve that needs them
+  bool exact = false; const float* master = nullptr;
+  float *jtA = nullptr, *jtB = nullptr, *jtE = nullptr, *jtET = nullptr, *jtWo = nullptr, *jtP = nullptr; int jt_chains = 0;
 };
 
 static int create(const NetDev& n, int rows_cap, Ctx** out) {
@@ -1255,6 +1328,7 @@ static void destroy(Ctx* w) {
   if (w->cmap) (void)hipFree(w->cmap);
   if (w->tz1c) (void)hipFree(w->tz1c);
   if (w->ffat5) (void)hipFree(w->ffat5);
+  for (float* p : {w->jtA, w->jtB, w->jtE, w->jtET, w->jtWo, w->jtP}) if (p) (void)hipFree(p);
   delete w;
 }
 
@@ -1281,10 +1355,11 @@ static Gemm kinv(const NetDev& n, const float* X, float* Y, int rows, bool with_
 static int grid4(int rows) { return (rows + 3) / 4; }
 static int grid_el(size_t n) { size_t b = (n + 255) / 256; return (int)(b < 4096 ? b : 4096); }
 
-static void target_eval(Ctx* w, const NetDev& n, const float* X, const float* Z, int rows, hipStream_t s) {
+static void target_eval(Ctx* w, const NetDev& n, const float* X, const float* Z, int rows, hipStream_t s, bool diag = false) {
   if (n.T.kind == MFM_TARGET_LGCP) launch_gemm(kinv(n, X, w->kv, rows, true), s);
   TgtArgs t; memset(&t, 0, sizeof t);
-  t.T = n.T; t.clip = n.grad_clip; t.rows = rows; t.d = n.d; t.dp = n.dp; t.X = X; t.Z = Z; t.KV = w->kv; t.KZ = w->kz; t.GC = w->gc; t.HZ = Z ? w->hz : nullptr;
+  t.T = n.T; t.clip = n.grad_clip; t.rows = rows; t.d = n.d; t.dp = n.dp; t.X = X; t.Z = Z; t.KV = w->kv; t.KZ = w->kz; t.GC = w->gc; t.HZ = (Z || diag) ? w->hz : nullptr;
+  t.diag = diag ? 1 : 0;
   t.cmap = w->cmap_use;
   hipLaunchKernelGGL(target_kernel, dim3(grid_el((size_t)rows * n.dp)), dim3(256), 0, s, t);
 }
@@ -1387,11 +1462,66 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
   return 0;
 }
 
+// ---- exact trace of d nn_xt / d x for the `rows` (compact) rows of the evaluation x_branch has just run: see jt_seed_kernel ----
+constexpr int JT_ROWS_CAP = 131072;      // tangent rows per pass (128 chains x hx1 = 1024): two buffers of rows x max(hx2, hj1, hj2) floats
+static int jt_alloc(Ctx* w, const NetDev& n) {
+  if (w->jtA) return 0;
+  int chains = JT_ROWS_CAP / n.hx1;
+  if (chains < 1) chains = 1;
+  if (chains > w->R) chains = w->R;
+  const size_t rows = (size_t)chains * n.hx1;
+  size_t hmax = n.hx2 > n.hj1 ? n.hx2 : n.hj1;
+  if ((size_t)n.hj2 > hmax) hmax = n.hj2;
+  if (hipMalloc((void**)&w->jtA, rows * hmax * sizeof(float)) != hipSuccess) return -4;
+  if (hipMalloc((void**)&w->jtB, rows * hmax * sizeof(float)) != hipSuccess) return -4;
+  if (hipMalloc((void**)&w->jtE, (size_t)n.hj2 * n.hx1 * sizeof(float)) != hipSuccess) return -4;
+  if (hipMalloc((void**)&w->jtET, (size_t)n.hj2 * n.hx1 * sizeof(float)) != hipSuccess) return -4;
+  if (hipMalloc((void**)&w->jtWo, (size_t)n.hj2 * n.dp * sizeof(float)) != hipSuccess) return -4;
+  if (hipMalloc((void**)&w->jtP, (size_t)w->R * JT_SLICES * sizeof(float)) != hipSuccess) return -4;
+  w->jt_chains = chains;
+  return 0;
+}
+// E^T, E = W_out W_x1 (the parameters do not change inside a solve): rows of the canonical out kernel [hj2][d] as the "activations"
+// of the x1 layer's packed weights, then a transpose so that jt_trace_kernel reads row i of E^T beside tangent row i
+static void jt_setup(Ctx* w, const NetDev& n, hipStream_t s) {
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_el((size_t)n.hj2 * n.dp)), dim3(256), 0, s, w->master + n.L[7].m_w, n.hj2, n.d, n.dp, w->jtWo);
+  Gemm g = fwd(n, 2, w->jtWo, n.dp, w->jtE, n.hx1, 0, n.hj2, 0);
+  g.bias = nullptr;
+  launch_gemm(g, s);
+  hipLaunchKernelGGL(transpose_kernel, dim3((n.hx1 + 31) / 32, (n.hj2 + 31) / 32), dim3(256), 0, s, w->jtE, n.hj2, n.hx1, w->jtET);
+}
+static void exact_trace(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
+  const bool pre = n.act >= MFM_ACT_GELU;       // act' from the stored pre-activations (gelu, swish) or from the stored outputs
+  for (int r0 = 0; r0 < rows; r0 += w->jt_chains) {
+    const int C = rows - r0 < w->jt_chains ? rows - r0 : w->jt_chains;
+    const int trows = C * n.hx1;
+    JtSeed sd; memset(&sd, 0, sizeof sd);
+    sd.chains = C; sd.hx1 = n.hx1; sd.hx2 = n.hx2; sd.row0 = r0; sd.W = w->master + n.L[3].m_w;
+    sd.m1 = pre ? w->px1 : w->x1; sd.ld1 = n.hx1; sd.m2 = pre ? w->pcat : w->catv; sd.ld2 = w->cat; sd.kind = n.act; sd.is_pre = pre; sd.X = w->jtA;
+    hipLaunchKernelGGL(jt_seed_kernel, dim3(grid_el((size_t)trows * n.hx2 / 4)), dim3(256), 0, s, sd);
+    Gemm g; memset(&g, 0, sizeof g);           // tangent rows x the sx rows of the joint layer, masked by the chain's act'(j1)
+    g.W = n.Wp + n.L[5].w_off; g.KBW = n.L[5].Kp / 16; g.KB = n.hx2 / 16; g.NT = n.L[5].Np / 16;
+    g.X = w->jtA; g.ldx = n.hx2; g.Y = w->jtB; g.ldy = n.hj1; g.rows = trows;
+    g.mask = (pre ? w->pj1 : w->j1) + (size_t)r0 * n.hj1; g.ldm = n.hj1; g.mask_kind = n.act; g.mask_is_pre = pre; g.mask_rdiv = n.hx1;
+    launch_gemm(g, s);
+    memset(&g, 0, sizeof g);                   // ... x the second joint layer, masked by act'(j2)
+    g.W = n.Wp + n.L[6].w_off; g.KB = n.L[6].Kp / 16; g.NT = n.L[6].Np / 16;
+    g.X = w->jtB; g.ldx = n.hj1; g.Y = w->jtA; g.ldy = n.hj2; g.rows = trows;
+    g.mask = (pre ? w->pj2 : w->j2) + (size_t)r0 * n.hj2; g.ldm = n.hj2; g.mask_kind = n.act; g.mask_is_pre = pre; g.mask_rdiv = n.hx1;
+    launch_gemm(g, s);
+    JtTrace t; t.hx1 = n.hx1; t.hj2 = n.hj2; t.row0 = r0; t.Y = w->jtA; t.ET = w->jtET; t.trp = w->jtP;
+    hipLaunchKernelGGL(jt_trace_kernel, dim3(JT_SLICES, C), dim3(256), 0, s, t);
+  }
+}
+
 // ---- one evaluation of the augmented field on the rows in w->X-like buffer `X` (times already in w->ffat) ----
-static void field_eval(Ctx* w, const NetDev& n, const float* X, bool tangent, bool time_too, int rows, hipStream_t s) {
+// mode 0: value rows only; 1: + the tangent rows of the probe (Hutchinson / mfm_vf_apply's JVP); 2: + the exact Jacobian trace
+// (`live`: the rows of the evaluation that carry a chain -- compact evaluations are padded to a multiple of 16)
+static void field_eval(Ctx* w, const NetDev& n, const float* X, int mode, bool time_too, int rows, hipStream_t s, int live = -1) {
   if (time_too) time_branch(w, n, rows, s);
-  target_eval(w, n, X, tangent ? w->zp : nullptr, rows, s);
-  x_branch(w, n, X, tangent, rows, s);
+  target_eval(w, n, X, mode == 1 ? w->zp : nullptr, rows, s, mode == 2);
+  x_branch(w, n, X, mode == 1, rows, s);
+  if (mode == 2) exact_trace(w, n, live < 0 ? rows : live, s);
 }
 
 struct SolveArgs { int sign; float rtol, atol; int max_attempts; int rows; WReplay rp; };
@@ -1402,12 +1532,18 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
   const int rows = c.rows;
   OdeBuf o; memset(&o, 0, sizeof o);
   o.rows = rows; o.d = n.d; o.dp = n.dp; o.F = n.F; o.F2p = n.F2p; o.sign = c.sign; o.rtol = c.rtol; o.atol = c.atol; o.max_attempts = c.max_attempts;
-  o.rs = w->rs; o.Y = w->Y; o.K = w->K; o.X = xstage; o.Z = w->zp; o.ffat = w->ffat; o.fourier = n.fourier;
+  const bool exact = w->exact;
+  const int fmode = exact ? 2 : 1;
+  if (exact) {
+    if (!w->master || jt_alloc(w, n)) return -4;
+    jt_setup(w, n, s);
+  }
+  o.rs = w->rs; o.Y = w->Y; o.K = w->K; o.X = xstage; o.Z = exact ? nullptr : w->zp; o.trp = exact ? w->jtP : nullptr; o.ffat = w->ffat; o.fourier = n.fourier;
   o.out = w->out; o.outT = w->outT; o.gate = w->gate; o.gc = w->gc; o.hz = w->hz; o.n_active = w->n_active;
   o.rp = c.rp;
   hipLaunchKernelGGL(ode_init_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, w->rs, rows);
   if (hipMemsetAsync(w->K, 0, (size_t)7 * rows * n.dp * sizeof(float), s) != hipSuccess) return -4;
-  probe_setup(w, n, rows, s);
+  if (!exact) probe_setup(w, n, rows, s);
   const bool vec4 = (n.d & 3) == 0 && (n.dp & 3) == 0;
   auto stage_prep = [&](const OdeBuf& ob, int phase) {
     if (vec4) hipLaunchKernelGGL(stage_prep_kernel<f32x4>, dim3(grid4(rows)), dim3(256), 0, s, ob, phase);
@@ -1425,8 +1561,8 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
   };
   for (int phase = 0; phase < 2; ++phase) {                   // f0 and the extra evaluation of the initial-step heuristic
     if (phase == 1 && hipMemsetAsync(w->n_active, 0, sizeof(int), s) != hipSuccess) return -4;
-    stage_prep(o, phase); 
-    field_eval(w, n, xstage, true, true, rows, s);
+    stage_prep(o, phase);
+    field_eval(w, n, xstage, fmode, true, rows, s);
     stage_finish(o, phase);
   }
   int active = 0;
@@ -1442,10 +1578,11 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
   const bool no_tbatch = g_sw.wide_no_tbatch;
   for (int it = 0; active > 0 && it < c.max_attempts; ++it) {
     if (hipMemsetAsync(w->n_active, 0, sizeof(int), s) != hipSuccess) return -4;
-    int rc = rows;
+    int rc = rows, live = rows;
     if (!no_compact && active < rows) {
+      live = active;
       hipLaunchKernelGGL(compact_map_kernel, dim3(1), dim3(1024), 0, s, w->rs, rows, c.max_attempts, w->cmap, w->cpos);
-      hipLaunchKernelGGL(gather_rows_c_kernel, dim3(grid_el((size_t)active * n.hx1 / 4)), dim3(256), 0, s, w->tz1, w->cmap, active, n.hx1, w->tz1c);
+      if (!exact) hipLaunchKernelGGL(gather_rows_c_kernel, dim3(grid_el((size_t)active * n.hx1 / 4)), dim3(256), 0, s, w->tz1, w->cmap, active, n.hx1, w->tz1c);
       rc = (active + 15) & ~15;
       o.cpos = w->cpos; w->tz1_use = w->tz1c; w->cmap_use = w->cmap;
     }
@@ -1468,14 +1605,14 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
         ob.gate = w->gate5 + (size_t)slot * rc * n.dp;
         w->catv = w->cat5 + (size_t)slot * rc * w->cat;        // x2 writes its sx half into the slot's [sx | st] rows, j1 reads them
         if (phase > 2) stage_prep(ob, phase);
-        field_eval(w, n, xstage, true, false, rc, s);
+        field_eval(w, n, xstage, fmode, false, rc, s, live);
         stage_finish(ob, phase);
       }
       w->catv = cat_keep;
     } else
     for (int phase = 2; phase < 8; ++phase) {
       stage_prep(o, phase);
-      field_eval(w, n, xstage, true, phase != 7, rc, s);
+      field_eval(w, n, xstage, fmode, phase != 7, rc, s, live);
       stage_finish(o, phase);
     }
     if (read_active(active)) { w->tz1_use = nullptr; w->cmap_use = nullptr; return -4; }
@@ -1555,7 +1692,7 @@ static int vf_apply(Ctx* w, const NetDev& n, const float* x, const float* t, con
     pad_rows(x + (size_t)r0 * n.d, rows, n.d, n.dp, w->cond, s);
     if (tan) { pad_rows(tan + (size_t)r0 * n.d, rows, n.d, n.dp, w->zp, s); probe_setup(w, n, rows, s); }
     hipLaunchKernelGGL(fourier_rows_kernel, dim3(grid4(rows)), dim3(256), 0, s, n.fourier, n.F, n.F2p, t + r0, rows, w->ffat);
-    field_eval(w, n, w->cond, tan != nullptr, true, rows, s);
+    field_eval(w, n, w->cond, tan != nullptr ? 1 : 0, true, rows, s);
     hipLaunchKernelGGL(vf_out_kernel, dim3(grid_el((size_t)rows * n.d)), dim3(256), 0, s, rows, n.d, n.dp, w->out, w->outT, w->gate, w->gc, w->hz,
                        v + (size_t)r0 * n.d, jvp ? jvp + (size_t)r0 * n.d : nullptr);
   }

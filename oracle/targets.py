@@ -57,6 +57,10 @@ class PhiFour:
     def hvp_logprob(self, x, v):
         return -self.beta * (self.coef * self._lap(v) - (1.0 - 3.0 * x * x) * v / self.coef)
 
+    def hess_diag(self, x):
+        """Diagonal of the Hessian of logprob = hvp_logprob(x, e_j)[j] (exact-trace log-det of the gate term)."""
+        return -self.beta * (2.0 * self.coef - (1.0 - 3.0 * x * x) / self.coef)
+
     def initialize_model(self, key, n_chain, start=0, count=None):
         """``distributions.py:162-164``: U(-1, 1) per chain key."""
         count = n_chain - start if count is None else count
@@ -210,6 +214,10 @@ class LogGaussianCoxPines:
 
     def hvp_logprob(self, x, v):
         return -self.poisson_a * np.exp(x) * v - v @ self.Kinv
+
+    def hess_diag(self, x):
+        """Diagonal of the Hessian of logprob = hvp_logprob(x, e_j)[j]."""
+        return -self.poisson_a * np.exp(x) - np.diag(self.Kinv)[None]
 
     def initialize_model(self, key, n_chain, start=0, count=None):
         """``distributions.py:312-314``: mu + L xi."""

@@ -134,8 +134,10 @@ class VectorFieldNet:
             out.append((acts_in, pre, g))
         return out[0] if len(out) == 1 else tuple(out)
 
-    def jacobian_trace(self, params, x, t):
-        """trace(d v / d x) by d forward-mode columns (``exe_flow_matching.py:216-217``)."""
+    def jacobian_trace_columns(self, params, x, t):
+        """trace(d v / d x) by d forward-mode columns, one ``forward`` per basis vector: the literal reading of
+        ``jnp.trace(jax.jacfwd(v)(x))`` (``exe_flow_matching.py:216-217``).  O(d) forwards; kept as the cross-check of
+        :meth:`jacobian_trace` (``tests/test_oracle_vfield.py``)."""
         B, d = x.shape
         tr = np.zeros(B)
         for j in range(d):
@@ -143,6 +145,41 @@ class VectorFieldNet:
             _, jv = self.forward(params, x, t, tangent=e)
             tr += jv[:, j]
         return tr
+
+    def jacobian_trace(self, params, x, t, block=256):
+        """trace(d v / d x) (``exe_flow_matching.py:216-217``, ``:236-237``): what ``jax.jacfwd`` does -- ALL d basis tangents pushed
+        through the layers at once (per chain a [d, h] tangent matrix, in blocks of ``block`` basis vectors to bound memory) on ONE
+        value pass -- then the diagonal of the result.  Same arithmetic per column as :meth:`jacobian_trace_columns`."""
+        lt, lx, lxt = len(self.hidden_t), len(self.hidden_x), len(self.hidden_xt)
+        W = [p["kernel"].astype(np.float64) for p in params]
+        _, (acts_in, pre, g) = self.forward(params, x, t, cache=True)
+        B, d = x.shape
+        nn_t = pre[lt + lx]
+        _, inside = self._gterm(x)
+        tr = np.zeros(B)
+        for j0 in range(0, d, block):
+            j1 = min(d, j0 + block)
+            li = lt
+            ts = np.broadcast_to(W[li][j0:j1][None], (B, j1 - j0, W[li].shape[1]))          # e_j W_x1: rows j0..j1 of the kernel
+            ts = self.dact(pre[li])[:, None, :] * ts
+            li += 1
+            for _ in range(lx - 1):
+                ts = self.dact(pre[li])[:, None, :] * (ts @ W[li]); li += 1
+            li += 1                                                                           # gate layer: no x-tangent
+            hx = ts.shape[2]
+            for k in range(lxt):
+                Wk = W[li][:hx] if k == 0 else W[li]                                          # the st half of the joint input has no tangent
+                ts = self.dact(pre[li])[:, None, :] * (ts @ Wk); li += 1
+            jv = ts @ W[li][:, j0:j1]                                                         # [B, blk, blk]: columns j0..j1 of the out layer
+            tr += np.einsum("bjj->b", jv)
+        # + the gate term: d/dx_j [nn_t_j clip(g_j(x))] = nn_t_j 1[|g_j| <= clip] H_jj
+        if hasattr(self.dist, "hess_diag"):
+            hd = self.dist.hess_diag(x)
+        else:                                                                                 # (the 2-d mixtures)
+            hd = np.stack([self.dist.hvp_logprob(x, np.broadcast_to(np.eye(d)[j][None], x.shape))[:, j] for j in range(d)], axis=1)
+        if inside is not None:
+            hd = hd * inside
+        return tr + (nn_t * hd).sum(1)
 
     def backward(self, params, cache, dv):
         """Parameter gradients of sum(dv * v) given the forward cache; float32 like the params."""

@@ -250,3 +250,120 @@ def test_wide_pines_loop_matches_oracle(monkeypatch):
     np.testing.assert_allclose(ex["betas"], tr["beta"], rtol=2e-3)
     assert np.isfinite(res).all()
     ex["engine"].close()
+
+
+# ---- exact-trace log-det on the wide family (README.md:58,60: `--example pines` WITHOUT --hutch; exe_flow_matching.py:216-217) ----------
+def _tamed_lgcp(model, seed=9, out_scale=3.0):
+    from tests import gpu_util as gu
+    p = gu.rand_params(model, seed=seed, out_scale=out_scale)      # 16 x 16 / hidden 64: ~16 attempted steps, |log-det| ~ 2, points move by ~8
+    p[4]["kernel"] *= 0.05; p[4]["bias"] *= 0.05
+    return p
+
+
+@pytest.mark.parametrize("kind,d,hidden,F", [("lgcp", 256, 64, 16), ("phi4", 144, 48, 16)])
+@pytest.mark.parametrize("direction", [1, -1])
+def test_wide_exact_trace_transform_on_prescribed_steps(kind, d, hidden, F, direction):
+    """jnp.trace(jax.jacfwd(v)(x)) as the log-det integrand (no --hutch) on the wide family: hx1 masked tangent rows per chain through
+    two GEMMs and a contraction with W_out W_x1 (wide.hip: exact_trace) against the oracle's d tangent columns, step for step on the
+    oracle's step sequence: attempt counts exact, outputs at float32 rounding, log-det <= 1e-4 of |l|.  lgcp 16 x 16 / hidden 64;
+    phi-four d = 144 > 128 switches the clip (and its 0/1 derivative on the Hessian diagonal) on."""
+    import torch
+    from tests.test_gpu_replay import _replay_arrays, _check_controller_tight, _tamed
+    B = 32
+    args, dist, k, model, state = _setup(kind, d, B, hidden, F, hutch=False)
+    params = _tamed_lgcp(model) if kind == "lgcp" else _tamed(model)
+    ctx = _wide_ctx(dist, args, model, params)
+    x64 = dist.init_params.astype(np.float32).astype(np.float64)
+    keys = prng.split(prng.PRNGKey(21), B)
+    fn = ode.transform_and_logdet if direction > 0 else ode.inverse_and_logdet
+    o = (False, args.rtol, args.atol, args.mxstep)
+    st = {}
+    fn(model, params, keys, x64, *o, stats=st)
+    dt, acc = _replay_arrays([st])
+    st_o = {}
+    y_o, l_o = fn(model, params, keys, x64, *o, stats=st_o, replay=dict(dt=dt[0].astype(np.float64), acc=acc[0]))
+    assert st["n_attempted"].mean() > 10, st["n_attempted"].mean()
+    ratio = torch.zeros(dt[0].shape, device="cuda"); own = torch.zeros(dt[0].shape, device="cuda")
+    ctx.debug_replay(_dev(dt[0]), _dev(acc[0]), ratio, own)
+    out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
+    d_keys = _dev(keys.astype(np.uint32).view(np.int32))
+    ctx.ode_transform(direction, _dev(x64.astype(np.float32)), out, ldj, keys=d_keys, nsteps=ns)
+    y, l, n = out.cpu().numpy(), ldj.cpu().numpy(), ns.cpu().numpy()
+    np.testing.assert_array_equal(n, st["n_attempted"])
+    ey, el, ls = np.abs(y - y_o).max(), np.abs(l - l_o), max(1.0, np.abs(l_o).max())
+    mr, md = _check_controller_tight(f"exact {kind} dir={direction}", st_o, ratio.cpu().numpy(), own.cpu().numpy(), n)
+    print(f"wide exact-trace transform {kind} d={d} dir={direction}: attempts {n.mean():.0f}, |dy| {ey:.2e}, |dl| max {el.max():.2e} (|l| {ls:.2f}), "
+          f"controller medians {mr:.1e} {md:.1e}")
+    assert np.abs(l_o).max() > 0.05                                # a log-det worth comparing
+    assert ey < 3e-5 * max(1.0, np.abs(y_o).max()), ey
+    # measured (MI355X): lgcp 2.4e-6 / 2.1e-6, phi-four 5.4e-7 forward; backward ONE chain of 32 at 1.2e-3: the clip's 0/1 derivative on the
+    # Hessian diagonal (gate_i H_ii, |H_ii| ~ 600) flips for an element within float32 rounding of |grad log pi| = 1 -- an isolated
+    # kink event as in tests/test_gpu_replay.py, bounded by a quantile; the smooth Cox target has none
+    assert np.quantile(el, 0.9) < 1e-4 * ls and el.max() < (1e-4 if kind == "lgcp" else 5e-3) * ls, (np.quantile(el, 0.9), el.max(), ls)
+    # natural controller: two adaptive solves of the same flow on their own step sequences (rtol = atol = 1e-5 on the RMS over d + 1
+    # components; measured log-det differences 1.2e-2 .. 3.4e-2 of |l| 1.2 .. 2.2: the bound of tests/test_gpu_ode.py, 5 %)
+    ctx.ode_transform(direction, _dev(x64.astype(np.float32)), out, ldj, keys=d_keys, nsteps=ns)
+    assert np.abs(out.cpu().numpy() - y_o).max() < 2e-3 * max(1.0, np.abs(y_o).max())
+    assert np.abs(ldj.cpu().numpy() - l_o).max() < 5e-2 * ls
+    ctx.close()
+
+
+def test_wide_exact_trace_flow_step_on_prescribed_steps():
+    """The flow-MH step with the exact trace on the wide family (lgcp 16 x 16, hidden 64): both solves on the oracle's step
+    sequences, log-dets, proposal, log alpha, decisions."""
+    from tests.test_gpu_replay import _flow_replay_raw
+    B = 32
+    args, dist, k, model, state = _setup("lgcp", 256, B, 64, 16, hutch=False)
+    params = _tamed_lgcp(model)
+    ctx = _wide_ctx(dist, args, model, params)
+    r = _flow_replay_raw(ctx, model, params, args, dist, 0.8, dist.init_params.astype(np.float32), prng.PRNGKey(43))
+    so, dg, info_o = r["so"], r["diag"], r["info_o"]
+    np.testing.assert_array_equal(r["n_g"], r["n_o"])
+    e_p = np.abs(r["prop"] - info_o.proposed_position).max()
+    vs = max(1.0, np.abs(so["vol0"]).max(), np.abs(so["volp"]).max())
+    e_v0, e_vp, e_la = np.abs(dg[:, 0] - so["vol0"]), np.abs(dg[:, 1] - so["volp"]), np.abs(dg[:, 3] - so["log_alpha"])
+    print(f"wide exact-trace flow step: attempts {r['n_o'].mean():.0f}, |dx'| {e_p:.2e}, |dvol0| {e_v0.max():.2e}, |dvolp| {e_vp.max():.2e} (scale {vs:.2f}), "
+          f"|d log alpha| med {np.median(e_la):.2e} max {e_la.max():.2e}")
+    assert e_p < 3e-5 * max(1.0, np.abs(info_o.proposed_position).max())
+    assert e_v0.max() < 1e-4 * vs and e_vp.max() < 1e-4 * vs, (e_v0.max(), e_vp.max(), vs)
+    vg = targets.Tempered(dist, 0.8).value_and_grad
+    gn = vg(info_o.proposed_position.astype(np.float64))[1]
+    bound = 2.0 * np.linalg.norm(gn, axis=1) * np.linalg.norm(r["prop"] - info_o.proposed_position, axis=1) + 1e-4 * vs + 1e-3
+    assert (e_la <= bound).all(), (e_la / bound).max()
+    assert (r["isacc"] == info_o.is_accepted).mean() > 0.9
+    ctx.close()
+
+
+def test_wide_exact_trace_at_the_pines_width_on_prescribed_steps():
+    """32 x 32 grid, hidden 1024 (the pines network of BASELINE configs[4] / multi_modal.py:96) with the exact trace: sixteen chains on
+    the GPU, the oracle's d = 1024 tangent columns on four of them (the other twelve replay those four inputs and step sequences, so
+    every row of the 16-row GEMM tiles is checked and equal inputs must give equal outputs)."""
+    import torch
+    from tests.test_gpu_replay import _replay_arrays
+    B, Bo, d = 16, 4, 1024
+    from tests import gpu_util as gu
+    args, dist, k, model, state = _setup("lgcp", d, B, 1024, 128, hutch=False)
+    params = gu.rand_params(model, seed=9, out_scale=2.0)          # 12-15 attempted steps, |log-det| ~ 1, points move by ~5
+    params[4]["kernel"] *= 0.05; params[4]["bias"] *= 0.05
+    ctx = _wide_ctx(dist, args, model, params)
+    x4 = dist.init_params[:Bo].astype(np.float32).astype(np.float64)
+    k4 = prng.split(prng.PRNGKey(23), B)[:Bo]
+    o = (False, args.rtol, args.atol, args.mxstep)
+    st = {}
+    ode.transform_and_logdet(model, params, k4, x4, *o, stats=st)
+    dt, acc = _replay_arrays([st])
+    y_o, l_o = ode.transform_and_logdet(model, params, k4, x4, *o, stats={}, replay=dict(dt=dt[0].astype(np.float64), acc=acc[0]))
+    rep = lambda a: np.concatenate([a] * (B // Bo), axis=0)
+    ratio = torch.zeros(B, dt.shape[2], device="cuda"); own = torch.zeros(B, dt.shape[2], device="cuda")
+    ctx.debug_replay(_dev(rep(dt[0])), _dev(rep(acc[0])), ratio, own)
+    out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
+    ctx.ode_transform(1, _dev(rep(x4).astype(np.float32)), out, ldj, keys=_dev(rep(k4).astype(np.uint32).view(np.int32)), nsteps=ns)
+    y, l, n = out.cpu().numpy(), ldj.cpu().numpy(), ns.cpu().numpy()
+    np.testing.assert_array_equal(n, rep(st["n_attempted"]))
+    ls = max(1.0, np.abs(l_o).max())
+    print(f"wide exact trace 32 x 32 / hidden 1024: attempts {n.mean():.1f}, |dy| {np.abs(y - rep(y_o)).max():.2e}, |dl| {np.abs(l - rep(l_o)).max():.2e} (|l| {np.abs(l_o).max():.3f})")
+    assert np.abs(l_o).max() > 0.05
+    assert np.abs(y - rep(y_o)).max() < 3e-5 * max(1.0, np.abs(y_o).max())
+    assert np.abs(l - rep(l_o)).max() < 1e-4 * ls
+    np.testing.assert_array_equal(y[:Bo], y[Bo:2 * Bo]); np.testing.assert_array_equal(l[:Bo], l[2 * Bo:3 * Bo])      # equal inputs, equal rows
+    ctx.close()

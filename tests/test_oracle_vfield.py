@@ -82,6 +82,8 @@ def test_forward_jvp_backward(act, clip, hid):
     J = torch.autograd.functional.jacobian(
         lambda xx: _torch_forward(model, params, xx[None], torch.tensor(t[:1]), tact, _phi4_grad_t(d))[0][0], torch.tensor(x[0]))
     np.testing.assert_allclose(tr[0], torch.trace(J).item(), rtol=1e-8, atol=1e-8)
+    # ... whose blocked all-columns-at-once form equals the one-forward-per-basis-vector reading of jnp.trace(jax.jacfwd(v)(x))
+    np.testing.assert_allclose(model.jacobian_trace(params, x, t, block=3), model.jacobian_trace_columns(params, x, t), rtol=1e-12, atol=1e-12)
     # parameter gradient of sum((v - target)^2)
     target = rng.standard_normal((B, d))
     loss = ((vt - torch.tensor(target)) ** 2).sum()
@@ -113,3 +115,20 @@ def test_zero_init_invariant_and_loss():
     t2, cond2, target2 = fm.cond_flow_batch(prng.PRNGKey(6), x[4:9], 1e-4, n_total=B, start=4)
     np.testing.assert_array_equal(t[4:9], t2); np.testing.assert_array_equal(cond[4:9], cond2)
     np.testing.assert_array_equal(target[4:9], target2)
+
+
+def test_jacobian_trace_with_clip_and_cox_target():
+    """The exact-trace log-det integrand (exe_flow_matching.py:216-217) where the gate term matters: the clipped phi-four gradient
+    (d > 128: the 0/1 derivative of the clip) and the Cox target (dense K^-1 on the Hessian diagonal); blocked form = column form."""
+    from tests import gpu_util as gu
+    for setup in ("phi4", "lgcp"):
+        if setup == "phi4":
+            args, dist, k, model, state = gu.phi4_setup(d=144, B=6, hidden=32, F=16, hutch=False)
+        else:
+            args, dist, k, model, state = gu.lgcp_setup(n=4, B=6, hidden=32, F=16, hutch=False)
+        params = gu.rand_params(model, seed=5)
+        x = dist.init_params.astype(np.float64)
+        t = np.linspace(0.05, 0.95, 6)
+        a, b = model.jacobian_trace_columns(params, x, t), model.jacobian_trace(params, x, t, block=11)
+        assert np.abs(a).max() > 1e-3
+        np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-12)
