@@ -1116,6 +1116,567 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
   }
 }
 
+// ---- end of an attempt, row leaders (lanes 0..15 of wave 0, one per row): totals of the partial sums, initial-step heuristic /
+// step-size controller / solve switch of the row, in its mode; publishes the new row state, a decision flag (0 keep, 1 advance,
+// 2 finish, 3 initial slope) and the interpolation abscissa.  Shared by the tile's main loop (solve2) and its tail (solve2_tail).
+// STICKY: the rows keep the slots they were given when the tail began (RS_RANK = slot or -1); otherwise ranks and the tile's
+// evaluation mode are recomputed from the rows that take part in the next attempt.  Returns "this row takes part in it".
+template <int D, bool RP, bool STICKY>
+__device__ __forceinline__ int leaders_end_of_attempt(FTile<D>& T, const OdeArgs& a, const FlowArgs& f, int b0, int cmode) {
+  using S = FS<D>;
+  const float rtol = a.rtol, atol = a.atol;
+  const int max_attempts = a.max_attempts;
+  const float inv_n = 1.f / (float)(D + 1);
+  int any = 0;
+  // (the tail derives its lane coordinates locally: see solve2_tail)
+  int o_l8 = T.o_l8, o_l1 = T.o_l1, ln = T.lane;
+  if constexpr (STICKY) { int t_ = threadIdx.x; asm volatile("" : "+v"(t_)); ln = t_ & 15; o_l8 = ln * 32; o_l1 = ln * 4; }
+      auto sum8 = [&](int base) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(T.at(o_l8, base)), v = *reinterpret_cast<const f32x4*>(T.at(o_l8, base + 4));
+    return ((u[0] + u[1]) + (u[2] + u[3])) + ((v[0] + v[1]) + (v[2] + v[3]));
+  };
+  auto R1 = [&](int field) -> float& { return *T.at(o_l1, S::RS + field * 16); };
+  const float mode = R1(RS_MODE);
+  float flag = 0.f, sw = 0.f;
+  // divergence partials of this row: full evaluation: M-row = row, direction already applied; compact evaluation: M-row
+  // 8 + rank(row), raw
+  const int dl_off = cmode == 0 ? o_l8 : (8 + (int)R1(RS_RANK)) * 32;
+  const float dl_sg = cmode == 0 ? 1.f : (R1(RS_SIGN) > 0.f ? -1.f : 1.f);
+  auto dlsum = [&](int base) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(T.at(dl_off, base)), v = *reinterpret_cast<const f32x4*>(T.at(dl_off, base + 4));
+    return dl_sg * (((u[0] + u[1]) + (u[2] + u[3])) + ((v[0] + v[1]) + (v[2] + v[3])));
+  };
+  if (mode == (float)RM_INIT0) {
+    // f0 sits in k[1] (slot 0 of the attempt): initial step size, part 1
+    if (R1(RS_SOLVE) != 0.f && f.mode == MFM_FLOW_IMH)                 // ref.logprob(u0) - ref.logprob(up)  (:254-255)
+      R1(RS_LQ) = -0.5f * (sum8(S::RED + 4 * 128) - sum8(S::RED + 5 * 128)) / (f.ref_std * f.ref_std);
+    const float dl0 = dlsum(S::DLP + 1 * 128);
+    const float a1 = dl0 / atol;
+    const float d0 = sqrtf(sum8(S::RED + 0 * 128)), d1 = sqrtf(sum8(S::RED + 1 * 128) + a1 * a1);
+    const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+    R1(RS_H0) = h0; R1(RS_D1) = d1; R1(RS_KL + 0) = dl0;
+    R1(RS_DT) = h0; R1(RS_MODE) = (float)RM_INIT1;
+    flag = 3.f;
+  } else if (mode == (float)RM_INIT1) {
+    const float h0 = R1(RS_H0), d1 = R1(RS_D1);
+    const float a2 = (dlsum(S::DLP + 1 * 128) - R1(RS_KL + 0)) / atol;
+    const float d2 = sqrtf(sum8(S::RED + 2 * 128) + a2 * a2) / h0;
+    const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
+    float dt = fminf(100.f * h0, h1);
+    if constexpr (RP) { const size_t o = a.rp.at((int)R1(RS_SOLVE), b0 + ln, 0); a.rp.dt_own[o] = dt; dt = a.rp.dt[o]; }
+    R1(RS_DT) = dt; R1(RS_MODE) = (float)RM_ATT;
+    flag = 0.f;
+  } else if (mode == (float)RM_ATT) {
+    float kl[7];
+    kl[0] = R1(RS_KL + 0);
+#pragma unroll
+    for (int j = 1; j < 7; ++j) kl[j] = dlsum(S::DLP + j * 128);
+    const float e2 = sum8(S::RED + 3 * 128);
+    const float t0 = R1(RS_T), dti = R1(RS_DT), ell0 = R1(RS_ELL), na = R1(RS_NATT);
+    const bool active = na < (float)max_attempts && dti > 0.f;
+    float sl = 0.f, el = 0.f, lm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) sl += DP_TAB[7][j] * kl[j];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) el += DP_E[j] * kl[j];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) lm += DP_M[j] * kl[j];
+    const float l1 = ell0 + dti * sl;
+    el *= dti;
+    const float tol = atol + rtol * fmaxf(fabsf(ell0), fabsf(l1));
+    const float rr = el / tol;
+    const float ratio = sqrtf((e2 + rr * rr) * inv_n);
+    bool acc = active && ratio <= 1.f;
+    const float dfac = ratio < 1.f ? 1.f : 0.2f;
+    const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
+    float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
+    if constexpr (RP) {
+      if (active) {
+        const int j = (int)na;
+        const bool in = j < a.rp.cap, nx = j + 1 < a.rp.cap;
+        const size_t o = a.rp.at((int)R1(RS_SOLVE), b0 + ln, in ? j : 0);
+        if (in) { a.rp.ratio[o] = ratio; if (nx) a.rp.dt_own[o + 1] = ndt; }
+        acc = in && a.rp.acc[o] != 0;
+        ndt = nx ? a.rp.dt[o + 1] : 0.f;
+      }
+    }
+    const float tn = t0 + dti;
+    const bool fin = acc && tn >= 1.f, adv = acc && !(tn >= 1.f);
+    const float sfrac = (1.f - t0) / (tn - t0);
+    const float y0 = ell0, ym = y0 + dti * lm, f0 = dti * kl[0], f1 = dti * kl[6];
+    const float pa = -2.f * f0 + 2.f * f1 - 8.f * y0 - 8.f * l1 + 16.f * ym;
+    const float pb = 5.f * f0 - 3.f * f1 + 18.f * y0 + 14.f * l1 - 32.f * ym;
+    const float pc = -4.f * f0 + f1 - 11.f * y0 - 5.f * l1 + 16.f * ym;
+    const float li = (((pa * sfrac + pb) * sfrac + pc) * sfrac + f0) * sfrac + y0;
+    const float dt_n = active ? ndt : dti, na_n = active ? na + 1.f : na;
+    const float ell_n = fin ? li : (adv ? l1 : ell0);
+    // the solve ends when t reaches 1, or (as in odeint's while_loop) when the step budget / step size runs out
+    const bool over = fin || !(na_n < (float)max_attempts && dt_n > 0.f);
+    flag = fin ? 2.f : (adv ? 1.f : 0.f);
+    R1(RS_SFRAC) = sfrac;
+    if (!over) {
+      R1(RS_T) = acc ? tn : t0; R1(RS_DT) = dt_n; R1(RS_ELL) = ell_n; R1(RS_KL + 0) = adv ? kl[6] : kl[0]; R1(RS_NATT) = na_n;
+    } else if (R1(RS_SOLVE) == 0.f) {
+      // inverse solve done: keep vol0, start this row's forward solve (:268-269 / :249-250)
+      R1(RS_VOL0) = ell_n; R1(RS_NTOT) = na_n;
+      R1(RS_T) = 0.f; R1(RS_DT) = 0.f; R1(RS_ELL) = 0.f; R1(RS_KL + 0) = 0.f; R1(RS_NATT) = 0.f;
+      R1(RS_SOLVE) = 1.f; R1(RS_SIGN) = 1.f; R1(RS_MODE) = (float)RM_INIT0;
+      sw = 1.f;
+      *T.at(0, S::RS + RS_TILE * 16) = 1.f;
+    } else {
+      R1(RS_ELL) = ell_n; R1(RS_NATT) = na_n; R1(RS_MODE) = (float)RM_DONE;
+    }
+  }
+  R1(RS_FLAG) = flag; R1(RS_SW) = sw;
+  any = R1(RS_MODE) != (float)RM_DONE ? 1 : 0;
+  if constexpr (STICKY) {
+    if (!any) R1(RS_RANK) = -1.f;
+  } else {
+    // rank of this row among the rows that take part in the next attempt: with <= 3 of them the time batch is compacted
+    const unsigned long long bal = __ballot(any != 0);
+    R1(RS_RANK) = any ? (float)__popcll(bal & ((1ull << ln) - 1ull)) : -1.f;
+    if (ln == 0) { const int na = __popcll(bal); *T.at(0, S::RS + RS_TILE * 16 + 1) = na <= MICRO_ROWS ? 3.f : (na <= 3 ? 2.f : (na <= 8 ? 1.f : 0.f)); }
+  }
+  return any;
+}
+
+// ---- THE TAIL OF A TILE: at most two rows still integrate (solve2_tail) ------------------------------------------------------
+// The launch lasts as long as its slowest tile, and that tile runs its last 110-230 attempts with one or two rows (tools/tail_stats.py).
+// Inside the main loop those attempts carried the full layout's register state (seven stage derivatives of 16 rows: 64 VGPRs of
+// which 4-8 are live), its spills (five scratch reloads per evaluation, each a vmcnt(0) that drains the weight stream) and a time
+// batch that pushes every weight fragment through a 16-row tile and its results through a global scratch.  A stand-alone model of
+// the 4-row evaluation (tools/mb/micro_eval.hip) runs in 9.3 k cycles against the 14.4 k measured in the main loop -- with the SAME
+// eight fragments in flight: the stream must simply never be drained.  Hence a loop of its own, entered once (the number of live
+// rows never grows) with the state of the two rows moved to a compact layout:
+//   * slot r (0, 1) = the row that had rank r when the tail began (sticky: a row that ends leaves its slot empty); lane (g, c) of
+//     wave w carries slot g & 1, columns 16 (w + 8 q) + c: y and k_1..7 of 2 elements = 16 registers (lane groups g and g ^ 2 hold
+//     copies: after the g-sum of the 4 x 4 x 1 MFMA every lane has all four M-rows of its column, so every lane can finish the
+//     value AND the divergence of its slot -- no LDS round trip for the evaluation's result);
+//   * ONE weight ring of eight fragments for the whole attempt -- time batch (32 + 8 TPW + 8 fragments) and six evaluations (D / 16
+//     + 24 + 8 TPW each), refilled one fragment at a time right after its use, across layers, barriers and attempts (the address
+//     sequence is static); no scratch, no spills in the loop;
+//   * the time batch of the <= 10 (stage, slot) pairs as one M tile with K = 256 (cos | sin side by side in a [16][264] image: no
+//     two-pass accumulation, no sine stash), its results (gate, st contribution to j1) in LDS, read back by plain ds_read;
+//     three barriers instead of six; sincos only for the pairs that exist (<= 3 per lane instead of 20).
+// Arithmetic: per-row controller, interpolation and step sizes are those of the main loop bit for bit (leaders_end_of_attempt); the
+// evaluation is eval_m's (4 x 4 x 1 MFMA, k-sum per 16-lane group then over the groups), the time batch sums K = 256 in the even /
+// odd k-block order of the single-tile batch, now over both halves at once (a float reassociation of the first time layer).
+template <int D>
+struct TailMap {
+  using S = FS<D>;
+  static constexpr int LDF = 2 * F + 8;                       // Fourier image [16][cos 128 | sin 128]
+  static constexpr int LDT = D + H + 8;                       // time-batch results [16][gate D | j1t H]
+  static constexpr int FH2 = S::R, T1I = S::R + 32 * S::LDH, STI = S::R + 48 * S::LDH;      // dead once the batch is done
+  static constexpr int A1 = S::R, SX = S::R + 32 * S::LDH, J1 = S::R2, J2 = S::R2 + 32 * S::LDH;   // 4-row images of the x branch (as eval_m)
+  static constexpr int TBR = S::R2 + 48 * S::LDH;             // lives through the attempt
+  static constexpr int STG = S::R2;                           // [2 slots][8][D]: state transfer at entry (before the first evaluation)
+  static_assert(16 * LDF <= 32 * S::LDH && TBR + 16 * LDT <= S::TOTAL && 36 <= 48 && 2 * 8 * D <= 48 * S::LDH, "tail LDS map");
+  // fragment i of the attempt's time batch / of an evaluation, wave w: byte offset in the packed weights
+  static __device__ __forceinline__ int tb_soff(int i, int w) {
+    constexpr int G = 8 * FTile<D>::TPW;
+    return i < 16 ? S::W0 * 4 + (w * 16 + i) * 1024
+         : i < 24 ? S::W1 * 4 + (w * 8 + i - 16) * 1024
+         : i < 24 + G ? S::W4 * 4 + ((w + 8 * ((i - 24) >> 3)) * 8 + ((i - 24) & 7)) * 1024
+         : S::W5 * 4 + (w * 16 + 8 + i - 24 - G) * 1024;
+  }
+  static constexpr int NTB = 32 + 8 * FTile<D>::TPW;
+  static __device__ __forceinline__ int ev_soff(int i, int w) {
+    constexpr int K1 = D / 16, TPW = FTile<D>::TPW;
+    return i < K1 ? S::W2 * 4 + (w * K1 + i) * 1024
+         : i < K1 + 8 ? S::W3 * 4 + (w * 8 + i - K1) * 1024
+         : i < K1 + 16 ? S::W5 * 4 + (w * 16 + i - K1 - 8) * 1024
+         : i < K1 + 24 ? S::W6 * 4 + (w * 8 + i - K1 - 16) * 1024
+         : S::W7 * 4 + ((w + 8 * ((i - K1 - 24) % TPW)) * 8 + (i - K1 - 24) / TPW) * 1024;
+  }
+  static constexpr int NEV = D / 16 + 24 + 8 * FTile<D>::TPW;
+  static_assert(NTB % 8 == 0 && NEV % 8 == 0, "the ring positions are static");
+};
+
+template <int D, bool RP>
+__device__ __forceinline__ void solve2_tail(FTile<D>& T, const OdeArgs& a, const FlowArgs& f, int b0, float (&y)[FTile<D>::TPW][4],
+                                            float (&kfull)[7][FTile<D>::TPW][4]) {
+  using S = FS<D>;
+  using M = TailMap<D>;
+  constexpr int TPW = FTile<D>::TPW, LDX = S::LDX, LDH = S::LDH, LDF = M::LDF, LDT = M::LDT, NTB = M::NTB, NEV = M::NEV, K1 = D / 16;
+  // Every per-lane quantity of this loop is derived HERE from an opaque copy of the thread index: values computed before the main
+  // loop (the tile's lane coordinates, its LDS offsets) are live across it, where all 256 registers are taken, so the allocator
+  // spills their whole live range and every use in this loop would be a scratch reload -- a vector-memory load whose wait drains
+  // the weight ring (seen in the ISA of the first version: one reload per layer for the bias column alone).
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int lane = tid_ & 63, g = lane >> 4, c = lane & 15, wave = T.wave;
+  const int slot = g & 1;
+  const bool is_t = g >= 2;
+  float* const lds = T.lds;
+  const float scale = 2.38f / sqrtf((float)D);                                                  // :262
+  const float rtol = a.rtol, atol = a.atol;
+  const float t_coef = a.net.T.coef, t_beta = a.net.T.tbeta, t_clip = a.net.grad_clip;
+  const float ffreq = a.net.fourier[16 * wave + c];
+  const float* const biasp = lds + S::BIAS + 16 * wave + c;    // column 16 wave + c (+ 128 q) of a layer's bias
+  auto RSF = [&](int field, int row) -> float& { return lds[S::RS + field * 16 + row]; };
+  // ---- slots: the row that holds rank r now keeps slot r ----
+  int row0, row1;
+  {
+    const float rkv = RSF(RS_RANK, lane & 15);
+    const unsigned long long m0 = __ballot(rkv == 0.f) & 0xFFFFull, m1 = __ballot(rkv == 1.f) & 0xFFFFull;
+    row0 = m0 ? __builtin_ctzll(m0) : -1; row1 = m1 ? __builtin_ctzll(m1) : -1;
+  }
+  const int myrow = slot ? row1 : row0;
+  const int mr = myrow < 0 ? 0 : myrow;                      // (an empty slot computes on row 0's numbers and stores nothing)
+  // ---- state of the two rows: full layout -> [slot][y, k_1..7][D] -> compact layout ----
+  unsigned intail = 0;
+  {
+    const f32x4 rk4 = T.rs_get(RS_RANK);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (rk4[i] >= 0.f) {
+        intail |= 1u << i;
+        const int r = (int)rk4[i];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+          const int col = 16 * (wave + NW * q) + c;
+          lds[M::STG + (r * 8 + 0) * D + col] = y[q][i];
+#pragma unroll
+          for (int j = 0; j < 7; ++j) lds[M::STG + (r * 8 + 1 + j) * D + col] = kfull[j][q][i];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float ym[TPW], km[7][TPW];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int col = 16 * (wave + NW * q) + c;
+    ym[q] = lds[M::STG + (slot * 8 + 0) * D + col];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) km[j][q] = lds[M::STG + (slot * 8 + 1 + j) * D + col];
+    if (!is_t && myrow >= 0) {                                // probe rows 2, 3 of both stage-input images
+      const float z = lds[S::ZB + myrow * LDX + 4 + col];
+      lds[S::XB0 + (2 + slot) * LDX + 4 + col] = z; lds[S::XB1 + (2 + slot) * LDX + 4 + col] = z;
+    }
+  }
+  __syncthreads();
+  // ---- the weight ring ----
+  f32x4 ring[8];
+  const int voff = lane * 16;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ring[i] = bload(T.wr, voff, M::tb_soff(i, wave));
+  // one fragment = one k-block of one column tile: A from LDS, four MFMAs, then the slot is refilled eight fragments ahead
+#define TAIL_F4(I, AP, ACC, NEXT)                                                                                       \
+  {                                                                                                                    \
+    const f32x4 a_ = *reinterpret_cast<const f32x4*>(AP);                                                              \
+    const f32x4 b_ = ring[(I) & 7];                                                                                    \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) (ACC)[s_] = mfma1(a_[s_], b_[s_], (ACC)[s_]);                    \
+    ring[(I) & 7] = bload(T.wr, voff, (NEXT));                                                                         \
+    asm volatile("" ::: "memory");                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  }
+#define TAIL_F16(I, AP, ACC, NEXT)                                                                                      \
+  {                                                                                                                    \
+    const f32x4 a_ = *reinterpret_cast<const f32x4*>(AP);                                                              \
+    const f32x4 b_ = ring[(I) & 7];                                                                                    \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) (ACC) = mfma4(a_[s_], b_[s_], (ACC));                            \
+    ring[(I) & 7] = bload(T.wr, voff, (NEXT));                                                                         \
+    asm volatile("" ::: "memory");                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  }
+  const int colw = 16 * wave + c;                             // this lane's column inside a 128-wide layer
+  int cur = 0;
+#pragma unroll 1
+  for (;;) {
+    const float mode = RSF(RS_MODE, mr), hs = RSF(RS_DT, mr), sgn = RSF(RS_SIGN, mr);
+    const bool alive = myrow >= 0 && RSF(RS_RANK, mr) >= 0.f;
+    const bool att = mode == (float)RM_ATT, in1 = mode == (float)RM_INIT1;
+#pragma unroll 1
+    for (int phase = 2; phase < 8; ++phase) {
+      // ---- stage input of my slot -> X[cur] row slot ----
+      {
+        float cf[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) cf[j] = DP_TAB[phase][j];
+        const float c0 = (in1 && phase == 2) ? 1.f : cf[0];
+        const float he = (att || phase == 2) ? hs : 0.f;
+        float* const X = lds + (cur ? S::XB1 : S::XB0);
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+          float acc = c0 * km[0][q];
+#pragma unroll
+          for (int j = 1; j < 6; ++j) acc += cf[j] * km[j][q];
+          const float xin = ym[q] + he * acc;
+          if (!is_t && alive) X[slot * LDX + 4 + colw + 128 * q] = xin;
+        }
+      }
+#ifdef MFM_STAMPS
+      const unsigned long long tb0_ = __builtin_amdgcn_s_memtime();
+#endif
+      if (phase == 2) {
+        // ---- time batch: M-row 2 s + slot, s = 0..4 ----
+        {
+          const double fq = (double)ffreq;
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) {
+            const int m = g + 4 * pp;                         // pair (stage m >> 1, slot m & 1), wave-uniform per lane group
+            if (m < 10) {
+              const int sl = m & 1, st = m >> 1;
+              const int rw = sl ? row1 : row0;
+              if (rw >= 0 && RSF(RS_RANK, rw < 0 ? 0 : rw) >= 0.f) {
+                const float md = RSF(RS_MODE, rw), t0 = RSF(RS_T, rw), h = RSF(RS_DT, rw), sg = RSF(RS_SIGN, rw);
+                // (stage fractions by selects: a table indexed per lane would be a vector-memory load, whose wait drains the weight ring)
+                const float c5 = st == 0 ? 1.f / 5 : (st == 1 ? 3.f / 10 : (st == 2 ? 4.f / 5 : (st == 3 ? 8.f / 9 : 1.f)));
+                const float csr = md == (float)RM_INIT1 ? (st == 0 ? 1.f : 0.f) : c5;
+                const float tt = t0 + h * csr;
+                const double te = sg > 0.f ? (double)tt : 1.0 - (double)tt;          // :229
+                double ft = fq * te;
+                ft -= rint(ft);
+                float sn, cs;
+                sincospif(2.f * (float)ft, &sn, &cs);                                // :70-71
+                lds[M::FH2 + m * LDF + colw] = cs; lds[M::FH2 + m * LDF + F + colw] = sn;
+              }
+            }
+          }
+        }
+        __syncthreads();
+        f32x4 ac[2];
+        const float* const af = lds + M::FH2 + (lane & 15) * LDF + 4 * g;
+        ac[0] = f32x4{0, 0, 0, 0}; ac[1] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) TAIL_F16(i, af + i * 16, ac[i & 1], M::tb_soff(i + 8, wave))
+        {
+          const f32x4 t1 = ac[0] + ac[1];
+          const float b = biasp[S::B0];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lds[M::T1I + (4 * g + i) * LDH + colw] = fmaxf(t1[i] + b, 0.f);
+        }
+        __syncthreads();
+        const float* const at1 = lds + M::T1I + (lane & 15) * LDH + 4 * g;
+        ac[0] = f32x4{0, 0, 0, 0}; ac[1] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) TAIL_F16(16 + i, at1 + i * 16, ac[i & 1], M::tb_soff(24 + i, wave))
+        {
+          const f32x4 t2 = ac[0] + ac[1];
+          const float b = biasp[S::B1];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lds[M::STI + (4 * g + i) * LDH + colw] = fmaxf(t2[i] + b, 0.f);          // st
+        }
+        __syncthreads();
+        const float* const ast = lds + M::STI + (lane & 15) * LDH + 4 * g;
+#pragma unroll
+        for (int q = 0; q < TPW + 1; ++q) {                   // gate tiles wave (+ 8), then the st half of j1
+          ac[0] = f32x4{0, 0, 0, 0}; ac[1] = f32x4{0, 0, 0, 0};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int fi = 24 + 8 * q + i;                    // fragment index in the batch; its refill is 8 ahead: the batch, then x1
+            TAIL_F16(fi, ast + i * 16, ac[i & 1], fi + 8 < NTB ? M::tb_soff(fi + 8, wave) : M::ev_soff(fi + 8 - NTB, wave))
+          }
+          const f32x4 r = ac[0] + ac[1];
+          const float b = q < TPW ? biasp[S::B4 + 128 * q] : biasp[S::B5];
+          const int co = q < TPW ? 128 * q : D;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lds[M::TBR + (4 * g + i) * LDT + co + colw] = r[i] + b;
+        }
+        // (no barrier here: the first read of these results comes after the evaluation's first barrier, and nothing the
+        // evaluation writes before it overlaps the images this batch still reads)
+      } else {
+        __syncthreads();
+      }
+#ifdef MFM_STAMPS
+      const unsigned long long ev0_ = __builtin_amdgcn_s_memtime();
+      if (phase == 2) { T.cyc_t1 += ev0_ - tb0_; T.n_t1 += 1; }
+#endif
+      // ---- one field evaluation of the two slots on the 4-row images ----
+      float kv[TPW];
+      {
+        const int ss = phase == 7 ? 4 : phase - 2;            // time slot of the stage
+        const bool next_tb = phase == 7;
+        const float* const X = lds + (cur ? S::XB1 : S::XB0);
+        const int mrow = 2 * ss + slot;
+        float gt[TPW], gc[TPW], hz[TPW], zz[TPW];
+        auto target_terms = [&]() {
+          const float icoef = 1.f / t_coef;
+#pragma unroll
+          for (int q = 0; q < TPW; ++q) {
+            const float* xr = X + slot * LDX + 4 + colw + 128 * q;
+            const float* zr = xr + 2 * LDX;
+            const float x = xr[0], z = zr[0];
+            const float graw = -t_beta * (t_coef * (2.f * x - xr[-1] - xr[1]) - x * (1.f - x * x) * icoef);
+            const float hv = -t_beta * (t_coef * (2.f * z - zr[-1] - zr[1]) - (1.f - 3.f * x * x) * z * icoef);
+            gc[q] = t_clip > 0.f ? fminf(fmaxf(graw, -t_clip), t_clip) : graw;
+            hz[q] = (!(t_clip > 0.f) || fabsf(graw) <= t_clip) ? hv : 0.f;
+            zz[q] = z;
+          }
+        };
+        f32x4 acc[TPW][4];
+        auto zero = [&]() {
+#pragma unroll
+          for (int q = 0; q < TPW; ++q)
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) acc[q][s_] = f32x4{0, 0, 0, 0};
+        };
+        // finish one layer: M-row g of this lane's column -> row g of the next layer's image
+        auto act_store = [&](float add, float* dst) {
+          const f32x4 pre = T.gsum((acc[0][0] + acc[0][1]) + (acc[0][2] + acc[0][3]));
+          const float pv = (slot ? pre[1] : pre[0]) + add, pt = slot ? pre[3] : pre[2];
+          dst[g * LDH + colw] = is_t ? (pv > 0.f ? pt : 0.f) : fmaxf(pv, 0.f);
+        };
+        if (wave < NW / 2) target_terms();
+        {   // x1 on [values ; probes]
+          const float* const ax = X + (c & 3) * LDX + 4 + 4 * g;
+          zero();
+#pragma unroll
+          for (int i = 0; i < K1; ++i) TAIL_F4(i, ax + i * 16, acc[0], M::ev_soff(i + 8, wave))
+          if (wave >= NW / 2) target_terms();
+          act_store(biasp[S::B2], lds + M::A1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) gt[q] = lds[M::TBR + mrow * LDT + 128 * q + colw];
+        const float j1t = lds[M::TBR + mrow * LDT + D + colw];
+        {   // x2
+          const float* const ah = lds + M::A1 + (c & 3) * LDH + 4 * g;
+          zero();
+#pragma unroll
+          for (int i = 0; i < 8; ++i) TAIL_F4(K1 + i, ah + i * 16, acc[0], M::ev_soff(K1 + i + 8, wave))
+          act_store(biasp[S::B3], lds + M::SX);
+        }
+        __syncthreads();
+        {   // j1: the st half + bias of the value rows come from the time batch
+          const float* const ah = lds + M::SX + (c & 3) * LDH + 4 * g;
+          zero();
+#pragma unroll
+          for (int i = 0; i < 8; ++i) TAIL_F4(K1 + 8 + i, ah + i * 16, acc[0], M::ev_soff(K1 + 16 + i, wave))
+          act_store(j1t, lds + M::J1);
+        }
+        __syncthreads();
+        {   // j2
+          const float* const ah = lds + M::J1 + (c & 3) * LDH + 4 * g;
+          zero();
+#pragma unroll
+          for (int i = 0; i < 8; ++i) TAIL_F4(K1 + 16 + i, ah + i * 16, acc[0], M::ev_soff(K1 + 24 + i, wave))
+          act_store(biasp[S::B6], lds + M::J2);
+        }
+        __syncthreads();
+        {   // out: every lane ends with all four M-rows of its columns -> value and divergence of its slot, no LDS round trip
+          const float* const ah = lds + M::J2 + (c & 3) * LDH + 4 * g;
+          zero();
+#pragma unroll
+          for (int i = 0; i < 8 * TPW; ++i) {
+            const int fi = K1 + 24 + i;
+            const int nx = fi + 8 < NEV ? M::ev_soff(fi + 8, wave) : (next_tb ? M::tb_soff(fi + 8 - NEV, wave) : M::ev_soff(fi + 8 - NEV, wave));
+            TAIL_F4(fi, ah + (i / TPW) * 16, acc[i % TPW], nx)
+          }
+          float dpv = 0.f;
+#pragma unroll
+          for (int q = 0; q < TPW; ++q) {
+            const f32x4 pre = T.gsum((acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]));
+            const float pv = slot ? pre[1] : pre[0], pt = slot ? pre[3] : pre[2];
+            dpv += zz[q] * (pt + gt[q] * hz[q]);                                                  // z . J z of the slot
+            const float v = pv + biasp[S::B7 + 128 * q] + gt[q] * gc[q];                          // v of the slot
+            kv[q] = sgn > 0.f ? v : -v;
+          }
+          dpv = group16_sum_dpp(dpv);
+          if (is_t && c == 0) lds[S::DLP + (phase - 1) * 128 + (8 + slot) * 8 + wave] = dpv;     // M-row 8 + slot of the partial sums (as eval_c); raw
+        }
+      }
+#ifdef MFM_STAMPS
+      T.cyc_em += __builtin_amdgcn_s_memtime() - ev0_; T.n_em += 1;
+#endif
+      cur ^= 1;
+#pragma unroll
+      for (int j = 1; j < 7; ++j)
+        if (j == phase - 1) {
+#pragma unroll
+          for (int q = 0; q < TPW; ++q) km[j][q] = kv[q];
+        }
+    }
+    // ---- end of the attempt: norms of my slot's row (lane groups 0, 1; groups 2, 3 hold copies) ----
+    {
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f, e2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const float sc = atol + fabsf(ym[q]) * rtol;                        // initial-step norms (Hairer II.4)
+        const float a0 = ym[q] / sc, a1 = km[1][q] / sc, a2 = (km[1][q] - km[0][q]) / sc;
+        p0 += a0 * a0; p1 += a1 * a1; p2 += a2 * a2;
+        float acc = 0.f, er = 0.f;                                          // error norm of the attempted step
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * km[j][q];
+        const float y1 = ym[q] + hs * acc;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) er += DP_E[j] * km[j][q];
+        er *= hs;
+        const float tol = atol + rtol * fmaxf(fabsf(ym[q]), fabsf(y1));
+        const float rr = er / tol;
+        e2 += rr * rr;
+      }
+      p0 = group16_sum_dpp(p0); p1 = group16_sum_dpp(p1); p2 = group16_sum_dpp(p2); e2 = group16_sum_dpp(e2);
+      if (!is_t && c == 0 && myrow >= 0) {
+        float* const rd = lds + S::RED + myrow * 8 + wave;
+        rd[0] = p0; rd[128] = p1; rd[256] = p2; rd[384] = e2;
+      }
+    }
+    if (threadIdx.x == 0) RSF(RS_TILE, 0) = 0.f;              // "some row switched solves in this attempt"
+    __syncthreads();
+    int any = 0;
+    if (wave == 0 && lane < 16) any = leaders_end_of_attempt<D, RP, true>(T, a, f, b0, 3);
+    const int go = __syncthreads_or(any);
+    // ---- apply the decision of my slot's row ----
+    {
+      const float fl = RSF(RS_FLAG, mr), sfrac = RSF(RS_SFRAC, mr);
+      const bool swr = RSF(RS_SW, mr) != 0.f && RSF(RS_TILE, 0) != 0.f;
+      const bool fin = fl == 2.f, adv = fl == 1.f, ini = fl == 3.f;
+      float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        float acc = 0.f, kmid = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * km[j][q];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) kmid += DP_M[j] * km[j][q];
+        const float x0 = ym[q], x1 = x0 + hs * acc, xm = x0 + hs * kmid, g0 = hs * km[0][q], g1 = hs * km[6][q];
+        const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
+        const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
+        const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
+        const float xi = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
+        float yn = fin ? xi : (adv ? x1 : x0);
+        km[0][q] = ini ? km[1][q] : (adv ? km[6][q] : km[0][q]);
+        if (swr && myrow >= 0) {             // this row starts its forward solve: latent proposal, forward probe
+          const int col = colw + 128 * q;
+          const size_t o = (size_t)(b0 + myrow) * D + col;
+          const float nz = a.zgen[o];
+          if (f.mode == MFM_FLOW_RWMH) yn = yn + scale * nz;                                        // :268
+          else { const float up = f.ref_std * nz; r0 += yn * yn; r1 += up * up; yn = up; }          // :249
+          const float z2 = a.z2[o];                                                                 // key_hutch1
+          if (!is_t) { lds[S::XB0 + (2 + slot) * LDX + 4 + col] = z2; lds[S::XB1 + (2 + slot) * LDX + 4 + col] = z2; }
+#pragma unroll
+          for (int j = 0; j < 7; ++j) km[j][q] = 0.f;
+        }
+        ym[q] = yn;
+      }
+      if (RSF(RS_TILE, 0) != 0.f && f.mode == MFM_FLOW_IMH) {      // tile-uniform: ref.logprob terms of the rows that switched
+        r0 = group16_sum_dpp(r0); r1 = group16_sum_dpp(r1);
+        if (!is_t && c == 0 && swr && myrow >= 0) { lds[S::RED + 4 * 128 + myrow * 8 + wave] = r0; lds[S::RED + 5 * 128 + myrow * 8 + wave] = r1; }
+      }
+    }
+    if (!go) break;
+    // (the next attempt's stage input is visible after the time batch's first barrier; the leaders rewrite the row state only
+    // after the end-of-attempt barrier of that attempt)
+  }
+#undef TAIL_F4
+#undef TAIL_F16
+  // ---- back to the full layout: the final state of the rows that ended here (the probe image is free now) ----
+  __syncthreads();
+  if (!is_t && myrow >= 0) {
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) lds[S::ZB + myrow * LDX + 4 + colw + 128 * q] = ym[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (intail >> i & 1u) {
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) y[q][i] = lds[S::ZB + (4 * g + i) * LDX + 4 + colw + 128 * q];
+    }
+}
+
 // ---- the flow step's two solves with PER-ROW phases ------------------------------------------------------------------
 // flow_step = inverse solve of the current position, latent proposal, forward solve of the proposal (:264-278 / :246-260).
 // Run as two tile-wide solves, a tile waits for its slowest inverse solve AND then for its slowest forward solve
@@ -1164,7 +1725,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
     const f32x4 md4 = T.rs_get(RS_MODE), rk4 = T.rs_get(RS_RANK);
     const int cmode = (int)*T.at(0, S::RS + RS_TILE * 16 + 1);             // 0: > 8 rows of the tile still integrate, 1: <= 8, 2: <= 3, 3: <= 2
     const int rps = cmode >= 2 ? 3 : (cmode == 1 ? 8 : 0);
-    const int prow = cmode == 3 ? 2 : 8;                                   // first probe row of the compact / micro input image
+    const int prow = 8;                                                    // first probe row of the compact input image
     {
       float cf[6];
 #pragma unroll
@@ -1215,7 +1776,6 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
     const unsigned long long ce0_ = __builtin_amdgcn_s_memtime();
 #endif
     if (cmode == 0) T.eval(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN), 0, rk4);
-    else if (cmode == 3) T.eval_m(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN), rk4);
     else T.eval_c(phase == 7 ? 4 : phase - 2, cur, dst, phase == 7, P, Q, kv, T.rs_get(RS_SIGN), rps, rk4);
 #ifdef MFM_STAMPS
     { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - ce0_;
@@ -1258,110 +1818,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
     if (threadIdx.x == 0) *T.at(0, S::RS + RS_TILE * 16) = 0.f;            // "some row switched solves in this attempt"
     __syncthreads();
     int any = 0;
-    if (wave == 0 && T.lane < 16) {        // row leaders
-      auto sum8 = [&](int base) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(T.at(T.o_l8, base)), v = *reinterpret_cast<const f32x4*>(T.at(T.o_l8, base + 4));
-        return ((u[0] + u[1]) + (u[2] + u[3])) + ((v[0] + v[1]) + (v[2] + v[3]));
-      };
-      auto R1 = [&](int field) -> float& { return *T.at(T.o_l1, S::RS + field * 16); };
-      const float mode = R1(RS_MODE);
-      float flag = 0.f, sw = 0.f;
-      // divergence partials of this row: full evaluation: M-row = row, direction already applied; compact evaluation: M-row
-      // 8 + rank(row), raw
-      const int dl_off = cmode == 0 ? T.o_l8 : (8 + (int)R1(RS_RANK)) * 32;
-      const float dl_sg = cmode == 0 ? 1.f : (R1(RS_SIGN) > 0.f ? -1.f : 1.f);
-      auto dlsum = [&](int base) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(T.at(dl_off, base)), v = *reinterpret_cast<const f32x4*>(T.at(dl_off, base + 4));
-        return dl_sg * (((u[0] + u[1]) + (u[2] + u[3])) + ((v[0] + v[1]) + (v[2] + v[3])));
-      };
-      if (mode == (float)RM_INIT0) {
-        // f0 sits in k[1] (slot 0 of the attempt): initial step size, part 1
-        if (R1(RS_SOLVE) != 0.f && f.mode == MFM_FLOW_IMH)                 // ref.logprob(u0) - ref.logprob(up)  (:254-255)
-          R1(RS_LQ) = -0.5f * (sum8(S::RED + 4 * 128) - sum8(S::RED + 5 * 128)) / (f.ref_std * f.ref_std);
-        const float dl0 = dlsum(S::DLP + 1 * 128);
-        const float a1 = dl0 / atol;
-        const float d0 = sqrtf(sum8(S::RED + 0 * 128)), d1 = sqrtf(sum8(S::RED + 1 * 128) + a1 * a1);
-        const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
-        R1(RS_H0) = h0; R1(RS_D1) = d1; R1(RS_KL + 0) = dl0;
-        R1(RS_DT) = h0; R1(RS_MODE) = (float)RM_INIT1;
-        flag = 3.f;
-      } else if (mode == (float)RM_INIT1) {
-        const float h0 = R1(RS_H0), d1 = R1(RS_D1);
-        const float a2 = (dlsum(S::DLP + 1 * 128) - R1(RS_KL + 0)) / atol;
-        const float d2 = sqrtf(sum8(S::RED + 2 * 128) + a2 * a2) / h0;
-        const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
-        float dt = fminf(100.f * h0, h1);
-        if constexpr (RP) { const size_t o = a.rp.at((int)R1(RS_SOLVE), b0 + T.lane, 0); a.rp.dt_own[o] = dt; dt = a.rp.dt[o]; }
-        R1(RS_DT) = dt; R1(RS_MODE) = (float)RM_ATT;
-        flag = 0.f;
-      } else if (mode == (float)RM_ATT) {
-        float kl[7];
-        kl[0] = R1(RS_KL + 0);
-#pragma unroll
-        for (int j = 1; j < 7; ++j) kl[j] = dlsum(S::DLP + j * 128);
-        const float e2 = sum8(S::RED + 3 * 128);
-        const float t0 = R1(RS_T), dti = R1(RS_DT), ell0 = R1(RS_ELL), na = R1(RS_NATT);
-        const bool active = na < (float)max_attempts && dti > 0.f;
-        float sl = 0.f, el = 0.f, lm = 0.f;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) sl += DP_TAB[7][j] * kl[j];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) el += DP_E[j] * kl[j];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) lm += DP_M[j] * kl[j];
-        const float l1 = ell0 + dti * sl;
-        el *= dti;
-        const float tol = atol + rtol * fmaxf(fabsf(ell0), fabsf(l1));
-        const float rr = el / tol;
-        const float ratio = sqrtf((e2 + rr * rr) * inv_n);
-        bool acc = active && ratio <= 1.f;
-        const float dfac = ratio < 1.f ? 1.f : 0.2f;
-        const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
-        float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
-        if constexpr (RP) {
-          if (active) {
-            const int j = (int)na;
-            const bool in = j < a.rp.cap, nx = j + 1 < a.rp.cap;
-            const size_t o = a.rp.at((int)R1(RS_SOLVE), b0 + T.lane, in ? j : 0);
-            if (in) { a.rp.ratio[o] = ratio; if (nx) a.rp.dt_own[o + 1] = ndt; }
-            acc = in && a.rp.acc[o] != 0;
-            ndt = nx ? a.rp.dt[o + 1] : 0.f;
-          }
-        }
-        const float tn = t0 + dti;
-        const bool fin = acc && tn >= 1.f, adv = acc && !(tn >= 1.f);
-        const float sfrac = (1.f - t0) / (tn - t0);
-        const float y0 = ell0, ym = y0 + dti * lm, f0 = dti * kl[0], f1 = dti * kl[6];
-        const float pa = -2.f * f0 + 2.f * f1 - 8.f * y0 - 8.f * l1 + 16.f * ym;
-        const float pb = 5.f * f0 - 3.f * f1 + 18.f * y0 + 14.f * l1 - 32.f * ym;
-        const float pc = -4.f * f0 + f1 - 11.f * y0 - 5.f * l1 + 16.f * ym;
-        const float li = (((pa * sfrac + pb) * sfrac + pc) * sfrac + f0) * sfrac + y0;
-        const float dt_n = active ? ndt : dti, na_n = active ? na + 1.f : na;
-        const float ell_n = fin ? li : (adv ? l1 : ell0);
-        // the solve ends when t reaches 1, or (as in odeint's while_loop) when the step budget / step size runs out
-        const bool over = fin || !(na_n < (float)max_attempts && dt_n > 0.f);
-        flag = fin ? 2.f : (adv ? 1.f : 0.f);
-        R1(RS_SFRAC) = sfrac;
-        if (!over) {
-          R1(RS_T) = acc ? tn : t0; R1(RS_DT) = dt_n; R1(RS_ELL) = ell_n; R1(RS_KL + 0) = adv ? kl[6] : kl[0]; R1(RS_NATT) = na_n;
-        } else if (R1(RS_SOLVE) == 0.f) {
-          // inverse solve done: keep vol0, start this row's forward solve (:268-269 / :249-250)
-          R1(RS_VOL0) = ell_n; R1(RS_NTOT) = na_n;
-          R1(RS_T) = 0.f; R1(RS_DT) = 0.f; R1(RS_ELL) = 0.f; R1(RS_KL + 0) = 0.f; R1(RS_NATT) = 0.f;
-          R1(RS_SOLVE) = 1.f; R1(RS_SIGN) = 1.f; R1(RS_MODE) = (float)RM_INIT0;
-          sw = 1.f;
-          *T.at(0, S::RS + RS_TILE * 16) = 1.f;
-        } else {
-          R1(RS_ELL) = ell_n; R1(RS_NATT) = na_n; R1(RS_MODE) = (float)RM_DONE;
-        }
-      }
-      R1(RS_FLAG) = flag; R1(RS_SW) = sw;
-      any = R1(RS_MODE) != (float)RM_DONE ? 1 : 0;
-      // rank of this row among the rows that take part in the next attempt: with <= 3 of them the time batch is compacted
-      const unsigned long long bal = __ballot(any != 0);
-      R1(RS_RANK) = any ? (float)__popcll(bal & ((1ull << T.lane) - 1ull)) : -1.f;
-      if (T.lane == 0) { const int na = __popcll(bal); *T.at(0, S::RS + RS_TILE * 16 + 1) = na <= MICRO_ROWS ? 3.f : (na <= 3 ? 2.f : (na <= 8 ? 1.f : 0.f)); }
-    }
+    if (wave == 0 && T.lane < 16) any = leaders_end_of_attempt<D, RP, false>(T, a, f, b0, cmode);
     const int go = __syncthreads_or(any);
     // ---- every lane: apply the decision of its rows (branch-free selects) ----
     const bool tile_sw = *T.at(0, S::RS + RS_TILE * 16) != 0.f;
@@ -1408,6 +1865,10 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
       }
     }
     if (!go) break;
+    if (MICRO_ROWS > 0 && *T.at(0, S::RS + RS_TILE * 16 + 1) == 3.f) {      // <= 2 rows left: the tile's tail runs in a loop of its own
+      solve2_tail<D, RP>(T, a, f, b0, y, k);
+      break;
+    }
     phase = 2;
   }
 }
