@@ -232,8 +232,8 @@ __device__ static const float C5[5] = {1.f / 5, 3.f / 10, 4.f / 5, 8.f / 9, 1.f}
 enum { RS_MODE = 16, RS_SOLVE = 17, RS_SIGN = 18, RS_VOL0 = 19, RS_NTOT = 20, RS_LQ = 21, RS_SW = 22, RS_TILE = 23,
        RS_RANK = 13 /* = RS_DONE, unused by solve2: rank of the row among the rows still integrating, -1 otherwise */ };
 enum { RM_INIT0 = 0, RM_INIT1 = 1, RM_ATT = 2, RM_DONE = 3 };
-#ifndef MICRO_ROWS
-#define MICRO_ROWS 2          // rows at or below which a tile's attempts run on the 4-row MFMA path (eval_m); 0 disables it
+#ifndef TAIL_PASSES
+#define TAIL_PASSES 2         // a tile enters the tail with <= 2 TAIL_PASSES live rows (1: the round-3 two-row tail)
 #endif
 
 template <int D>
@@ -258,6 +258,8 @@ struct FTile {
   __device__ __forceinline__ float* at(int off_bytes, int cfloats) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + off_bytes) + cfloats; }
 #ifdef MFM_STAMPS
   unsigned long long n_em = 0, cyc_em = 0, n_t1 = 0, cyc_t1 = 0;      // micro evaluations, single-tile time batches
+  unsigned long long cyc_si = 0, cyc_n1 = 0, cyc_n2 = 0, cyc_n3 = 0;      // main loop outside the batch and the evaluations: stage inputs, norms, leaders' barrier, decision
+  unsigned long long cyc_tail = 0, cyc_done = 0;      // time in the tail loops; kernel start -> this tile done (before the noise work)
   unsigned long long n_tc = 0, cyc_tc = 0;      // compacted time batches
   unsigned long long n_ec = 0, cyc_ec = 0;      // compact evaluations
   unsigned long long n_eval = 0, cyc_eval = 0, n_tb = 0, cyc_tb = 0, cyc_sec[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sec_t0 = 0;
@@ -502,31 +504,111 @@ struct FTile {
     // so on every SIMD one wave's VALU phase runs beside its partner's MFMAs instead of both stalling the matrix pipe
     // at the head of the out job.
     float gc[TPW][4], hz[TPW][4], zz[TPW][4];
+    const float icoef = 1.f / coef;
+    auto tt_elem = [&](int q, int i) {
+      const float* xr = at(o_xo + xsel, i * LDX + 128 * q);
+      const float* zr = at(o_xo, S::ZB + i * LDX + 128 * q);
+      const float x = xr[0], z = zr[0];
+      const float graw = -tbeta * (coef * (2.f * x - xr[-1] - xr[1]) - x * (1.f - x * x) * icoef);
+      const float hv = -tbeta * (coef * (2.f * z - zr[-1] - zr[1]) - (1.f - 3.f * x * x) * z * icoef);
+      gc[q][i] = clip > 0.f ? fminf(fmaxf(graw, -clip), clip) : graw;
+      hz[q][i] = (!(clip > 0.f) || fabsf(graw) <= clip) ? hv : 0.f;
+      zz[q][i] = z;
+    };
     auto target_terms = [&]() {
-      const float icoef = 1.f / coef;
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float* xr = at(o_xo + xsel, i * LDX + 128 * q);
-          const float* zr = at(o_xo, S::ZB + i * LDX + 128 * q);
-          const float x = xr[0], z = zr[0];
-          const float graw = -tbeta * (coef * (2.f * x - xr[-1] - xr[1]) - x * (1.f - x * x) * icoef);
-          const float hv = -tbeta * (coef * (2.f * z - zr[-1] - zr[1]) - (1.f - 3.f * x * x) * z * icoef);
-          gc[q][i] = clip > 0.f ? fminf(fmaxf(graw, -clip), clip) : graw;
-          hz[q][i] = (!(clip > 0.f) || fabsf(graw) <= clip) ? hv : 0.f;
-          zz[q][i] = z;
-        }
+        for (int i = 0; i < 4; ++i) tt_elem(q, i);
       }
     };
 #ifndef MFM_TT_MODE
-#define MFM_TT_MODE 0        // 0: waves 0-3 before their x1 job, waves 4-7 after theirs (stagger); 1: every wave before; 2: every wave after
-                             // (same-trajectory A/B, tools/flow_ab.py, round 2: 52.75 / 52.95 / 53.03 ms)
+#define MFM_TT_MODE 3        // 0: waves 0-3 before their x1 job, waves 4-7 after theirs (stagger); 1: every wave before; 2: every wave after
+                             // (same-trajectory A/B, tools/flow_ab.py, round 2: 52.75 / 52.95 / 53.03 ms: none of them overlaps anything --
+                             // a wave issues in order, so its vector work only runs in the shadow of ITS OWN queued MFMAs);
+                             // 3 (round 4): every wave, INSIDE its x1 job: two elements per fragment group, the scheduler told to put
+                             // vector and LDS instructions between the group's sixteen MFMAs (sched_group_barrier)
 #endif
     if (MFM_TT_MODE == 1 || (MFM_TT_MODE == 0 && wave < NW / 2)) target_terms();
     {   // x1: value rows; tangent rows = relu' * (z W_x1)
       f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-      run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(at(o_xa + xsel, 0), wr, W(S::W2, wave, D / 16), W(S::W3, wave, 8), lane, P, Q, acc);
+      if constexpr (MFM_TT_MODE == 3) {
+        // One PAIR of elements (q, i0), (q, i0 + 1) per fragment group of sixteen MFMAs; its six pieces sit between the group's MFMAs,
+        // fenced so they stay there, and the operands of the next pair are fetched one group ahead.  The arithmetic is spelled with
+        // explicit fused multiply-adds in the form the compiler chose for target_terms(): the two are bit-identical.
+        constexpr int G = D / 64;                 // fragment groups of four k-blocks = pairs of elements (4 TPW / 2)
+        const float* arow = at(o_xa + xsel, 0);
+        const int w0 = W(S::W2, wave, D / 16), wnx = W(S::W3, wave, 8);
+        const float ntb = -tbeta;
+        float ox[2][2][6];                        // [buffer][element of the pair][x, x-, x+, z, z-, z+]
+        auto tt_fetch = [&](int p, float (&o)[2][6]) {
+          const int q = p >> 1, i0 = 2 * (p & 1);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float* xr = at(o_xo + xsel, (i0 + e) * LDX + 128 * q);
+            const float* zr = at(o_xo, S::ZB + (i0 + e) * LDX + 128 * q);
+            o[e][0] = xr[0]; o[e][1] = xr[-1]; o[e][2] = xr[1]; o[e][3] = zr[0]; o[e][4] = zr[-1]; o[e][5] = zr[1];
+          }
+        };
+        float lx[2], lz[2], ax[2], bz[2], gr[2], hv[2];
+        auto piece = [&](int p, int k, const float (&o)[2][6]) {
+          const int q = p >> 1, i0 = 2 * (p & 1);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float x = o[e][0], z = o[e][3];
+            if (k == 0) { lx[e] = __builtin_fmaf(x, 2.f, -o[e][1]) - o[e][2]; lz[e] = __builtin_fmaf(z, 2.f, -o[e][4]) - o[e][5]; }
+            if (k == 1) ax[e] = icoef * (x * __builtin_fmaf(-x, x, 1.f));
+            if (k == 2) { gr[e] = __builtin_fmaf(coef, lx[e], -ax[e]) * ntb; bz[e] = icoef * (z * __builtin_fmaf(-x, x * 3.f, 1.f)); }
+            if (k == 3) hv[e] = __builtin_fmaf(coef, lz[e], -bz[e]) * ntb;
+            if (k == 4) {
+              gc[q][i0 + e] = clip > 0.f ? fminf(fmaxf(gr[e], -clip), clip) : gr[e];
+              hz[q][i0 + e] = (!(clip > 0.f) || fabsf(gr[e]) <= clip) ? hv[e] : 0.f;
+              zz[q][i0 + e] = z;
+            }
+          }
+          // pin the piece where it stands: pure arithmetic is otherwise sunk to its first use (the last piece) before the
+          // instruction scheduler ever sees it, whatever the scheduling fences say
+          if (k == 0) asm volatile("" : "+v"(lx[0]), "+v"(lx[1]), "+v"(lz[0]), "+v"(lz[1]));
+          if (k == 1) asm volatile("" : "+v"(ax[0]), "+v"(ax[1]));
+          if (k == 2) asm volatile("" : "+v"(gr[0]), "+v"(gr[1]), "+v"(bz[0]), "+v"(bz[1]));
+          if (k == 3) asm volatile("" : "+v"(hv[0]), "+v"(hv[1]));
+          if (k == 4) asm volatile("" : "+v"(gc[q][i0]), "+v"(gc[q][i0 + 1]), "+v"(hz[q][i0]), "+v"(hz[q][i0 + 1]));
+        };
+        tt_fetch(0, ox[0]);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          f32x4 (&B)[4] = (gi & 1) ? Q : P;
+          f32x4 (&N)[4] = (gi & 1) ? P : Q;
+          if (gi + 1 < G) load_group<1, 0>(N, wr, w0 + (gi + 1) * 4 * 1024, lane);
+          else load_group<1, 0>(N, wr, wnx, lane);
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 an = *reinterpret_cast<const f32x4*>(arow + gi * 64);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const f32x4 a = an;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              acc[u & 1] = mfma4(a[s4], B[u][s4], acc[u & 1]);
+              const int slot = u * 4 + s4;                              // 0..15 inside the group
+              __builtin_amdgcn_sched_barrier(0);
+              if (s4 == 0 && u < 3) { an = *reinterpret_cast<const f32x4*>(arow + gi * 64 + (u + 1) * 16); asm volatile("" ::: "memory"); }   // A fragment one k-block ahead
+              if (slot == 1 && gi + 1 < G) { tt_fetch(gi + 1, ox[(gi + 1) & 1]); asm volatile("" ::: "memory"); }      // issued here, awaited a group later
+              if (slot == 3) piece(gi, 0, ox[gi & 1]);
+              if (slot == 5) piece(gi, 1, ox[gi & 1]);
+              if (slot == 7) piece(gi, 2, ox[gi & 1]);
+              if (slot == 9) piece(gi, 3, ox[gi & 1]);
+              if (slot == 12) piece(gi, 4, ox[gi & 1]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        if constexpr (G & 1) {                    // (never: G = 2 or 4) the job must end with its next group in P
+#pragma unroll
+          for (int j = 0; j < 4; ++j) P[j] = Q[j];
+        }
+      } else {
+        run_job<1, 1, D / 16, LDX, 0, 1, 0, true>(at(o_xa + xsel, 0), wr, W(S::W2, wave, D / 16), W(S::W3, wave, 8), lane, P, Q, acc);
+      }
       FSEC(8);
       if (MFM_TT_MODE == 2 || (MFM_TT_MODE == 0 && wave >= NW / 2)) target_terms();
       const float b = bias(S::B2);
@@ -1121,8 +1203,8 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
 // 2 finish, 3 initial slope) and the interpolation abscissa.  Shared by the tile's main loop (solve2) and its tail (solve2_tail).
 // STICKY: the rows keep the slots they were given when the tail began (RS_RANK = slot or -1); otherwise ranks and the tile's
 // evaluation mode are recomputed from the rows that take part in the next attempt.  Returns "this row takes part in it".
-template <int D, bool RP, bool STICKY>
-__device__ __forceinline__ int leaders_end_of_attempt(FTile<D>& T, const OdeArgs& a, const FlowArgs& f, int b0, int cmode) {
+template <int D, bool RP, bool STICKY, typename AA, typename FA>
+__device__ __forceinline__ int leaders_end_of_attempt(FTile<D>& T, const AA& a, const FA& f, int b0, int cmode) {
   using S = FS<D>;
   const float rtol = a.rtol, atol = a.atol;
   const int max_attempts = a.max_attempts;
@@ -1235,7 +1317,7 @@ __device__ __forceinline__ int leaders_end_of_attempt(FTile<D>& T, const OdeArgs
     // rank of this row among the rows that take part in the next attempt: with <= 3 of them the time batch is compacted
     const unsigned long long bal = __ballot(any != 0);
     R1(RS_RANK) = any ? (float)__popcll(bal & ((1ull << ln) - 1ull)) : -1.f;
-    if (ln == 0) { const int na = __popcll(bal); *T.at(0, S::RS + RS_TILE * 16 + 1) = na <= MICRO_ROWS ? 3.f : (na <= 3 ? 2.f : (na <= 8 ? 1.f : 0.f)); }
+    if (ln == 0) { const int na = __popcll(bal); *T.at(0, S::RS + RS_TILE * 16 + 1) = na <= 2 * TAIL_PASSES ? 3.f : ((TAIL_PASSES < 2 && na <= 3) ? 2.f : (na <= 8 ? 1.f : 0.f)); }
   }
   return any;
 }
@@ -1261,16 +1343,22 @@ __device__ __forceinline__ int leaders_end_of_attempt(FTile<D>& T, const OdeArgs
 // Arithmetic: per-row controller, interpolation and step sizes are those of the main loop bit for bit (leaders_end_of_attempt); the
 // evaluation is eval_m's (4 x 4 x 1 MFMA, k-sum per 16-lane group then over the groups), the time batch sums K = 256 in the even /
 // odd k-block order of the single-tile batch, now over both halves at once (a float reassociation of the first time layer).
-template <int D>
+template <int D, int P>
 struct TailMap {
   using S = FS<D>;
-  static constexpr int LDF = 2 * F + 8;                       // Fourier image [16][cos 128 | sin 128]
-  static constexpr int LDT = D + H + 8;                       // time-batch results [16][gate D | j1t H]
-  static constexpr int FH2 = S::R, T1I = S::R + 32 * S::LDH, STI = S::R + 48 * S::LDH;      // dead once the batch is done
-  static constexpr int A1 = S::R, SX = S::R + 32 * S::LDH, J1 = S::R2, J2 = S::R2 + 32 * S::LDH;   // 4-row images of the x branch (as eval_m)
-  static constexpr int TBR = S::R2 + 48 * S::LDH;             // lives through the attempt
-  static constexpr int STG = S::R2;                           // [2 slots][8][D]: state transfer at entry (before the first evaluation)
-  static_assert(16 * LDF <= 32 * S::LDH && TBR + 16 * LDT <= S::TOTAL && 36 <= 48 && 2 * 8 * D <= 48 * S::LDH, "tail LDS map");
+  static constexpr int NS = 2 * P;                            // slots
+  static constexpr int MT = (10 * P + 15) / 16;               // M tiles of the time batch: M-row NS * stage + slot
+  static constexpr int LDF = 2 * F + 8;                       // Fourier image [16 MT][cos 128 | sin 128]
+  static constexpr int LDT = D + H + 8;                       // time-batch results [10 P][gate D | j1t H]
+  static constexpr int IMG = 4 * P * S::LDH;                  // one image of the x branch: pass p owns rows 4 p .. 4 p + 3 (as eval_m)
+  // area U (dead once the batch is done, then the four x-branch images): the Fourier image, later t1 | st side by side
+  static constexpr int USZ = (16 * MT * LDF > 2 * 16 * MT * S::LDH ? 16 * MT * LDF : 2 * 16 * MT * S::LDH) > 4 * IMG
+                           ? (16 * MT * LDF > 2 * 16 * MT * S::LDH ? 16 * MT * LDF : 2 * 16 * MT * S::LDH) : 4 * IMG;
+  static constexpr int FH2 = S::R, T1I = S::R, STI = S::R + 16 * MT * S::LDH;
+  static constexpr int A1 = S::R, SX = A1 + IMG, J1 = SX + IMG, J2 = J1 + IMG;
+  static constexpr int TBR = S::R + USZ;                      // lives through the attempt
+  static constexpr int STG = S::R;                            // [slot][y, k_1..7][D]: state transfer at entry and exit
+  static_assert(TBR + 10 * P * LDT <= S::TOTAL && NS * 8 * D <= S::TOTAL - S::R && 4 * P <= 16, "tail LDS map");
   // fragment i of the attempt's time batch / of an evaluation, wave w: byte offset in the packed weights
   static __device__ __forceinline__ int tb_soff(int i, int w) {
     constexpr int G = 8 * FTile<D>::TPW;
@@ -1280,79 +1368,95 @@ struct TailMap {
          : S::W5 * 4 + (w * 16 + 8 + i - 24 - G) * 1024;
   }
   static constexpr int NTB = 32 + 8 * FTile<D>::TPW;
+  // the out layer's fragments come column tile by column tile (q-major): one accumulator set per pass is live at a time
   static __device__ __forceinline__ int ev_soff(int i, int w) {
-    constexpr int K1 = D / 16, TPW = FTile<D>::TPW;
+    constexpr int K1 = D / 16;
     return i < K1 ? S::W2 * 4 + (w * K1 + i) * 1024
          : i < K1 + 8 ? S::W3 * 4 + (w * 8 + i - K1) * 1024
          : i < K1 + 16 ? S::W5 * 4 + (w * 16 + i - K1 - 8) * 1024
          : i < K1 + 24 ? S::W6 * 4 + (w * 8 + i - K1 - 16) * 1024
-         : S::W7 * 4 + ((w + 8 * ((i - K1 - 24) % TPW)) * 8 + (i - K1 - 24) / TPW) * 1024;
+         : S::W7 * 4 + ((w + 8 * ((i - K1 - 24) >> 3)) * 8 + ((i - K1 - 24) & 7)) * 1024;
   }
   static constexpr int NEV = D / 16 + 24 + 8 * FTile<D>::TPW;
   static_assert(NTB % 8 == 0 && NEV % 8 == 0, "the ring positions are static");
 };
 
-template <int D, bool RP>
-__device__ __forceinline__ void solve2_tail(FTile<D>& T, const OdeArgs& a, const FlowArgs& f, int b0, float (&y)[FTile<D>::TPW][4],
-                                            float (&kfull)[7][FTile<D>::TPW][4]) {
+// Runs the tile from <= 2 P live rows until <= 2 (P - 1) are left (P = 1: until none is).  Entry: RS_RANK = rank of the row among
+// the live ones (-1: not live), the Runge-Kutta state of live row r in STG[rank r] (y, k_1..7: written by the caller, or by the loop
+// that just ended), a barrier since.  Exit: the same for the rows that are still live, ranked again; the final y of a row that
+// ended here in its (now free) row of the probe image.  Nothing is passed in registers: the full layout's sixty-four state
+// registers must not stay live across these loops (when they did, the allocator spilled them inside the MAIN loop).
+// (what the loops need of the kernel's arguments, by value: the loops are functions of their own -- see below -- and a reference to
+// the kernel's argument structs would pin those to memory for the main loop as well)
+struct TailArgs {
+  float rtol, atol; int max_attempts;
+  float coef, tbeta, clip; const float* fourier; const float* Wp;
+  const float* zgen; const float* z2;
+  int mode; float ref_std;                                    // FlowArgs::mode, ::ref_std
+  Replay rp;
+};
+// NOT inlined: inlined into solve2, the three loops changed the register allocation of the MAIN loop (its Runge-Kutta stages went
+// to scratch: 50 -> 63 ms).  As functions they get an allocation of their own and the main loop keeps the one it had.
+template <int D, bool RP, int P>
+__device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
   using S = FS<D>;
-  using M = TailMap<D>;
+  using M = TailMap<D, P>;
+  // The workgroup's LDS and the weight descriptor are formed HERE: as arguments they arrive as a flat pointer (every LDS address
+  // a 64-bit sum of its own, no immediate offsets) and as a descriptor in vector registers (every buffer load in a waterfall loop).
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn_[];
+  FTile<D> T;
+  T.lds = lds_dyn_;
+  {
+    const unsigned long long wp = (unsigned long long)a.Wp;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)wp), hi = __builtin_amdgcn_readfirstlane((unsigned)(wp >> 32));
+    T.wr = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, S::WTOT * 4, 0x00020000);
+  }
+  const TailArgs& f = a;
   constexpr int TPW = FTile<D>::TPW, LDX = S::LDX, LDH = S::LDH, LDF = M::LDF, LDT = M::LDT, NTB = M::NTB, NEV = M::NEV, K1 = D / 16;
+  constexpr int NS = M::NS, MT = M::MT;
   // Every per-lane quantity of this loop is derived HERE from an opaque copy of the thread index: values computed before the main
   // loop (the tile's lane coordinates, its LDS offsets) are live across it, where all 256 registers are taken, so the allocator
   // spills their whole live range and every use in this loop would be a scratch reload -- a vector-memory load whose wait drains
   // the weight ring (seen in the ISA of the first version: one reload per layer for the bias column alone).
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));
-  const int lane = tid_ & 63, g = lane >> 4, c = lane & 15, wave = T.wave;
-  const int slot = g & 1;
+  const int lane = tid_ & 63, g = lane >> 4, c = lane & 15, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+  const int sl2 = g & 1;                                      // slot of this lane inside a pass
   const bool is_t = g >= 2;
   float* const lds = T.lds;
   const float scale = 2.38f / sqrtf((float)D);                                                  // :262
   const float rtol = a.rtol, atol = a.atol;
-  const float t_coef = a.net.T.coef, t_beta = a.net.T.tbeta, t_clip = a.net.grad_clip;
-  const float ffreq = a.net.fourier[16 * wave + c];
+  const float t_coef = a.coef, t_beta = a.tbeta, t_clip = a.clip;
+  const float ffreq = a.fourier[16 * wave + c];
   const float* const biasp = lds + S::BIAS + 16 * wave + c;    // column 16 wave + c (+ 128 q) of a layer's bias
   auto RSF = [&](int field, int row) -> float& { return lds[S::RS + field * 16 + row]; };
   // ---- slots: the row that holds rank r now keeps slot r ----
-  int row0, row1;
+  int rowof[NS];
   {
     const float rkv = RSF(RS_RANK, lane & 15);
-    const unsigned long long m0 = __ballot(rkv == 0.f) & 0xFFFFull, m1 = __ballot(rkv == 1.f) & 0xFFFFull;
-    row0 = m0 ? __builtin_ctzll(m0) : -1; row1 = m1 ? __builtin_ctzll(m1) : -1;
-  }
-  const int myrow = slot ? row1 : row0;
-  const int mr = myrow < 0 ? 0 : myrow;                      // (an empty slot computes on row 0's numbers and stores nothing)
-  // ---- state of the two rows: full layout -> [slot][y, k_1..7][D] -> compact layout ----
-  unsigned intail = 0;
-  {
-    const f32x4 rk4 = T.rs_get(RS_RANK);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (rk4[i] >= 0.f) {
-        intail |= 1u << i;
-        const int r = (int)rk4[i];
-#pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-          const int col = 16 * (wave + NW * q) + c;
-          lds[M::STG + (r * 8 + 0) * D + col] = y[q][i];
-#pragma unroll
-          for (int j = 0; j < 7; ++j) lds[M::STG + (r * 8 + 1 + j) * D + col] = kfull[j][q][i];
-        }
-      }
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const unsigned long long m = __ballot(rkv == (float)s_) & 0xFFFFull;
+      rowof[s_] = m ? __builtin_ctzll(m) : -1;
     }
   }
-  __syncthreads();
-  float ym[TPW], km[7][TPW];
+  int myrow[P], mr[P];
 #pragma unroll
-  for (int q = 0; q < TPW; ++q) {
-    const int col = 16 * (wave + NW * q) + c;
-    ym[q] = lds[M::STG + (slot * 8 + 0) * D + col];
+  for (int p = 0; p < P; ++p) { myrow[p] = sl2 ? rowof[2 * p + 1] : rowof[2 * p]; mr[p] = myrow[p] < 0 ? 0 : myrow[p]; }   // (an empty slot computes on row 0's numbers and stores nothing)
+  float ym[P][TPW], km[P][7][TPW];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) km[j][q] = lds[M::STG + (slot * 8 + 1 + j) * D + col];
-    if (!is_t && myrow >= 0) {                                // probe rows 2, 3 of both stage-input images
-      const float z = lds[S::ZB + myrow * LDX + 4 + col];
-      lds[S::XB0 + (2 + slot) * LDX + 4 + col] = z; lds[S::XB1 + (2 + slot) * LDX + 4 + col] = z;
+  for (int p = 0; p < P; ++p) {
+    const int slot = 2 * p + sl2;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int col = 16 * (wave + NW * q) + c;
+      ym[p][q] = lds[M::STG + (slot * 8 + 0) * D + col];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) km[p][j][q] = lds[M::STG + (slot * 8 + 1 + j) * D + col];
+      if (!is_t && myrow[p] >= 0) {                           // probe rows 4 p + 2, 4 p + 3 of both stage-input images
+        const float z = lds[S::ZB + myrow[p] * LDX + 4 + col];
+        lds[S::XB0 + (4 * p + 2 + sl2) * LDX + 4 + col] = z; lds[S::XB1 + (4 * p + 2 + sl2) * LDX + 4 + col] = z;
+      }
     }
   }
   __syncthreads();
@@ -1361,64 +1465,86 @@ __device__ __forceinline__ void solve2_tail(FTile<D>& T, const OdeArgs& a, const
   const int voff = lane * 16;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ring[i] = bload(T.wr, voff, M::tb_soff(i, wave));
-  // one fragment = one k-block of one column tile: A from LDS, four MFMAs, then the slot is refilled eight fragments ahead
-#define TAIL_F4(I, AP, ACC, NEXT)                                                                                       \
+  // one fragment = one k-block of one column tile: per pass (per M tile) A from LDS and four MFMAs, then the ring slot is refilled
+  // eight fragments ahead
+#define TAIL_F4(I, AP, PSTRIDE, ACC, NEXT)                                                                              \
   {                                                                                                                    \
-    const f32x4 a_ = *reinterpret_cast<const f32x4*>(AP);                                                              \
     const f32x4 b_ = ring[(I) & 7];                                                                                    \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) (ACC)[s_] = mfma1(a_[s_], b_[s_], (ACC)[s_]);                    \
+    _Pragma("unroll") for (int p_ = 0; p_ < P; ++p_) {                                                                 \
+      const f32x4 a_ = *reinterpret_cast<const f32x4*>((AP) + p_ * (PSTRIDE));                                        \
+      _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) (ACC)[p_][s_] = mfma1(a_[s_], b_[s_], (ACC)[p_][s_]);          \
+    }                                                                                                                  \
     ring[(I) & 7] = bload(T.wr, voff, (NEXT));                                                                         \
     asm volatile("" ::: "memory");                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
   }
-#define TAIL_F16(I, AP, ACC, NEXT)                                                                                      \
+#define TAIL_F16(I, AP, ACC, EO, NEXT)                                                                                  \
   {                                                                                                                    \
-    const f32x4 a_ = *reinterpret_cast<const f32x4*>(AP);                                                              \
     const f32x4 b_ = ring[(I) & 7];                                                                                    \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) (ACC) = mfma4(a_[s_], b_[s_], (ACC));                            \
+    _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                                                \
+      const f32x4 a_ = *reinterpret_cast<const f32x4*>((AP) + m_ * 16 * (LDA_));                                       \
+      _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) (ACC)[m_][EO] = mfma4(a_[s_], b_[s_], (ACC)[m_][EO]);          \
+    }                                                                                                                  \
     ring[(I) & 7] = bload(T.wr, voff, (NEXT));                                                                         \
     asm volatile("" ::: "memory");                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
   }
   const int colw = 16 * wave + c;                             // this lane's column inside a 128-wide layer
   int cur = 0;
+#ifdef MFM_STAMPS
+  const unsigned long long tp0_ = __builtin_amdgcn_s_memtime();
+  unsigned long long tp_att_ = 0;
+#endif
 #pragma unroll 1
   for (;;) {
-    const float mode = RSF(RS_MODE, mr), hs = RSF(RS_DT, mr), sgn = RSF(RS_SIGN, mr);
-    const bool alive = myrow >= 0 && RSF(RS_RANK, mr) >= 0.f;
-    const bool att = mode == (float)RM_ATT, in1 = mode == (float)RM_INIT1;
+#ifdef MFM_STAMPS
+    tp_att_ += 1;
+#endif
+    float mode[P], hs[P], sgn[P];
+    bool alive[P], att[P], in1[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      mode[p] = RSF(RS_MODE, mr[p]); hs[p] = RSF(RS_DT, mr[p]); sgn[p] = RSF(RS_SIGN, mr[p]);
+      alive[p] = myrow[p] >= 0 && RSF(RS_RANK, mr[p]) >= 0.f;
+      att[p] = mode[p] == (float)RM_ATT; in1[p] = mode[p] == (float)RM_INIT1;
+    }
 #pragma unroll 1
     for (int phase = 2; phase < 8; ++phase) {
-      // ---- stage input of my slot -> X[cur] row slot ----
+      // ---- stage inputs of my slots -> X[cur] rows 4 p + slot ----
       {
         float cf[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) cf[j] = DP_TAB[phase][j];
-        const float c0 = (in1 && phase == 2) ? 1.f : cf[0];
-        const float he = (att || phase == 2) ? hs : 0.f;
         float* const X = lds + (cur ? S::XB1 : S::XB0);
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-          float acc = c0 * km[0][q];
+        for (int p = 0; p < P; ++p) {
+          const float c0 = (in1[p] && phase == 2) ? 1.f : cf[0];
+          const float he = (att[p] || phase == 2) ? hs[p] : 0.f;
 #pragma unroll
-          for (int j = 1; j < 6; ++j) acc += cf[j] * km[j][q];
-          const float xin = ym[q] + he * acc;
-          if (!is_t && alive) X[slot * LDX + 4 + colw + 128 * q] = xin;
+          for (int q = 0; q < TPW; ++q) {
+            float acc = c0 * km[p][0][q];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) acc += cf[j] * km[p][j][q];
+            const float xin = ym[p][q] + he * acc;
+            if (!is_t && alive[p]) X[(4 * p + sl2) * LDX + 4 + colw + 128 * q] = xin;
+          }
         }
       }
 #ifdef MFM_STAMPS
       const unsigned long long tb0_ = __builtin_amdgcn_s_memtime();
 #endif
       if (phase == 2) {
-        // ---- time batch: M-row 2 s + slot, s = 0..4 ----
+        // ---- time batch: M-row NS s + slot, s = 0..4 ----
         {
           const double fq = (double)ffreq;
 #pragma unroll
-          for (int pp = 0; pp < 3; ++pp) {
-            const int m = g + 4 * pp;                         // pair (stage m >> 1, slot m & 1), wave-uniform per lane group
-            if (m < 10) {
-              const int sl = m & 1, st = m >> 1;
-              const int rw = sl ? row1 : row0;
+          for (int pp = 0; pp < (10 * P + 3) / 4; ++pp) {
+            const int m = g + 4 * pp;                         // pair (stage m / NS, slot m % NS), wave-uniform per lane group
+            if (m < 10 * P) {
+              const int so = m % NS, st = m / NS;
+              int rw = rowof[0];
+#pragma unroll
+              for (int s_ = 1; s_ < NS; ++s_) rw = so == s_ ? rowof[s_] : rw;
               if (rw >= 0 && RSF(RS_RANK, rw < 0 ? 0 : rw) >= 0.f) {
                 const float md = RSF(RS_MODE, rw), t0 = RSF(RS_T, rw), h = RSF(RS_DT, rw), sg = RSF(RS_SIGN, rw);
                 // (stage fractions by selects: a table indexed per lane would be a vector-memory load, whose wait drains the weight ring)
@@ -1436,46 +1562,66 @@ __device__ __forceinline__ void solve2_tail(FTile<D>& T, const OdeArgs& a, const
           }
         }
         __syncthreads();
-        f32x4 ac[2];
-        const float* const af = lds + M::FH2 + (lane & 15) * LDF + 4 * g;
-        ac[0] = f32x4{0, 0, 0, 0}; ac[1] = f32x4{0, 0, 0, 0};
+        f32x4 ac[MT][2];
+        auto zero_b = [&]() {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) TAIL_F16(i, af + i * 16, ac[i & 1], M::tb_soff(i + 8, wave))
+          for (int m_ = 0; m_ < MT; ++m_) { ac[m_][0] = f32x4{0, 0, 0, 0}; ac[m_][1] = f32x4{0, 0, 0, 0}; }
+        };
+        const float* const af = lds + M::FH2 + (lane & 15) * LDF + 4 * g;
+        zero_b();
+#define LDA_ LDF
+#pragma unroll
+        for (int i = 0; i < 16; ++i) TAIL_F16(i, af + i * 16, ac, i & 1, M::tb_soff(i + 8, wave))
+#undef LDA_
+        __syncthreads();                                      // the Fourier image is dead: t1 takes its place
         {
-          const f32x4 t1 = ac[0] + ac[1];
           const float b = biasp[S::B0];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) lds[M::T1I + (4 * g + i) * LDH + colw] = fmaxf(t1[i] + b, 0.f);
+          for (int m_ = 0; m_ < MT; ++m_) {
+            const f32x4 t1 = ac[m_][0] + ac[m_][1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds[M::T1I + (16 * m_ + 4 * g + i) * LDH + colw] = fmaxf(t1[i] + b, 0.f);
+          }
         }
         __syncthreads();
         const float* const at1 = lds + M::T1I + (lane & 15) * LDH + 4 * g;
-        ac[0] = f32x4{0, 0, 0, 0}; ac[1] = f32x4{0, 0, 0, 0};
+        zero_b();
+#define LDA_ LDH
 #pragma unroll
-        for (int i = 0; i < 8; ++i) TAIL_F16(16 + i, at1 + i * 16, ac[i & 1], M::tb_soff(24 + i, wave))
+        for (int i = 0; i < 8; ++i) TAIL_F16(16 + i, at1 + i * 16, ac, i & 1, M::tb_soff(24 + i, wave))
         {
-          const f32x4 t2 = ac[0] + ac[1];
           const float b = biasp[S::B1];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) lds[M::STI + (4 * g + i) * LDH + colw] = fmaxf(t2[i] + b, 0.f);          // st
+          for (int m_ = 0; m_ < MT; ++m_) {
+            const f32x4 t2 = ac[m_][0] + ac[m_][1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds[M::STI + (16 * m_ + 4 * g + i) * LDH + colw] = fmaxf(t2[i] + b, 0.f);          // st
+          }
         }
         __syncthreads();
         const float* const ast = lds + M::STI + (lane & 15) * LDH + 4 * g;
 #pragma unroll
         for (int q = 0; q < TPW + 1; ++q) {                   // gate tiles wave (+ 8), then the st half of j1
-          ac[0] = f32x4{0, 0, 0, 0}; ac[1] = f32x4{0, 0, 0, 0};
+          zero_b();
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int fi = 24 + 8 * q + i;                    // fragment index in the batch; its refill is 8 ahead: the batch, then x1
-            TAIL_F16(fi, ast + i * 16, ac[i & 1], fi + 8 < NTB ? M::tb_soff(fi + 8, wave) : M::ev_soff(fi + 8 - NTB, wave))
+            TAIL_F16(fi, ast + i * 16, ac, i & 1, fi + 8 < NTB ? M::tb_soff(fi + 8, wave) : M::ev_soff(fi + 8 - NTB, wave))
           }
-          const f32x4 r = ac[0] + ac[1];
           const float b = q < TPW ? biasp[S::B4 + 128 * q] : biasp[S::B5];
           const int co = q < TPW ? 128 * q : D;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) lds[M::TBR + (4 * g + i) * LDT + co + colw] = r[i] + b;
+          for (int m_ = 0; m_ < MT; ++m_) {
+            const f32x4 r = ac[m_][0] + ac[m_][1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (16 * m_ + 4 * g + i < 10 * P) lds[M::TBR + (16 * m_ + 4 * g + i) * LDT + co + colw] = r[i] + b;
+          }
         }
-        // (no barrier here: the first read of these results comes after the evaluation's first barrier, and nothing the
-        // evaluation writes before it overlaps the images this batch still reads)
+#undef LDA_
+        // The x-branch images take the place of t1 | st: every wave must have finished reading st before the first
+        // evaluation's epilogue writes there
+        __syncthreads();
       } else {
         __syncthreads();
       }
@@ -1483,98 +1629,122 @@ __device__ __forceinline__ void solve2_tail(FTile<D>& T, const OdeArgs& a, const
       const unsigned long long ev0_ = __builtin_amdgcn_s_memtime();
       if (phase == 2) { T.cyc_t1 += ev0_ - tb0_; T.n_t1 += 1; }
 #endif
-      // ---- one field evaluation of the two slots on the 4-row images ----
-      float kv[TPW];
+      // ---- one field evaluation of the slots on the 4-row images ----
+      float kv[P][TPW];
       {
         const int ss = phase == 7 ? 4 : phase - 2;            // time slot of the stage
         const bool next_tb = phase == 7;
         const float* const X = lds + (cur ? S::XB1 : S::XB0);
-        const int mrow = 2 * ss + slot;
-        float gt[TPW], gc[TPW], hz[TPW], zz[TPW];
+        float gt[P][TPW], gc[P][TPW], hz[P][TPW], zz[P][TPW];
         auto target_terms = [&]() {
           const float icoef = 1.f / t_coef;
 #pragma unroll
-          for (int q = 0; q < TPW; ++q) {
-            const float* xr = X + slot * LDX + 4 + colw + 128 * q;
-            const float* zr = xr + 2 * LDX;
-            const float x = xr[0], z = zr[0];
-            const float graw = -t_beta * (t_coef * (2.f * x - xr[-1] - xr[1]) - x * (1.f - x * x) * icoef);
-            const float hv = -t_beta * (t_coef * (2.f * z - zr[-1] - zr[1]) - (1.f - 3.f * x * x) * z * icoef);
-            gc[q] = t_clip > 0.f ? fminf(fmaxf(graw, -t_clip), t_clip) : graw;
-            hz[q] = (!(t_clip > 0.f) || fabsf(graw) <= t_clip) ? hv : 0.f;
-            zz[q] = z;
+          for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+              const float* xr = X + (4 * p + sl2) * LDX + 4 + colw + 128 * q;
+              const float* zr = xr + 2 * LDX;
+              const float x = xr[0], z = zr[0];
+              const float graw = -t_beta * (t_coef * (2.f * x - xr[-1] - xr[1]) - x * (1.f - x * x) * icoef);
+              const float hv = -t_beta * (t_coef * (2.f * z - zr[-1] - zr[1]) - (1.f - 3.f * x * x) * z * icoef);
+              gc[p][q] = t_clip > 0.f ? fminf(fmaxf(graw, -t_clip), t_clip) : graw;
+              hz[p][q] = (!(t_clip > 0.f) || fabsf(graw) <= t_clip) ? hv : 0.f;
+              zz[p][q] = z;
+            }
           }
         };
-        f32x4 acc[TPW][4];
+        f32x4 acc[P][4];
         auto zero = [&]() {
 #pragma unroll
-          for (int q = 0; q < TPW; ++q)
+          for (int p = 0; p < P; ++p)
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) acc[q][s_] = f32x4{0, 0, 0, 0};
+            for (int s_ = 0; s_ < 4; ++s_) acc[p][s_] = f32x4{0, 0, 0, 0};
         };
-        // finish one layer: M-row g of this lane's column -> row g of the next layer's image
-        auto act_store = [&](float add, float* dst) {
-          const f32x4 pre = T.gsum((acc[0][0] + acc[0][1]) + (acc[0][2] + acc[0][3]));
-          const float pv = (slot ? pre[1] : pre[0]) + add, pt = slot ? pre[3] : pre[2];
-          dst[g * LDH + colw] = is_t ? (pv > 0.f ? pt : 0.f) : fmaxf(pv, 0.f);
+        // finish one layer: M-row g of this lane's column -> row 4 p + g of the next layer's image
+        auto act_store = [&](int p, float add, float* dst) {
+          const f32x4 pre = T.gsum((acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]));
+          const float pv = (sl2 ? pre[1] : pre[0]) + add, pt = sl2 ? pre[3] : pre[2];
+          dst[(4 * p + g) * LDH + colw] = is_t ? (pv > 0.f ? pt : 0.f) : fmaxf(pv, 0.f);
         };
         if (wave < NW / 2) target_terms();
         {   // x1 on [values ; probes]
           const float* const ax = X + (c & 3) * LDX + 4 + 4 * g;
           zero();
 #pragma unroll
-          for (int i = 0; i < K1; ++i) TAIL_F4(i, ax + i * 16, acc[0], M::ev_soff(i + 8, wave))
+          for (int i = 0; i < K1; ++i) TAIL_F4(i, ax + i * 16, 4 * LDX, acc, M::ev_soff(i + 8, wave))
           if (wave >= NW / 2) target_terms();
-          act_store(biasp[S::B2], lds + M::A1);
+          const float b = biasp[S::B2];
+#pragma unroll
+          for (int p = 0; p < P; ++p) act_store(p, b, lds + M::A1);
         }
         __syncthreads();
+        float j1t[P];
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) gt[q] = lds[M::TBR + mrow * LDT + 128 * q + colw];
-        const float j1t = lds[M::TBR + mrow * LDT + D + colw];
+        for (int p = 0; p < P; ++p) {
+          const int mrow = NS * ss + 2 * p + sl2;
+#pragma unroll
+          for (int q = 0; q < TPW; ++q) gt[p][q] = lds[M::TBR + mrow * LDT + 128 * q + colw];
+          j1t[p] = lds[M::TBR + mrow * LDT + D + colw];
+        }
         {   // x2
           const float* const ah = lds + M::A1 + (c & 3) * LDH + 4 * g;
           zero();
 #pragma unroll
-          for (int i = 0; i < 8; ++i) TAIL_F4(K1 + i, ah + i * 16, acc[0], M::ev_soff(K1 + i + 8, wave))
-          act_store(biasp[S::B3], lds + M::SX);
+          for (int i = 0; i < 8; ++i) TAIL_F4(K1 + i, ah + i * 16, 4 * LDH, acc, M::ev_soff(K1 + i + 8, wave))
+          const float b = biasp[S::B3];
+#pragma unroll
+          for (int p = 0; p < P; ++p) act_store(p, b, lds + M::SX);
         }
         __syncthreads();
         {   // j1: the st half + bias of the value rows come from the time batch
           const float* const ah = lds + M::SX + (c & 3) * LDH + 4 * g;
           zero();
 #pragma unroll
-          for (int i = 0; i < 8; ++i) TAIL_F4(K1 + 8 + i, ah + i * 16, acc[0], M::ev_soff(K1 + 16 + i, wave))
-          act_store(j1t, lds + M::J1);
+          for (int i = 0; i < 8; ++i) TAIL_F4(K1 + 8 + i, ah + i * 16, 4 * LDH, acc, M::ev_soff(K1 + 16 + i, wave))
+#pragma unroll
+          for (int p = 0; p < P; ++p) act_store(p, j1t[p], lds + M::J1);
         }
         __syncthreads();
         {   // j2
           const float* const ah = lds + M::J1 + (c & 3) * LDH + 4 * g;
           zero();
 #pragma unroll
-          for (int i = 0; i < 8; ++i) TAIL_F4(K1 + 16 + i, ah + i * 16, acc[0], M::ev_soff(K1 + 24 + i, wave))
-          act_store(biasp[S::B6], lds + M::J2);
+          for (int i = 0; i < 8; ++i) TAIL_F4(K1 + 16 + i, ah + i * 16, 4 * LDH, acc, M::ev_soff(K1 + 24 + i, wave))
+          const float b = biasp[S::B6];
+#pragma unroll
+          for (int p = 0; p < P; ++p) act_store(p, b, lds + M::J2);
         }
         __syncthreads();
-        {   // out: every lane ends with all four M-rows of its columns -> value and divergence of its slot, no LDS round trip
+        {   // out, one column tile after the other: every lane ends with all four M-rows of its columns -> value and divergence
+            // of its slot, no LDS round trip
           const float* const ah = lds + M::J2 + (c & 3) * LDH + 4 * g;
-          zero();
+          float dpv[P];
 #pragma unroll
-          for (int i = 0; i < 8 * TPW; ++i) {
-            const int fi = K1 + 24 + i;
-            const int nx = fi + 8 < NEV ? M::ev_soff(fi + 8, wave) : (next_tb ? M::tb_soff(fi + 8 - NEV, wave) : M::ev_soff(fi + 8 - NEV, wave));
-            TAIL_F4(fi, ah + (i / TPW) * 16, acc[i % TPW], nx)
-          }
-          float dpv = 0.f;
+          for (int p = 0; p < P; ++p) dpv[p] = 0.f;
 #pragma unroll
           for (int q = 0; q < TPW; ++q) {
-            const f32x4 pre = T.gsum((acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]));
-            const float pv = slot ? pre[1] : pre[0], pt = slot ? pre[3] : pre[2];
-            dpv += zz[q] * (pt + gt[q] * hz[q]);                                                  // z . J z of the slot
-            const float v = pv + biasp[S::B7 + 128 * q] + gt[q] * gc[q];                          // v of the slot
-            kv[q] = sgn > 0.f ? v : -v;
+            zero();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int fi = K1 + 24 + 8 * q + i;
+              const int nx = fi + 8 < NEV ? M::ev_soff(fi + 8, wave) : (next_tb ? M::tb_soff(fi + 8 - NEV, wave) : M::ev_soff(fi + 8 - NEV, wave));
+              TAIL_F4(fi, ah + i * 16, 4 * LDH, acc, nx)
+            }
+            const float b = biasp[S::B7 + 128 * q];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              const f32x4 pre = T.gsum((acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]));
+              const float pv = sl2 ? pre[1] : pre[0], pt = sl2 ? pre[3] : pre[2];
+              dpv[p] += zz[p][q] * (pt + gt[p][q] * hz[p][q]);                                      // z . J z of the slot
+              const float v = pv + b + gt[p][q] * gc[p][q];                                         // v of the slot
+              kv[p][q] = sgn[p] > 0.f ? v : -v;
+            }
           }
-          dpv = group16_sum_dpp(dpv);
-          if (is_t && c == 0) lds[S::DLP + (phase - 1) * 128 + (8 + slot) * 8 + wave] = dpv;     // M-row 8 + slot of the partial sums (as eval_c); raw
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            const float d_ = group16_sum_dpp(dpv[p]);
+            if (is_t && c == 0) lds[S::DLP + (phase - 1) * 128 + (8 + 2 * p + sl2) * 8 + wave] = d_;    // M-row 8 + slot of the partial sums (as eval_c); raw
+          }
         }
       }
 #ifdef MFM_STAMPS
@@ -1585,31 +1755,34 @@ __device__ __forceinline__ void solve2_tail(FTile<D>& T, const OdeArgs& a, const
       for (int j = 1; j < 7; ++j)
         if (j == phase - 1) {
 #pragma unroll
-          for (int q = 0; q < TPW; ++q) km[j][q] = kv[q];
+          for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) km[p][j][q] = kv[p][q];
         }
     }
-    // ---- end of the attempt: norms of my slot's row (lane groups 0, 1; groups 2, 3 hold copies) ----
-    {
+    // ---- end of the attempt: norms of my slots' rows (lane groups 0, 1; groups 2, 3 hold copies) ----
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
       float p0 = 0.f, p1 = 0.f, p2 = 0.f, e2 = 0.f;
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
-        const float sc = atol + fabsf(ym[q]) * rtol;                        // initial-step norms (Hairer II.4)
-        const float a0 = ym[q] / sc, a1 = km[1][q] / sc, a2 = (km[1][q] - km[0][q]) / sc;
+        const float sc = atol + fabsf(ym[p][q]) * rtol;                     // initial-step norms (Hairer II.4)
+        const float a0 = ym[p][q] / sc, a1 = km[p][1][q] / sc, a2 = (km[p][1][q] - km[p][0][q]) / sc;
         p0 += a0 * a0; p1 += a1 * a1; p2 += a2 * a2;
         float acc = 0.f, er = 0.f;                                          // error norm of the attempted step
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * km[j][q];
-        const float y1 = ym[q] + hs * acc;
+        for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * km[p][j][q];
+        const float y1 = ym[p][q] + hs[p] * acc;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) er += DP_E[j] * km[j][q];
-        er *= hs;
-        const float tol = atol + rtol * fmaxf(fabsf(ym[q]), fabsf(y1));
+        for (int j = 0; j < 7; ++j) er += DP_E[j] * km[p][j][q];
+        er *= hs[p];
+        const float tol = atol + rtol * fmaxf(fabsf(ym[p][q]), fabsf(y1));
         const float rr = er / tol;
         e2 += rr * rr;
       }
       p0 = group16_sum_dpp(p0); p1 = group16_sum_dpp(p1); p2 = group16_sum_dpp(p2); e2 = group16_sum_dpp(e2);
-      if (!is_t && c == 0 && myrow >= 0) {
-        float* const rd = lds + S::RED + myrow * 8 + wave;
+      if (!is_t && c == 0 && myrow[p] >= 0) {
+        float* const rd = lds + S::RED + myrow[p] * 8 + wave;
         rd[0] = p0; rd[128] = p1; rd[256] = p2; rd[384] = e2;
       }
     }
@@ -1617,64 +1790,94 @@ __device__ __forceinline__ void solve2_tail(FTile<D>& T, const OdeArgs& a, const
     __syncthreads();
     int any = 0;
     if (wave == 0 && lane < 16) any = leaders_end_of_attempt<D, RP, true>(T, a, f, b0, 3);
-    const int go = __syncthreads_or(any);
-    // ---- apply the decision of my slot's row ----
-    {
-      const float fl = RSF(RS_FLAG, mr), sfrac = RSF(RS_SFRAC, mr);
-      const bool swr = RSF(RS_SW, mr) != 0.f && RSF(RS_TILE, 0) != 0.f;
+    (void)__syncthreads_or(any);
+    // ---- apply the decision of my slots' rows ----
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float fl = RSF(RS_FLAG, mr[p]), sfrac = RSF(RS_SFRAC, mr[p]);
+      const bool swr = RSF(RS_SW, mr[p]) != 0.f && RSF(RS_TILE, 0) != 0.f;
       const bool fin = fl == 2.f, adv = fl == 1.f, ini = fl == 3.f;
       float r0 = 0.f, r1 = 0.f;
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
         float acc = 0.f, kmid = 0.f;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * km[j][q];
+        for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * km[p][j][q];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) kmid += DP_M[j] * km[j][q];
-        const float x0 = ym[q], x1 = x0 + hs * acc, xm = x0 + hs * kmid, g0 = hs * km[0][q], g1 = hs * km[6][q];
+        for (int j = 0; j < 7; ++j) kmid += DP_M[j] * km[p][j][q];
+        const float x0 = ym[p][q], x1 = x0 + hs[p] * acc, xm = x0 + hs[p] * kmid, g0 = hs[p] * km[p][0][q], g1 = hs[p] * km[p][6][q];
         const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
         const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
         const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
         const float xi = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
         float yn = fin ? xi : (adv ? x1 : x0);
-        km[0][q] = ini ? km[1][q] : (adv ? km[6][q] : km[0][q]);
-        if (swr && myrow >= 0) {             // this row starts its forward solve: latent proposal, forward probe
+        km[p][0][q] = ini ? km[p][1][q] : (adv ? km[p][6][q] : km[p][0][q]);
+        if (swr && myrow[p] >= 0) {          // this row starts its forward solve: latent proposal, forward probe
           const int col = colw + 128 * q;
-          const size_t o = (size_t)(b0 + myrow) * D + col;
+          const size_t o = (size_t)(b0 + myrow[p]) * D + col;
           const float nz = a.zgen[o];
           if (f.mode == MFM_FLOW_RWMH) yn = yn + scale * nz;                                        // :268
           else { const float up = f.ref_std * nz; r0 += yn * yn; r1 += up * up; yn = up; }          // :249
           const float z2 = a.z2[o];                                                                 // key_hutch1
-          if (!is_t) { lds[S::XB0 + (2 + slot) * LDX + 4 + col] = z2; lds[S::XB1 + (2 + slot) * LDX + 4 + col] = z2; }
+          if (!is_t) {
+            lds[S::XB0 + (4 * p + 2 + sl2) * LDX + 4 + col] = z2; lds[S::XB1 + (4 * p + 2 + sl2) * LDX + 4 + col] = z2;
+            lds[S::ZB + myrow[p] * LDX + 4 + col] = z2;       // the full layout's probe row (a row that leaves this loop alive needs it)
+          }
 #pragma unroll
-          for (int j = 0; j < 7; ++j) km[j][q] = 0.f;
+          for (int j = 0; j < 7; ++j) km[p][j][q] = 0.f;
         }
-        ym[q] = yn;
+        ym[p][q] = yn;
       }
       if (RSF(RS_TILE, 0) != 0.f && f.mode == MFM_FLOW_IMH) {      // tile-uniform: ref.logprob terms of the rows that switched
         r0 = group16_sum_dpp(r0); r1 = group16_sum_dpp(r1);
-        if (!is_t && c == 0 && swr && myrow >= 0) { lds[S::RED + 4 * 128 + myrow * 8 + wave] = r0; lds[S::RED + 5 * 128 + myrow * 8 + wave] = r1; }
+        if (!is_t && c == 0 && swr && myrow[p] >= 0) { lds[S::RED + 4 * 128 + myrow[p] * 8 + wave] = r0; lds[S::RED + 5 * 128 + myrow[p] * 8 + wave] = r1; }
       }
     }
-    if (!go) break;
+    // leave when the rows that are left fit a smaller loop (P = 1: when none is left)
+    {
+      const unsigned long long lv = __ballot(RSF(RS_RANK, lane & 15) >= 0.f) & 0xFFFFull;
+      if (__popcll(lv) <= 2 * (P - 1)) break;
+    }
     // (the next attempt's stage input is visible after the time batch's first barrier; the leaders rewrite the row state only
     // after the end-of-attempt barrier of that attempt)
   }
 #undef TAIL_F4
 #undef TAIL_F16
-  // ---- back to the full layout: the final state of the rows that ended here (the probe image is free now) ----
-  __syncthreads();
-  if (!is_t && myrow >= 0) {
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) lds[S::ZB + myrow * LDX + 4 + colw + 128 * q] = ym[q];
+#ifdef MFM_STAMPS
+  if (g_flow_dbg && threadIdx.x == 0) {      // cumulative over the launches of a process: tools/flow_cycles.py takes differences
+    unsigned long long* o = g_flow_dbg + blockIdx.x * 64;
+    o[54 + 2 * (P - 1)] += __builtin_amdgcn_s_memtime() - tp0_; o[55 + 2 * (P - 1)] += tp_att_;
   }
+#endif
+  // ---- leave: the rows that are still live are ranked again and their state goes to STG[new rank]; a row that ended here leaves
+  // its final y in its row of the probe image (free now) ----
   __syncthreads();
+  {
+    const unsigned long long lv = __ballot(RSF(RS_RANK, lane & 15) >= 0.f) & 0xFFFFull;
+    if (!is_t) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (intail >> i & 1u) {
+      for (int p = 0; p < P; ++p) {
+        if (myrow[p] >= 0) {
+          const bool live = (lv >> myrow[p]) & 1ull;
+          const int nr = __popcll(lv & ((1ull << myrow[p]) - 1ull));
 #pragma unroll
-      for (int q = 0; q < TPW; ++q) y[q][i] = lds[S::ZB + (4 * g + i) * LDX + 4 + colw + 128 * q];
+          for (int q = 0; q < TPW; ++q) {
+            const int col = colw + 128 * q;
+            if (live) {
+              lds[M::STG + (nr * 8 + 0) * D + col] = ym[p][q];
+#pragma unroll
+              for (int j = 0; j < 7; ++j) lds[M::STG + (nr * 8 + 1 + j) * D + col] = km[p][j][q];
+            } else {
+              lds[S::ZB + myrow[p] * LDX + 4 + col] = ym[p][q];
+            }
+          }
+        }
+      }
     }
+    __syncthreads();                                          // every lane has read the old ranks
+    if (wave == 0 && lane < 16) RSF(RS_RANK, lane) = ((lv >> lane) & 1ull) ? (float)__popcll(lv & ((1ull << lane) - 1ull)) : -1.f;
+    __syncthreads();
+  }
 }
 
 // ---- the flow step's two solves with PER-ROW phases ------------------------------------------------------------------
@@ -1721,6 +1924,9 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
 #pragma unroll 1
   for (;;) {
     // ---- stage input -> X[cur] ----
+#ifdef MFM_STAMPS
+    const unsigned long long si0_ = __builtin_amdgcn_s_memtime();
+#endif
     float hs[4];
     const f32x4 md4 = T.rs_get(RS_MODE), rk4 = T.rs_get(RS_RANK);
     const int cmode = (int)*T.at(0, S::RS + RS_TILE * 16 + 1);             // 0: > 8 rows of the tile still integrate, 1: <= 8, 2: <= 3, 3: <= 2
@@ -1758,11 +1964,12 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
     }
 #ifdef MFM_STAMPS
     const unsigned long long tb0_ = __builtin_amdgcn_s_memtime();
+    T.cyc_si += tb0_ - si0_;
 #endif
     if (phase == 2) {
       float cvv[5][4], svv[5][4];
       T.template tb_trig<true>(2, cvv, svv);
-      if (cmode >= 2) T.template tbatch<true, 1>(2, P, Q, cvv, svv);
+      if (TAIL_PASSES < 2 && cmode >= 2) T.template tbatch<true, 1>(2, P, Q, cvv, svv);
       else if (cmode == 1) T.template tbatch<true, 3>(2, P, Q, cvv, svv);
       else T.template tbatch<true, 5>(2, P, Q, cvv, svv);
     } else __syncthreads();
@@ -1793,6 +2000,9 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
     if (phase < 7) { phase += 1; continue; }
 
     // ---- end of an attempt: per-lane partials of every norm a row may need in its mode ----
+#ifdef MFM_STAMPS
+    const unsigned long long n0_ = __builtin_amdgcn_s_memtime();
+#endif
     {
       float p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0}, p2[4] = {0, 0, 0, 0}, e2[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1817,9 +2027,16 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
     }
     if (threadIdx.x == 0) *T.at(0, S::RS + RS_TILE * 16) = 0.f;            // "some row switched solves in this attempt"
     __syncthreads();
+#ifdef MFM_STAMPS
+    const unsigned long long n1_ = __builtin_amdgcn_s_memtime();
+#endif
     int any = 0;
     if (wave == 0 && T.lane < 16) any = leaders_end_of_attempt<D, RP, false>(T, a, f, b0, cmode);
     const int go = __syncthreads_or(any);
+#ifdef MFM_STAMPS
+    const unsigned long long n2_ = __builtin_amdgcn_s_memtime();
+    T.cyc_n1 += n1_ - n0_; T.cyc_n2 += n2_ - n1_;
+#endif
     // ---- every lane: apply the decision of its rows (branch-free selects) ----
     const bool tile_sw = *T.at(0, S::RS + RS_TILE * 16) != 0.f;
     {
@@ -1864,9 +2081,55 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
         T.precompute_tz1(P, Q);
       }
     }
+#ifdef MFM_STAMPS
+    T.cyc_n3 += __builtin_amdgcn_s_memtime() - n2_;
+#endif
     if (!go) break;
-    if (MICRO_ROWS > 0 && *T.at(0, S::RS + RS_TILE * 16 + 1) == 3.f) {      // <= 2 rows left: the tile's tail runs in a loop of its own
-      solve2_tail<D, RP>(T, a, f, b0, y, k);
+    if (TAIL_PASSES > 0 && *T.at(0, S::RS + RS_TILE * 16 + 1) == 3.f) {      // <= 2 TAIL_PASSES rows left: the tile's tail runs in loops of its own
+      using M1 = TailMap<D, 1>;
+      unsigned intail = 0;
+      {
+        const f32x4 rk4n = T.rs_get(RS_RANK);                               // rank among the live rows
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (rk4n[i] >= 0.f) {
+            intail |= 1u << i;
+            const int r = (int)rk4n[i];
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+              const int col = 16 * (wave + NW * q) + c;
+              T.lds[M1::STG + (r * 8 + 0) * D + col] = y[q][i];
+#pragma unroll
+              for (int j = 0; j < 7; ++j) T.lds[M1::STG + (r * 8 + 1 + j) * D + col] = k[j][q][i];
+            }
+          }
+        }
+      }
+      __syncthreads();
+#ifdef MFM_STAMPS
+      const unsigned long long tl0_ = __builtin_amdgcn_s_memtime();
+#endif
+      TailArgs ta;
+      ta.rtol = a.rtol; ta.atol = a.atol; ta.max_attempts = a.max_attempts;
+      ta.coef = a.net.T.coef; ta.tbeta = a.net.T.tbeta; ta.clip = a.net.grad_clip; ta.fourier = a.net.fourier; ta.Wp = a.net.Wp;
+      ta.zgen = a.zgen; ta.z2 = a.z2; ta.mode = f.mode; ta.ref_std = f.ref_std; ta.rp = a.rp;
+#pragma unroll 1
+      for (;;) {
+        const int live = __popcll(__ballot(*T.at((T.lane & 15) * 4, S::RS + RS_RANK * 16) >= 0.f) & 0xFFFFull);
+        if (live == 0) break;
+        if (TAIL_PASSES >= 3 && live > 4) solve2_tail<D, RP, TAIL_PASSES >= 3 ? 3 : 1>(ta, b0);
+        else if (TAIL_PASSES >= 2 && live > 2) solve2_tail<D, RP, TAIL_PASSES >= 2 ? 2 : 1>(ta, b0);
+        else solve2_tail<D, RP, 1>(ta, b0);
+      }
+#ifdef MFM_STAMPS
+      T.cyc_tail += __builtin_amdgcn_s_memtime() - tl0_;
+#endif
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (intail >> i & 1u) {
+#pragma unroll
+          for (int q = 0; q < TPW; ++q) y[q][i] = *T.at(T.o_xo, S::ZB + i * LDX + 128 * q);
+        }
       break;
     }
     phase = 2;
@@ -2054,6 +2317,9 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
     }
   }
   // this tile is done: until the slowest tile of the launch finishes, fill the idle CU with the draws of the coming iterations
+#ifdef MFM_STAMPS
+  T.cyc_done = __builtin_amdgcn_s_memtime() - fc0_;
+#endif
   if (nz.n_items > 0) noise_tail(nz, reinterpret_cast<volatile int*>(lds + S::RS));
 #ifdef MFM_STAMPS
   if (g_flow_dbg && (threadIdx.x == 0 || threadIdx.x == 256)) {
@@ -2063,7 +2329,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
     for (int i = 0; i < 20; ++i) o[8 + i] = T.cyc_sec[i];
     o[28] = T.n_tc; o[29] = T.cyc_tc; o[30] = T.n_ec; o[31] = T.cyc_ec;
     for (int i = 0; i < 16; ++i) o[32 + i] = T.cyc_csec[i];
-    o[48] = T.n_em; o[49] = T.cyc_em; o[50] = T.n_t1; o[51] = T.cyc_t1;
+    o[48] = T.n_em; o[49] = T.cyc_em; o[50] = T.n_t1; o[51] = T.cyc_t1; o[52] = T.cyc_tail; o[53] = T.cyc_done; o[60] = T.cyc_si; o[61] = T.cyc_n1; o[62] = T.cyc_n2; o[63] = T.cyc_n3;
   }
 #endif
 }

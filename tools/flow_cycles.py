@@ -72,6 +72,25 @@ for count in range(1, 304):
                 c = np.median(dd[f, 32:48] / dd[f, 30:31], axis=0).astype(int)
                 print(f"   COMPACT eval sections, {wname}, cycles per evaluation: gathers {c[0]} target(pre) {c[1]} x1 job {c[2]} target(post)+epi {c[3]} barriers(4) {c[4]} "
                       f"x2 job {c[5]} epilogues x2/j1/j2 {c[6]} j1 job {c[7]} j2 job {c[8]} out job+epi {c[9]} partials+readback {c[10]}")
+        done = d[:, 53]
+        tl = d[:, 54:60].copy()
+        if "tl_prev" in globals(): tl_now = tl - tl_prev
+        else: tl_now = tl
+        tl_prev = tl
+        for P in (1, 2, 3):
+            cc, nn = tl_now[:, 2 * (P - 1)], tl_now[:, 2 * (P - 1) + 1]
+            if nn.sum() > 0: print(f"   tail loop P = {P}: attempts per WG mean {nn.mean():.1f}, cycles per attempt {cc.sum() / nn.sum() / 1e3:.1f}k")
+        print(f"   tile done (before the noise work): mean {done.mean()/1e6:.1f}M max {done.max()/1e6:.1f}M mean/max {done.mean()/done.max():.3f} | time in the tail loops: mean {d[:,52].mean()/1e6:.1f}M")
+        natt_main = d[:, 5] + d[:, 28]
+        for nm, dd in (("wave 0", d), ("wave 4", d4)):
+            print(f"   main loop outside batch / evaluations, {nm}, cycles per attempt: stage inputs (6) {np.median(dd[:,60]/natt_main):.0f}, norms {np.median(dd[:,61]/natt_main):.0f}, leaders + barrier {np.median(dd[:,62]/natt_main):.0f}, decision (+ solve switches) {np.median(dd[:,63]/natt_main):.0f}")
+        for w in np.argsort(-done)[:4]:
+            r = d[w]
+            full = r[6] + r[3]; cmp8 = r[29] + r[31]; tail = r[52]
+            ts = np.sort(t[w])[::-1].astype(int)
+            natt_tail = ts[0] + 4 - r[5] - r[28]
+            print(f"   slow WG {w}: done {r[53]/1e6:.1f}M | full: {r[5]:.0f} att {full/1e6:.1f}M ({full/max(r[5],1)/1e3:.0f}k/att) | compact: {r[28]:.0f} att {cmp8/1e6:.1f}M ({cmp8/max(r[28],1)/1e3:.0f}k/att) | "
+                  f"tails: ~{natt_tail:.0f} att {tail/1e6:.1f}M ({tail/max(natt_tail,1)/1e3:.0f}k/att) | rest {(r[53]-full-cmp8-tail)/1e6:.1f}M ({(r[53]-full-cmp8-tail)/max(r[5]+r[28],1)/1e3:.0f}k/att) | tile natt sorted {ts[:9]}")
         print(f"   WG time: mean/max {cyc.mean()/cyc.max():.3f}; alg evals (4+6 natt) mean {4+6*n.mean():.0f}; executed/alg {nev.mean()/(4+6*n.mean()):.3f}; max-WG/alg {nev.max()/(4+6*n.mean()):.3f}")
     else:
         ctx.mala_step(kg, 1.0, args.step_size, pos, logp, grad, acc)
