@@ -83,7 +83,7 @@ __device__ __forceinline__ void load_group(f32x4 (&bf)[4], __amdgpu_buffer_rsrc_
 }
 
 #ifndef FAST_DBUF_MAX_MT
-#define FAST_DBUF_MAX_MT 1
+#define FAST_DBUF_MAX_MT 2      // (round 4: 1 -> 2, x2 / j1 / j2 read their two A fragments one k-block ahead: -0.5 % on the launch)
 #endif
 template <int MT, int NTL, int LDA>
 __device__ __forceinline__ void exec_group(const float* arow, const f32x4 (&bf)[4], f32x4 (&acc)[NTL][MT]) {
@@ -264,8 +264,14 @@ struct FTile {
   unsigned long long n_ec = 0, cyc_ec = 0;      // compact evaluations
   unsigned long long n_eval = 0, cyc_eval = 0, n_tb = 0, cyc_tb = 0, cyc_sec[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sec_t0 = 0;
   unsigned long long cyc_csec[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // sections of the compact evaluation
+#ifdef MFM_STAMPS_FINE      // section stamps INSIDE the batch and the evaluations: every stamp waits for the wave's outstanding LDS / scalar
+                            // operations, so this build runs ~15 % slower and inflates short sections; the coarse stamps alone cost < 1 %
 #define FSEC(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cyc_sec[i] += t_ - sec_t0; sec_t0 = t_; } while (0)
 #define CSEC(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cyc_csec[i] += t_ - sec_t0; sec_t0 = t_; } while (0)
+#else
+#define FSEC(i) do {} while (0)
+#define CSEC(i) do {} while (0)
+#endif
 #else
 #define FSEC(i) do {} while (0)
 #define CSEC(i) do {} while (0)
@@ -356,23 +362,32 @@ struct FTile {
     sec_t0 = __builtin_amdgcn_s_memtime();
 #endif
     constexpr bool CMP = MTB != 5;
+    // MTB = 3, 5 (round 4): cos | sin SIDE BY SIDE in one [16 MTB][264] image and ONE K = 256 job over it (the same k order as the
+    // two half jobs it replaces: bit-identical).  The sine block used to wait in the global scratch while the cosine half ran,
+    // with two more barriers and a second write pass.  The image overlaps the place of t1, hence the barrier after the job.
+    constexpr bool SIDE = MTB != 1;
+    constexpr int LDF = 2 * F + 8;
+    static_assert(!SIDE || 16 * MTB * LDF <= 160 * LDH, "Fourier image");
     int mrow[5][4];                         // compact mode: LDS row of (stage s, this lane's row i), -1: row not integrating
     {
       f32x4 rk4 = {0.f, 0.f, 0.f, 0.f};
       if constexpr (CMP) rk4 = rs_get(RS_RANK);
+      const int o_hf = o_hc + g * (4 * LDF * 4);      // image row 4 g, this lane's column
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if constexpr (CMP) {
             mrow[s][i] = rk4[i] >= 0.f ? RPS * s + (int)rk4[i] : -1;
-            if (mrow[s][i] >= 0) *at(o_hc, mrow[s][i] * LDH) = cv[s][i];
+            if constexpr (SIDE) { if (mrow[s][i] >= 0) { *at(o_hc, mrow[s][i] * LDF) = cv[s][i]; *at(o_hc, mrow[s][i] * LDF + F) = sv[s][i]; } }
+            else if (mrow[s][i] >= 0) *at(o_hc, mrow[s][i] * LDH) = cv[s][i];
           } else {
-            *at(o_he, (s * 16 + i) * LDH) = cv[s][i];
+            if constexpr (SIDE) { *at(o_hf, (s * 16 + i) * LDF) = cv[s][i]; *at(o_hf, (s * 16 + i) * LDF + F) = sv[s][i]; }
+            else *at(o_he, (s * 16 + i) * LDH) = cv[s][i];
           }
         }
         // the sine block waits in this lane's scratch slot of the stage (rewritten by the gate epilogue afterwards)
-        bstore(sr, lane * 16, ((s * NW + wave) * 3 + 0) * 1024, f32x4{sv[s][0], sv[s][1], sv[s][2], sv[s][3]});
+        if constexpr (!SIDE) bstore(sr, lane * 16, ((s * NW + wave) * 3 + 0) * 1024, f32x4{sv[s][0], sv[s][1], sv[s][2], sv[s][3]});
       }
     }
     FSEC(0);
@@ -396,6 +411,13 @@ struct FTile {
     };
     auto fold = [&]() { if constexpr (MTB == 1) acc[0][0] = ac2[0] + ac2[1]; };
     zero();
+    if constexpr (SIDE) {
+      const int o_hfa = (S::R + (lane & 15) * LDF + 4 * g) * 4;
+      run_job<MTB, 1, 16, LDF, 0, 1, 0>(at(o_hfa, 0), wr, W(S::W0, wave, 16, 0), W(S::W1, wave, 8), lane, P, Q, acc);
+      FSEC(2);
+      __syncthreads();                    // every wave has read the image: t1 may take its place
+      FSEC(3);
+    } else {
     job(afh, W(S::W0, wave, 16, 0), W(S::W0, wave, 16, 8));      // cos half
     FSEC(2);
     __syncthreads();
@@ -419,6 +441,7 @@ struct FTile {
     FSEC(3);
     job(afh, W(S::W0, wave, 16, 8), W(S::W1, wave, 8));           // sin half (accumulates on the cos half)
     fold();
+    }
     {
       const float b = bias(S::B0);
 #pragma unroll
@@ -522,6 +545,9 @@ struct FTile {
         for (int i = 0; i < 4; ++i) tt_elem(q, i);
       }
     };
+#ifndef MFM_X1_RING
+#define MFM_X1_RING 0
+#endif
 #ifndef MFM_TT_MODE
 #define MFM_TT_MODE 3        // 0: waves 0-3 before their x1 job, waves 4-7 after theirs (stagger); 1: every wave before; 2: every wave after
                              // (same-trajectory A/B, tools/flow_ab.py, round 2: 52.75 / 52.95 / 53.03 ms: none of them overlaps anything --
@@ -540,38 +566,43 @@ struct FTile {
         const float* arow = at(o_xa + xsel, 0);
         const int w0 = W(S::W2, wave, D / 16), wnx = W(S::W3, wave, 8);
         const float ntb = -tbeta;
-        float ox[2][2][6];                        // [buffer][element of the pair][x, x-, x+, z, z-, z+]
-        auto tt_fetch = [&](int p, float (&o)[2][6]) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 ox[2][6];                           // [buffer][x, x-, x+, z, z-, z+] of the pair's two elements
+        auto tt_fetch = [&](int p, f32x2 (&o)[6]) {
           const int q = p >> 1, i0 = 2 * (p & 1);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const float* xr = at(o_xo + xsel, (i0 + e) * LDX + 128 * q);
             const float* zr = at(o_xo, S::ZB + (i0 + e) * LDX + 128 * q);
-            o[e][0] = xr[0]; o[e][1] = xr[-1]; o[e][2] = xr[1]; o[e][3] = zr[0]; o[e][4] = zr[-1]; o[e][5] = zr[1];
+            o[0][e] = xr[0]; o[1][e] = xr[-1]; o[2][e] = xr[1]; o[3][e] = zr[0]; o[4][e] = zr[-1]; o[5][e] = zr[1];
           }
         };
-        float lx[2], lz[2], ax[2], bz[2], gr[2], hv[2];
-        auto piece = [&](int p, int k, const float (&o)[2][6]) {
+        // two elements per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): beside MFMAs every vector instruction costs
+        // the SIMD its issue cycles whether or not the matrix pipe is busy (measured: the scalar form of these pieces, 240
+        // instructions, took as long inside the job as the packed 110 had taken in front of it)
+        f32x2 lx, lz, ax, bz, gr, hv;
+        const f32x2 two = {2.f, 2.f}, one = {1.f, 1.f}, three = {3.f, 3.f}, ic2 = {icoef, icoef}, co2 = {coef, coef}, nt2 = {ntb, ntb};
+        auto piece = [&](int p, int k, const f32x2 (&o)[6]) {
           const int q = p >> 1, i0 = 2 * (p & 1);
+          const f32x2 x = o[0], z = o[3];
+          if (k == 0) { lx = __builtin_elementwise_fma(x, two, -o[1]) - o[2]; lz = __builtin_elementwise_fma(z, two, -o[4]) - o[5]; }
+          if (k == 1) ax = ic2 * (x * __builtin_elementwise_fma(-x, x, one));
+          if (k == 2) { gr = __builtin_elementwise_fma(co2, lx, -ax) * nt2; bz = ic2 * (z * __builtin_elementwise_fma(-x, x * three, one)); }
+          if (k == 3) hv = __builtin_elementwise_fma(co2, lz, -bz) * nt2;
+          if (k == 4) {
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float x = o[e][0], z = o[e][3];
-            if (k == 0) { lx[e] = __builtin_fmaf(x, 2.f, -o[e][1]) - o[e][2]; lz[e] = __builtin_fmaf(z, 2.f, -o[e][4]) - o[e][5]; }
-            if (k == 1) ax[e] = icoef * (x * __builtin_fmaf(-x, x, 1.f));
-            if (k == 2) { gr[e] = __builtin_fmaf(coef, lx[e], -ax[e]) * ntb; bz[e] = icoef * (z * __builtin_fmaf(-x, x * 3.f, 1.f)); }
-            if (k == 3) hv[e] = __builtin_fmaf(coef, lz[e], -bz[e]) * ntb;
-            if (k == 4) {
+            for (int e = 0; e < 2; ++e) {
               gc[q][i0 + e] = clip > 0.f ? fminf(fmaxf(gr[e], -clip), clip) : gr[e];
               hz[q][i0 + e] = (!(clip > 0.f) || fabsf(gr[e]) <= clip) ? hv[e] : 0.f;
-              zz[q][i0 + e] = z;
+              zz[q][i0 + e] = z[e];
             }
           }
           // pin the piece where it stands: pure arithmetic is otherwise sunk to its first use (the last piece) before the
           // instruction scheduler ever sees it, whatever the scheduling fences say
-          if (k == 0) asm volatile("" : "+v"(lx[0]), "+v"(lx[1]), "+v"(lz[0]), "+v"(lz[1]));
-          if (k == 1) asm volatile("" : "+v"(ax[0]), "+v"(ax[1]));
-          if (k == 2) asm volatile("" : "+v"(gr[0]), "+v"(gr[1]), "+v"(bz[0]), "+v"(bz[1]));
-          if (k == 3) asm volatile("" : "+v"(hv[0]), "+v"(hv[1]));
+          if (k == 0) asm volatile("" : "+v"(lx), "+v"(lz));
+          if (k == 1) asm volatile("" : "+v"(ax));
+          if (k == 2) asm volatile("" : "+v"(gr), "+v"(bz));
+          if (k == 3) asm volatile("" : "+v"(hv));
           if (k == 4) asm volatile("" : "+v"(gc[q][i0]), "+v"(gc[q][i0 + 1]), "+v"(hz[q][i0]), "+v"(hz[q][i0 + 1]));
         };
         tt_fetch(0, ox[0]);
@@ -579,8 +610,14 @@ struct FTile {
         for (int gi = 0; gi < G; ++gi) {
           f32x4 (&B)[4] = (gi & 1) ? Q : P;
           f32x4 (&N)[4] = (gi & 1) ? P : Q;
+#if MFM_X1_RING
+          // fragment ring: the slot of fragment f is refilled with fragment f + 8 as soon as its MFMAs are issued (twice the
+          // distance of the group ping-pong with the same eight fragment registers)
+          if (gi == 0) load_group<1, 0>(N, wr, w0 + 4 * 1024, lane);
+#else
           if (gi + 1 < G) load_group<1, 0>(N, wr, w0 + (gi + 1) * 4 * 1024, lane);
           else load_group<1, 0>(N, wr, wnx, lane);
+#endif
           __builtin_amdgcn_sched_barrier(0);
           f32x4 an = *reinterpret_cast<const f32x4*>(arow + gi * 64);
 #pragma unroll
@@ -598,6 +635,13 @@ struct FTile {
               if (slot == 7) piece(gi, 2, ox[gi & 1]);
               if (slot == 9) piece(gi, 3, ox[gi & 1]);
               if (slot == 12) piece(gi, 4, ox[gi & 1]);
+#if MFM_X1_RING
+              if (s4 == 3) {
+                const int fn = gi * 4 + u + 8;                          // fragment that takes this slot
+                if (fn < 4 * G) { B[u] = bload(wr, lane * 16, w0 + fn * 1024); asm volatile("" ::: "memory"); }
+                else if (fn < 4 * G + 4) { B[u] = bload(wr, lane * 16, wnx + (fn - 4 * G) * 1024); asm volatile("" ::: "memory"); }
+              }
+#endif
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -1311,6 +1355,13 @@ __device__ __forceinline__ int leaders_end_of_attempt(FTile<D>& T, const AA& a, 
   }
   R1(RS_FLAG) = flag; R1(RS_SW) = sw;
   any = R1(RS_MODE) != (float)RM_DONE ? 1 : 0;
+  {
+    // tile-wide: "a row will be in an initial-step phase during the next attempt" (only then are its three extra norms needed) and
+    // "a row ends a solve with this attempt" (only then is the interpolant needed); the other lanes skip that arithmetic otherwise
+    const float mn = R1(RS_MODE);
+    const unsigned long long bi = __ballot(mn == (float)RM_INIT0 || mn == (float)RM_INIT1), bf = __ballot(flag == 2.f);
+    if (ln == 0) { *T.at(0, S::RS + RS_TILE * 16 + 2) = bi ? 1.f : 0.f; *T.at(0, S::RS + RS_TILE * 16 + 3) = bf ? 1.f : 0.f; }
+  }
   if constexpr (STICKY) {
     if (!any) R1(RS_RANK) = -1.f;
   } else {
@@ -1761,14 +1812,21 @@ __device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
         }
     }
     // ---- end of the attempt: norms of my slots' rows (lane groups 0, 1; groups 2, 3 hold copies) ----
+    const bool some_init = RSF(RS_TILE, 2) != 0.f;             // (published by the leaders of the previous attempt)
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       float p0 = 0.f, p1 = 0.f, p2 = 0.f, e2 = 0.f;
+      if (some_init) {
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+          const float sc = atol + fabsf(ym[p][q]) * rtol;                   // initial-step norms (Hairer II.4)
+          const float a0 = ym[p][q] / sc, a1 = km[p][1][q] / sc, a2 = (km[p][1][q] - km[p][0][q]) / sc;
+          p0 += a0 * a0; p1 += a1 * a1; p2 += a2 * a2;
+        }
+        p0 = group16_sum_dpp(p0); p1 = group16_sum_dpp(p1); p2 = group16_sum_dpp(p2);
+      }
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
-        const float sc = atol + fabsf(ym[p][q]) * rtol;                     // initial-step norms (Hairer II.4)
-        const float a0 = ym[p][q] / sc, a1 = km[p][1][q] / sc, a2 = (km[p][1][q] - km[p][0][q]) / sc;
-        p0 += a0 * a0; p1 += a1 * a1; p2 += a2 * a2;
         float acc = 0.f, er = 0.f;                                          // error norm of the attempted step
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * km[p][j][q];
@@ -1780,10 +1838,11 @@ __device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
         const float rr = er / tol;
         e2 += rr * rr;
       }
-      p0 = group16_sum_dpp(p0); p1 = group16_sum_dpp(p1); p2 = group16_sum_dpp(p2); e2 = group16_sum_dpp(e2);
+      e2 = group16_sum_dpp(e2);
       if (!is_t && c == 0 && myrow[p] >= 0) {
         float* const rd = lds + S::RED + myrow[p] * 8 + wave;
-        rd[0] = p0; rd[128] = p1; rd[256] = p2; rd[384] = e2;
+        if (some_init) { rd[0] = p0; rd[128] = p1; rd[256] = p2; }
+        rd[384] = e2;
       }
     }
     if (threadIdx.x == 0) RSF(RS_TILE, 0) = 0.f;              // "some row switched solves in this attempt"
@@ -1792,6 +1851,7 @@ __device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
     if (wave == 0 && lane < 16) any = leaders_end_of_attempt<D, RP, true>(T, a, f, b0, 3);
     (void)__syncthreads_or(any);
     // ---- apply the decision of my slots' rows ----
+    const bool some_fin = RSF(RS_TILE, 3) != 0.f;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const float fl = RSF(RS_FLAG, mr[p]), sfrac = RSF(RS_SFRAC, mr[p]);
@@ -1800,16 +1860,21 @@ __device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
       float r0 = 0.f, r1 = 0.f;
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
-        float acc = 0.f, kmid = 0.f;
+        float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * km[p][j][q];
+        const float x0 = ym[p][q], x1 = x0 + hs[p] * acc;
+        float xi = x1;
+        if (some_fin) {
+          float kmid = 0.f;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) kmid += DP_M[j] * km[p][j][q];
-        const float x0 = ym[p][q], x1 = x0 + hs[p] * acc, xm = x0 + hs[p] * kmid, g0 = hs[p] * km[p][0][q], g1 = hs[p] * km[p][6][q];
-        const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
-        const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
-        const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
-        const float xi = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
+          for (int j = 0; j < 7; ++j) kmid += DP_M[j] * km[p][j][q];
+          const float xm = x0 + hs[p] * kmid, g0 = hs[p] * km[p][0][q], g1 = hs[p] * km[p][6][q];
+          const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
+          const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
+          const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
+          xi = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
+        }
         float yn = fin ? xi : (adv ? x1 : x0);
         km[p][0][q] = ini ? km[p][1][q] : (adv ? km[p][6][q] : km[p][0][q]);
         if (swr && myrow[p] >= 0) {          // this row starts its forward solve: latent proposal, forward probe
@@ -1913,6 +1978,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
 #pragma unroll
     for (int fld = 0; fld < 24; ++fld) T.rs_put(fld, z4);      // mode INIT0, solve 0, t = 0, dt = 0
     T.rs_put(RS_SIGN, m1);                                     // inverse solve first (:267 / :251)
+    if (threadIdx.x == 0) *T.at(0, S::RS + RS_TILE * 16 + 2) = 1.f;      // every row starts in an initial-step phase
   }
   f32x4 P[4], Q[4];
   load_group<1, 0>(P, T.wtr, T.W(S::W7, wave, D / 16), T.lane);
@@ -2005,13 +2071,22 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
 #endif
     {
       float p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0}, p2[4] = {0, 0, 0, 0}, e2[4] = {0, 0, 0, 0};
+      const bool some_init = *T.at(0, S::RS + RS_TILE * 16 + 2) != 0.f;     // (published by the leaders of the previous attempt)
+      if (some_init) {
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float sc = atol + fabsf(y[q][i]) * rtol;                  // initial-step norms (Hairer II.4)
+            const float a0 = y[q][i] / sc, a1 = k[1][q][i] / sc, a2 = (k[1][q][i] - k[0][q][i]) / sc;
+            p0[i] += a0 * a0; p1[i] += a1 * a1; p2[i] += a2 * a2;
+          }
+        T.part_put(S::RED + 0 * 128, p0); T.part_put(S::RED + 1 * 128, p1); T.part_put(S::RED + 2 * 128, p2);
+      }
 #pragma unroll
       for (int q = 0; q < TPW; ++q)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float sc = atol + fabsf(y[q][i]) * rtol;                    // initial-step norms (Hairer II.4)
-          const float a0 = y[q][i] / sc, a1 = k[1][q][i] / sc, a2 = (k[1][q][i] - k[0][q][i]) / sc;
-          p0[i] += a0 * a0; p1[i] += a1 * a1; p2[i] += a2 * a2;
           float acc = 0.f, er = 0.f;                                       // error norm of the attempted step
 #pragma unroll
           for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * k[j][q][i];
@@ -2023,7 +2098,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
           const float rr = er / tol;
           e2[i] += rr * rr;
         }
-      T.part_put(S::RED + 0 * 128, p0); T.part_put(S::RED + 1 * 128, p1); T.part_put(S::RED + 2 * 128, p2); T.part_put(S::RED + 3 * 128, e2);
+      T.part_put(S::RED + 3 * 128, e2);
     }
     if (threadIdx.x == 0) *T.at(0, S::RS + RS_TILE * 16) = 0.f;            // "some row switched solves in this attempt"
     __syncthreads();
@@ -2039,6 +2114,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
 #endif
     // ---- every lane: apply the decision of its rows (branch-free selects) ----
     const bool tile_sw = *T.at(0, S::RS + RS_TILE * 16) != 0.f;
+    const bool some_fin = *T.at(0, S::RS + RS_TILE * 16 + 3) != 0.f;       // tile-uniform: a row reaches t = 1 with this attempt
     {
       const f32x4 fl4 = T.rs_get(RS_FLAG), sf4 = T.rs_get(RS_SFRAC), sw4 = T.rs_get(RS_SW);
       float r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
@@ -2048,16 +2124,21 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
         const bool fin = fl4[i] == 2.f, adv = fl4[i] == 1.f, ini = fl4[i] == 3.f, swr = sw4[i] != 0.f;
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-          float acc = 0.f, km = 0.f;
+          float acc = 0.f;
 #pragma unroll
           for (int j = 0; j < 6; ++j) acc += DP_TAB[7][j] * k[j][q][i];
+          const float x0 = y[q][i], x1 = x0 + dti * acc;
+          float xi = x1;
+          if (some_fin) {                     // the interpolant at t = 1 (2 of a row's ~330 attempts need it)
+            float km = 0.f;
 #pragma unroll
-          for (int j = 0; j < 7; ++j) km += DP_M[j] * k[j][q][i];
-          const float x0 = y[q][i], x1 = x0 + dti * acc, xm = x0 + dti * km, g0 = dti * k[0][q][i], g1 = dti * k[6][q][i];
-          const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
-          const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
-          const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
-          const float xi = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
+            for (int j = 0; j < 7; ++j) km += DP_M[j] * k[j][q][i];
+            const float xm = x0 + dti * km, g0 = dti * k[0][q][i], g1 = dti * k[6][q][i];
+            const float qa = -2.f * g0 + 2.f * g1 - 8.f * x0 - 8.f * x1 + 16.f * xm;
+            const float qb = 5.f * g0 - 3.f * g1 + 18.f * x0 + 14.f * x1 - 32.f * xm;
+            const float qc = -4.f * g0 + g1 - 11.f * x0 - 5.f * x1 + 16.f * xm;
+            xi = (((qa * sfrac + qb) * sfrac + qc) * sfrac + g0) * sfrac + x0;
+          }
           float yn = fin ? xi : (adv ? x1 : x0);
           k[0][q][i] = ini ? k[1][q][i] : (adv ? k[6][q][i] : k[0][q][i]);
           if (tile_sw && swr) {              // this row starts its forward solve: latent proposal, forward probe
