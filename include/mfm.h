@@ -65,6 +65,10 @@ typedef struct mfm_config {
                                   run on either kernel family; gelu and swish need stored pre-activations: wide family */
   double ref_std;              /* std of the flow's reference distribution IndepGaussian(dim, var): 1 for args.ref_dist = 'stdgauss',
                                   sqrt(5) for 'widegauss' (exe_flow_matching.py:48-54, distributions.py:80-97); 0 = 1 */
+  int32_t n_chain_valid;       /* 0 = n_chain_local.  args.num_chain takes any integer (multi_modal.py:169); the kernels work on tiles of
+                                  16 chains, so the host pads its shard to n_chain_local (a multiple of 16) and names here how many of
+                                  those rows are chains: rows >= n_chain_valid are integrated like any other but contribute nothing to
+                                  the flow-matching loss and its gradient (exe_flow_matching.py:171-178) */
 } mfm_config;
 
 const char* mfm_last_error(void);

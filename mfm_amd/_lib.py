@@ -31,7 +31,7 @@ class Config(C.Structure):
         ("learning_rate", C.c_double), ("adam_b1", C.c_double), ("adam_b2", C.c_double), ("adam_eps", C.c_double),
         ("weight_decay", C.c_double), ("update_clip", C.c_double),
         ("learning_iter", C.c_int32), ("warmup_steps", C.c_int32), ("max_eval_samples", C.c_int32),
-        ("kernel_family", C.c_int32), ("activation", C.c_int32), ("ref_std", C.c_double),
+        ("kernel_family", C.c_int32), ("activation", C.c_int32), ("ref_std", C.c_double), ("n_chain_valid", C.c_int32),
     ]
 
 

@@ -199,9 +199,11 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
     if (h <= 0 || h % 16) return fail(MFM_EUNSUPPORTED, "hidden widths must be positive multiples of 16 (got %d)", h);
   if (c.n_chain_local <= 0 || c.n_chain_local % 16)
     return fail(MFM_EUNSUPPORTED, "n_chain_local must be a positive multiple of 16 (got %d)", c.n_chain_local);
-  if (c.chain_offset < 0 || c.chain_offset + c.n_chain_local > c.n_chain_total)
+  const int n_valid = c.n_chain_valid > 0 ? c.n_chain_valid : c.n_chain_local;
+  if (n_valid > c.n_chain_local) return fail(MFM_EINVAL, "n_chain_valid=%d exceeds n_chain_local=%d", n_valid, c.n_chain_local);
+  if (c.chain_offset < 0 || c.chain_offset + n_valid > c.n_chain_total)
     return fail(MFM_EINVAL, "chain shard [%d, %d) outside n_chain_total=%d", c.chain_offset,
-                c.chain_offset + c.n_chain_local, c.n_chain_total);
+                c.chain_offset + n_valid, c.n_chain_total);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MFM_EHIP, "no HIP device available");
   switches_read();                     // development / A-B switches: fixed from here until the next mfm_create (common.cuh)
@@ -520,6 +522,7 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
   }
   a.n_total = n_total; a.chain_offset = offset; a.B = n; a.sigma = x->cfg.sigma; a.cond_flow = x->cfg.cond_flow;
   a.ref_std = x->cfg.ref_std;
+  a.n_valid = train && x->cfg.n_chain_valid > 0 ? x->cfg.n_chain_valid : n;      // (padding rows of the chain shard: no loss, no gradient)
   a.pos = d_samples; a.acts = x->acts; a.dzs = x->dzs; a.dacts = x->dacts; a.loss_part = x->loss_part;
   if (x->wide) {      // R rows per pass; the loss is accumulated over the passes
     wide::Ctx* w = x->wide;
@@ -527,6 +530,7 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
       wide::FmCall c;
       c.key_time = a.key_time; c.key_ref = a.key_ref; c.key_gauss = a.key_gauss; c.n_total = (uint32_t)n_total; c.chain_offset = (uint32_t)(offset + r0);
       c.sigma = a.sigma; c.cond_flow = a.cond_flow; c.ref_std = a.ref_std; c.pos = d_samples + (size_t)r0 * x->cfg.dim; c.rows = n - r0 < w->R ? n - r0 : w->R;
+      c.rows_valid = a.n_valid - r0 < 0 ? 0 : (a.n_valid - r0 < c.rows ? a.n_valid - r0 : c.rows);
       // one rank, one pass: this IS the gradient the optimizer will see, so its finite check rides in the weight-gradient kernel
       const bool inline_check = train && n <= w->R && x->cfg.n_chain_total == x->cfg.n_chain_local;
       c.bad = inline_check ? x->flag : nullptr;

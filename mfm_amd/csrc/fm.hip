@@ -36,6 +36,7 @@ struct FmArgs {
   Key2 key_time, key_ref, key_gauss;
   uint32_t n_total, chain_offset;
   int B;                 // samples handled by this launch (multiple of 16)
+  int n_valid;           // rows >= n_valid are padding of the chain shard: residual 0, i.e. no loss and no gradient (B: none)
   float sigma;
   int cond_flow;
   const float* pos;      // [B][d] samples x1
@@ -392,7 +393,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                          float tg = 0.f;
 #pragma unroll
                          for (int qq = 0; qq < TPW; ++qq) tg = (qq == q) ? tgt[qq][i] : tg;
-                         const float r = v - tg;
+                         const float r = b0 + row < a.n_valid ? v - tg : 0.f;
                          loss_loc += r * r;
                          dv[i] = 2.f * r;
                          dg[i] = dv[i] * gc;

@@ -649,7 +649,7 @@ __global__ void elem_mask_kernel(ElemMask a) {
 }
 
 // loss (:177-178) and the two output-side gradients: dv = 2 (v - target), dgate = dv * clip(grad log pi)
-struct LossArgs { int rows, d, dp; const float* out; const float* gate; const float* gc; const float* tgt; float* dv; float* dg; double* part; };
+struct LossArgs { int rows, rows_valid, d, dp; const float* out; const float* gate; const float* gc; const float* tgt; float* dv; float* dg; double* part; };
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   __shared__ double sm[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.x * 4 + w;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
       float dv = 0.f, dg = 0.f;
       if (col < a.d) {
         const float gc = a.gc[o];
-        const float r = a.out[o] + a.gate[o] * gc - a.tgt[o];
+        const float r = b < a.rows_valid ? a.out[o] + a.gate[o] * gc - a.tgt[o] : 0.f;      // (padding rows of the chain shard)
         loc += r * r;
         dv = 2.f * r; dg = dv * gc;
       }
@@ -1399,6 +1399,7 @@ static void probe_setup(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
 struct FmCall {
   Key2 key_time, key_ref, key_gauss; uint32_t n_total, chain_offset; float sigma; int cond_flow; double ref_std;
   const float* pos; int rows;
+  int rows_valid;        // rows >= rows_valid: padding of the chain shard (no loss, no gradient)
   int* bad;              // non-null (training, one rank): finite check of the gradient rides in the weight-gradient kernel
 };
 // loss (+ gradient into d_grads, canonical layout) on `rows` samples; the per-workgroup loss partials land in w->loss_part
@@ -1414,7 +1415,7 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
   target_eval(w, n, w->cond, nullptr, rows, s);
   x_branch(w, n, w->cond, false, rows, s);
   LossArgs l; memset(&l, 0, sizeof l);
-  l.rows = rows; l.d = n.d; l.dp = n.dp; l.out = w->out; l.gate = w->gate; l.gc = w->gc; l.tgt = w->tgt; l.part = w->loss_part;
+  l.rows = rows; l.rows_valid = c.rows_valid; l.d = n.d; l.dp = n.dp; l.out = w->out; l.gate = w->gate; l.gc = w->gc; l.tgt = w->tgt; l.part = w->loss_part;
   if (train) { l.dv = w->dv; l.dg = w->dg; }
   hipLaunchKernelGGL(loss_kernel, dim3(grid4(rows)), dim3(256), 0, s, l);
   if (!train) return 0;

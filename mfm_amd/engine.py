@@ -30,13 +30,15 @@ def _collective(td):
 
 
 def shard(n_total, rank, world):
-    """Contiguous shard of the chain axis; every shard must be a multiple of 16 chains (one MFMA M-tile)."""
+    """Contiguous shard of the chain axis: (rows resident on this GPU, global id of its first chain, chains among those rows).
+
+    ``--num_chain`` takes any integer (multi_modal.py:169).  The kernels work on tiles of 16 chains (one MFMA M-tile), so a
+    shard that is not a multiple of 16 is padded with copies of its last chain: those rows are integrated like any other and
+    contribute nothing to the loss, the gradient or any statistic (``mfm_config.n_chain_valid``)."""
     if n_total % world:
         raise ValueError(f"num_chain={n_total} is not divisible by world size {world}")
-    n_local = n_total // world
-    if n_local % 16:
-        raise ValueError(f"chains per GPU ({n_local}) must be a multiple of 16")
-    return n_local, rank * n_local
+    n_valid = n_total // world
+    return -(-n_valid // 16) * 16, rank * n_valid, n_valid
 
 
 def allreduce_sum_(*tensors):
@@ -115,7 +117,7 @@ class Engine:
         self.world = td.get_world_size() if td else 1
         self.rank = td.get_rank() if td else 0
         self.n_total = int(args.num_chain)
-        self.n_local, self.offset = shard(self.n_total, self.rank, self.world)
+        self.n_local, self.offset, self.n_valid = shard(self.n_total, self.rank, self.world)
         self.dim = int(args.dim)
         if len(args.hidden_x) != 2 or len(args.hidden_t) != 2 or len(args.hidden_xt) != 2:
             raise NotImplementedError("the fused MLP kernels are built for two hidden layers per branch")
@@ -130,7 +132,7 @@ class Engine:
         self.args = args
         self.ctx = _lib.Context(
             dim=self.dim, fourier_dim=int(args.fourier_dim), hidden_t=args.hidden_t, hidden_x=args.hidden_x,
-            hidden_xt=args.hidden_xt, n_chain_local=self.n_local, n_chain_total=self.n_total, chain_offset=self.offset,
+            hidden_xt=args.hidden_xt, n_chain_local=self.n_local, n_chain_valid=self.n_valid, n_chain_total=self.n_total, chain_offset=self.offset,
             grad_clip=float(args.gradient_clip) if self.dim > 128 else 0.0,          # exe_flow_matching.py:351
             sigma=float(args.sigma), cond_flow=int(bool(args.cond_flow)), hutch=int(bool(args.hutchs)),
             rtol=float(args.rtol), atol=float(args.atol), mxstep=int(args.mxstep),
@@ -169,8 +171,14 @@ class Engine:
     # ---- helpers --------------------------------------------------------------------------------------------
     def local(self, full):
         """Rows of a [n_total, ...] host array owned by this rank, as a float32 device tensor."""
-        a = np.asarray(full)[self.offset:self.offset + self.n_local]
-        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=self.dev)
+        return self.torch.as_tensor(self.pad_rows(np.asarray(full)[self.offset:self.offset + self.n_valid]), device=self.dev)
+
+    def pad_rows(self, a):
+        """[n_valid, ...] host rows -> [n_local, ...] float32: the padding rows repeat the last chain (finite, never counted)."""
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.shape[0] < self.n_local:
+            a = np.concatenate([a, np.repeat(a[-1:], self.n_local - a.shape[0], axis=0)])
+        return a
 
     def empty_state(self):
         t = self.torch
@@ -184,7 +192,7 @@ class Engine:
         return out
 
     def all_logliks(self, pos):
-        return allgather_cat(self.loglik(pos))
+        return allgather_cat(self.loglik(pos)[:self.n_valid].contiguous())
 
     # ---- one training step on the local chains (exe_flow_matching.py:362-368) -----------------------------------
     def train_step(self, key, positions, loss_out=None):

@@ -191,6 +191,8 @@ def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
     def conditional_importance_sampling(rng_key, beta, pos, logp):
         """:280-296.  The solves and target evaluations are the kernels the other flow steps use; the per-chain
         weights, the categorical draw and the state update run in ``mfm_cis_select``."""
+        if eng.n_valid != eng.n_local:
+            raise NotImplementedError("num_importance_samples > 0 with a chain count that is not a multiple of 16 per GPU")
         keys = jr.split(rng_key, eng.n_total)[eng.offset:eng.offset + n]                   # :303
         kk = jr.split_rows(keys, 4)                                                        # :281
         u0 = t.empty_like(pos); vol0 = t.empty(n, device=eng.dev, dtype=t.float32)
@@ -261,15 +263,20 @@ def final_sampling(eng, dist, args, key_gen, transform_and_logdet, params=None):
     the same N indices from the same key.  Returns tensors over all N samples, identical on every rank."""
     t = eng.torch
     n_final = args.eval_iter * args.num_chain
-    if n_final % (16 * eng.world):
-        raise ValueError(f"eval_iter * num_chain = {n_final} must be a multiple of 16 x world size")
+    if n_final % eng.world:
+        raise ValueError(f"eval_iter * num_chain = {n_final} must be a multiple of the world size")
     ref = ref_dists[args.ref_dist](args.dim)                                                # :388
     u_host = ref.sample_rows(jr.split(key_gen, n_final))                                    # :453 (:389)
     key_hutch, key_choice = jr.split(key_gen)                                               # :454
     per = n_final // eng.world
     lo = eng.rank * per
     u = t.as_tensor(np.ascontiguousarray(u_host[lo:lo + per], dtype=np.float32), device=eng.dev)
-    flow_local, vols = transform_and_logdet(key_hutch, u, params)                           # :455
+    if per % 16:                                                                            # (tiles of 16 samples: pad with copies, drop them again)
+        u_pad = t.cat([u, u[-1:].expand(16 - per % 16, -1)]).contiguous()
+        flow_pad, vols_pad = transform_and_logdet(key_hutch, u_pad, params)
+        flow_local, vols = flow_pad[:per].contiguous(), vols_pad[:per].contiguous()
+    else:
+        flow_local, vols = transform_and_logdet(key_hutch, u, params)                       # :455
     lp_local = _logprob_any(eng, flow_local)                                                # :456
     ref_lp = (-0.5 * (((u.double() - ref.mean) / ref.std) ** 2).sum(1) - args.dim * np.log(ref.std) - 0.5 * args.dim * np.log(2 * np.pi))   # distributions.py:89-90
     logw_local = lp_local - ref_lp - vols.double()                                          # :457
@@ -302,7 +309,7 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     model = VectorFieldNet(fourier_random, dist.grad_logprob, args.hidden_x, args.hidden_t, args.hidden_xt,
                            non_lins[args.non_linearity], args.gradient_clip if args.dim > 128 else None)     # :351
     n_eval = n_iter * n_chain if target_gn is not None else 0
-    eng = Engine(dist, args, fourier_random, max_eval_samples=max(n_eval, n_iter * n_chain, n_chain * max(int(args.num_importance_samples), 0)))
+    eng = Engine(dist, args, fourier_random, max_eval_samples=-(-max(n_eval, n_iter * n_chain, n_chain * max(int(args.num_importance_samples), 0)) // 16) * 16)
     model.attach(eng)
     vector_field_param = model.init(key_init, dist.init_params[0], 0.0)                     # :353
     learning_rate_fn = create_learning_rate_fn(learning_iter, args.warmup_steps, args.learning_rate)          # :355-359
@@ -325,8 +332,8 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
     if use_real_samples:                                                                    # :382-386, :429-430
         def train_data_generator(key, states, count, *_):
             """positions = vmap(target_gn)(split(key, n_chain)); no MCMC state, acceptance is NaN."""
-            rows = dist.sample_rows(jr.split(key, n_chain))[eng.offset:eng.offset + eng.n_local]
-            states.position.copy_(torch.as_tensor(np.ascontiguousarray(rows, dtype=np.float32), device=eng.dev))
+            rows = dist.sample_rows(jr.split(key, n_chain))[eng.offset:eng.offset + eng.n_valid]
+            states.position.copy_(torch.as_tensor(eng.pad_rows(rows), device=eng.dev))
             return states, MALAInfo(nan_acc, None, None, None)
         nan_acc = torch.full((eng.n_local,), float("nan"), device=eng.dev, dtype=torch.float32)
         init_fn = lambda positions, *_: MALAState(positions, None, None)
@@ -371,7 +378,7 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
         if not use_real_samples and count % iter_per_temp == 0 and beta < 1.0:              # :440-441, :417
             beta = eng.ctx.beta_update(beta, eng.all_logliks(train_states.position), args.alpha)              # :413
             train_states = init_fn(train_states.position, beta)                             # :415
-        eng.ctx.acc_stats(infos.acceptance_rate, row[1:3])                                  # :442-443, per-rank partial sums
+        eng.ctx.acc_stats(infos.acceptance_rate[:eng.n_valid], row[1:3])                    # :442-443, per-rank partial sums (chains only: no padding rows)
         if real_samples is not None:                                                        # :444-446
             eng.eval_loss(key_loss, real_samples, row[3:4], n_total=n_eval, offset=eng.rank * (n_eval // eng.world))
         betas.append(beta)

@@ -75,6 +75,34 @@ def test_phi4_loop_matches_oracle():
     ex["engine"].close()
 
 
+@pytest.mark.parametrize("family", ["tile", "wide"])
+def test_loop_with_a_chain_count_that_is_not_a_multiple_of_16(monkeypatch, family):
+    """--num_chain takes any integer in the reference (multi_modal.py:169).  40 chains: the shard is padded to 48 rows
+    (mfm_config.n_chain_valid = 40); the padding rows must not show in the loss, the gradient (through the parameters), the
+    annealing temperatures (ESS over the chains) or the acceptance statistics.  Both kernel families."""
+    from mfm_amd import _lib
+    if family == "wide":
+        monkeypatch.setenv("MFM_KERNEL_FAMILY", str(_lib.FAMILY_WIDE))
+    out, res, ex = _run_both("phi-four", 64, 40, 9, 3, step_size=1e-4)
+    tr, m = out["trace"], ex["metrics"]
+    assert ex["states"].position.shape[0] == 48 and ex["engine"].n_valid == 40
+    np.testing.assert_allclose(m[:3, 0], tr["loss"][:3], rtol=1e-6)      # before the first flow step: same chains, same noise
+    np.testing.assert_allclose(m[:, 0], tr["loss"], rtol=1e-2)           # (one flipped chain of 40 after a flow step: test_phi4_loop_matches_oracle)
+    np.testing.assert_allclose(ex["betas"], tr["beta"], rtol=2e-3)
+    mala_it = [i for i in range(9) if (i + 1) % 4 != 0]
+    np.testing.assert_allclose(m[mala_it, 1], np.array(tr["acc_mean"])[mala_it], atol=2e-3)
+    np.testing.assert_allclose(m[mala_it, 2], np.array(tr["acc_std"])[mala_it], atol=5e-3)
+    from tests import gpu_util as gu
+    po = gu.flat_params(out["state"].params)
+    pg = ex["engine"].ctx.get_params()
+    assert np.abs(pg - po).max() < 3e-3 * max(1.0, np.abs(po).max())
+    g = ex["states"].position.cpu().numpy().astype(np.float64)[:40]
+    dmax = np.abs(g - out["states"].position).max(1)
+    assert (dmax > 0.05).sum() <= 4 and dmax[dmax <= 0.05].max() < 2e-2
+    assert ex["final"]["flow_samples"].shape[0] == 40 and np.isfinite(res[0])
+    ex["engine"].close()
+
+
 @pytest.mark.parametrize("hutch", [True, False])
 def test_four_mode_loop_matches_oracle(hutch):
     """BASELINE configs[0] in miniature; hutch=False is the reference's default (exact trace)."""

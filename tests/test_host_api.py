@@ -116,8 +116,8 @@ def test_cli_defaults_and_overrides_match_reference():
 
 def test_chain_sharding():
     from mfm_amd.engine import shard
-    assert shard(32768, 3, 8) == (4096, 12288)
+    assert shard(32768, 3, 8) == (4096, 12288, 4096)
     with pytest.raises(ValueError):
         shard(100, 0, 8)
-    with pytest.raises(ValueError):
-        shard(64, 0, 8)                      # 8 chains per GPU: not a multiple of one MFMA M-tile
+    assert shard(64, 3, 8) == (16, 24, 8)    # 8 chains per GPU: padded to one MFMA M-tile, global ids stay those of the chains
+    assert shard(100, 0, 1) == (112, 0, 100)  # --num_chain takes any integer (multi_modal.py:169)

@@ -18,7 +18,7 @@ def _worker(rank, world, port, out):
     from oracle.vfield import VectorFieldNet
     from tests import gpu_util as gu
     n_total, d = 64, 16
-    n_local, off = engine.shard(n_total, rank, world)
+    n_local, off, _ = engine.shard(n_total, rank, world)
     dist = targets.PhiFour(d)
     x = dist.initialize_model(prng.PRNGKey(3), n_total, start=off, count=n_local)
     model = VectorFieldNet(prng.normal(prng.PRNGKey(4), (8,)), dist, [16, 16], [16, 16], [16, 16])
