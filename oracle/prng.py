@@ -123,6 +123,30 @@ def normal(key, shape=(), start=0, count=None):
     return np.sqrt(2.0) * erfinv(u)
 
 
+# ---- 32-bit draw mode --------------------------------------------------------------------------------------------------------
+# What jax.random does WITHOUT jax_enable_x64.  The reference never draws this way (multi_modal.py:14 enables x64) and neither do the
+# kernels; these three functions exist to pin the CONVENTIONS the 64-bit path shares with it -- the counter layout of
+# ``_random_bits`` (``threefry_2x32(key, iota(n))``, odd sizes padded), the mantissa fill ``bits >> (nbits - nmant) | 1.0`` minus one,
+# the (nextafter(-1, 0), 1) range and sqrt(2) erfinv of ``normal`` -- against values PUBLISHED in the jax documentation
+# (tests/test_oracle_prng.py): jax itself cannot be imported here.
+def random_bits32(key, size):
+    return _threefry_2x32_counts(key, size)
+
+
+def uniform32(key, shape=(), minval=0.0, maxval=1.0):
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    size = int(np.prod(shape)) if shape else 1
+    fb = (random_bits32(key, size) >> _U32(9)) | np.float32(1.0).view(_U32)
+    f = fb.view(np.float32) - np.float32(1.0)
+    lo, hi = np.float32(minval), np.float32(maxval)
+    return np.maximum(lo, (f * (hi - lo) + lo).astype(np.float32)).reshape(shape)
+
+
+def normal32(key, shape=()):
+    u = uniform32(key, shape, np.nextafter(np.float32(-1.0), np.float32(0.0)), 1.0)
+    return (np.float32(np.sqrt(2.0)) * erfinv(u.astype(np.float64)).astype(np.float32)).astype(np.float32)
+
+
 def bernoulli(key, p):
     p = np.asarray(p, dtype=np.float64)
     return uniform(key, p.shape) < p

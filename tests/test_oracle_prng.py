@@ -70,3 +70,17 @@ def test_dirichlet_restatement():
     d = np.array([prng.dirichlet(k, 4.0 * np.ones(4)) for k in prng.split(prng.PRNGKey(9), 300)])
     np.testing.assert_allclose(d.mean(0), 0.25, atol=0.02)                         # E[w_i] = alpha_i / sum(alpha)
     np.testing.assert_allclose(d.var(0), 0.25 * 0.75 / 17.0, rtol=0.3)             # Var[w_i] = a_i (a_0 - a_i) / (a_0^2 (a_0 + 1))
+
+
+def test_32_bit_draws_match_values_published_in_the_jax_documentation():
+    """Outside pins of the draw conventions (counter layout of random_bits, mantissa fill, the normal's range and erfinv):
+    values printed in jax's own documentation for its default 32-bit mode -- the "Pseudorandom numbers" tutorial
+    (``random.normal(PRNGKey(42))``, ``random.normal(subkey)`` after one split) and the ``jax.random`` module page
+    (``random.uniform(PRNGKey(0))``).  The 64-bit path the reference uses (jax_enable_x64) applies the same conventions to
+    64-bit words; it has no published values."""
+    assert prng.uniform32(prng.PRNGKey(0)) == np.float32(0.41845703)
+    key = prng.PRNGKey(42)
+    # (published: -0.18471177; float32 erfinv implementations differ in the last two bits)
+    assert abs(float(prng.normal32(key)) - (-0.18471177)) < 1e-7
+    _, subkey = prng.split(key)
+    assert prng.normal32(subkey) == np.float32(1.3694694)
