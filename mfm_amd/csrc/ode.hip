@@ -23,7 +23,12 @@
 // Gaussian draws the solver kernels consume (Hutchinson probes of both solves, latent random-walk noise) are
 // produced by a small separate kernel into this workspace: the float64 erfinv code would otherwise sit inside the
 // persistent solver kernel and cost it ~200 spilled registers.
-struct OdeWs { float* noise; size_t rows; f32x4* fast_scr; size_t fast_wgs; };
+// padded images for the shape-specialised kernels serving a NARROWER lattice than their tile width (ode_fast.hip: dispatch):
+// the parameter pack in the tile's shapes and six [rows][D] images (position, gradient, proposal / output, three probes)
+struct PadWs { float* Wp; float* WpT; float* bias; float* img[6]; size_t rows; int D; };
+struct OdeWs { float* noise; size_t rows; f32x4* fast_scr; size_t fast_wgs; PadWs pad; };
+static thread_local const PadWs* t_pad = nullptr;      // the padded images of the context whose OdeArgs were formed last (ode_args): host-side only,
+                                                        // kept out of the kernel arguments (two more words there cost the headline kernel 2 %)
 #define ODE_FAST_MAX_WGS 1024                 // grid cap of the shape-specialised transform kernel (it loops over tiles)
 #define ODE_FAST_SCR_F4 (5 * 8 * 3 * 64)      // float4 of time-branch scratch per workgroup (ode_fast.hip)
 static int ode_ws_alloc(const NetDev& n, const mfm_config& c, OdeWs& w) {
@@ -32,11 +37,27 @@ static int ode_ws_alloc(const NetDev& n, const mfm_config& c, OdeWs& w) {
   const size_t t_all = w.rows / 16, t_chain = (size_t)c.n_chain_local / 16;
   w.fast_wgs = t_all < ODE_FAST_MAX_WGS ? t_all : ODE_FAST_MAX_WGS;
   if (w.fast_wgs < t_chain) w.fast_wgs = t_chain;        // the flow step runs one workgroup per tile of 16 chains
+  memset(&w.pad, 0, sizeof w.pad);
+  if (c.hutch && n.T.kind == MFM_TARGET_PHI4 && n.act == MFM_ACT_RELU && n.F == 128 && n.ht1 == 128 && n.ht2 == 128 && n.hx1 == 128 &&
+      n.hx2 == 128 && n.hj1 == 128 && n.hj2 == 128 && n.d >= 16 && n.d < 256 && n.d != 128 && n.d % 16 == 0) {
+    const int D = n.d < 128 ? 128 : 256;
+    const size_t wtot = (size_t)2 * 128 * 128 + 5 * 128 * 128 + 3 * (size_t)D * 128;      // FS<D>::WTOT
+    w.pad.D = D; w.pad.rows = w.rows;
+    if (hipMalloc((void**)&w.pad.Wp, wtot * sizeof(float)) != hipSuccess || hipMalloc((void**)&w.pad.WpT, wtot * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&w.pad.bias, (6 * 128 + 2 * D) * sizeof(float)) != hipSuccess) return -4;
+    if (hipMemset(w.pad.WpT, 0, wtot * sizeof(float)) != hipSuccess) return -4;
+    for (int i = 0; i < 6; ++i)
+      if (hipMalloc((void**)&w.pad.img[i], w.rows * D * sizeof(float)) != hipSuccess) return -4;
+  }
   return hipMalloc((void**)&w.fast_scr, w.fast_wgs * ODE_FAST_SCR_F4 * sizeof(f32x4)) == hipSuccess ? 0 : -4;
 }
 static void ode_ws_free(OdeWs& w) {
   if (w.noise) (void)hipFree(w.noise);
   if (w.fast_scr) (void)hipFree(w.fast_scr);
+  for (void* p_ : {(void*)w.pad.Wp, (void*)w.pad.WpT, (void*)w.pad.bias, (void*)w.pad.img[0], (void*)w.pad.img[1], (void*)w.pad.img[2],
+                   (void*)w.pad.img[3], (void*)w.pad.img[4], (void*)w.pad.img[5]})
+    if (p_) (void)hipFree(p_);
+  memset(&w.pad, 0, sizeof w.pad);
   w.noise = nullptr; w.fast_scr = nullptr;
 }
 
@@ -78,7 +99,7 @@ struct FlowArgs {
 
 static OdeArgs ode_args(const NetDev& n, const mfm_config& c, const OdeWs& w) {
   OdeArgs a; memset(&a, 0, sizeof a);
-  a.z1 = w.noise; a.z2 = w.noise + w.rows * n.d; a.zgen = w.noise + 2 * w.rows * n.d; a.fast_scr = w.fast_scr;
+  a.z1 = w.noise; a.z2 = w.noise + w.rows * n.d; a.zgen = w.noise + 2 * w.rows * n.d; a.fast_scr = w.fast_scr; t_pad = &w.pad;
   a.net = n; a.hutch = c.hutch; a.rtol = (float)c.rtol; a.atol = (float)c.atol;
   a.max_attempts = c.mxstep * (c.n_ts > 1 ? c.n_ts - 1 : 1);
   return a;
@@ -1253,7 +1274,7 @@ int launch_ode_transform(const OdeArgs& a, hipStream_t stream) {
   if (a.hutch) launch_probe(a.per_chain_keys ? 0 : 1, a.keys, a.key, 0, 0, 0, a.n, a.net.d, const_cast<float*>(a.z1), stream);
   if (d2::use_for(a.net, a.hutch, a.n)) return d2::launch_transform(a, stream);
   if (fast::shape_ok(a.net, a.hutch) && !g_sw.generic_ode)
-    return a.net.d == 256 ? fast::launch_transform_t<256>(a, a.fast_scr, stream) : fast::launch_transform_t<128>(a, a.fast_scr, stream);
+    return fast::tile_width(a.net) == 256 ? fast::launch_transform_t<256>(a, a.fast_scr, stream) : fast::launch_transform_t<128>(a, a.fast_scr, stream);
   ODE_LAUNCH(ode_transform_kernel, dim3(a.n / 16), a);
   return 0;
 }
@@ -1273,7 +1294,7 @@ int launch_flow_step(const OdeArgs& a, const FlowArgs& f, const NoiseArgs& nz, h
   }
   if (d2::use_for(a.net, a.hutch, a.n)) return d2::launch_flow(a, f, stream);
   if (fast::shape_ok(a.net, a.hutch) && !g_sw.generic_ode)
-    return a.net.d == 256 ? fast::launch_flow_t<256>(a, f, nz, a.fast_scr, stream) : fast::launch_flow_t<128>(a, f, nz, a.fast_scr, stream);
+    return fast::tile_width(a.net) == 256 ? fast::launch_flow_t<256>(a, f, nz, a.fast_scr, stream) : fast::launch_flow_t<128>(a, f, nz, a.fast_scr, stream);
   ODE_LAUNCH(flow_step_kernel, dim3(a.n / 16), a, f);
   return 0;
 }

@@ -1,5 +1,5 @@
 // K5f / K6f: the flow-MH step and the CNF transforms for the HEADLINE network shape (fourier_dim = 128, all hidden
-// widths 128, dim 128 or 256, Hutchinson log-det, PhiFour target), as a shape-specialised sibling of the generic solver
+// widths 128, dim 128 or 256 -- narrower lattices zero-padded to those, see the dispatch section --, Hutchinson log-det, PhiFour target), as a shape-specialised sibling of the generic solver
 // tile in ode.hip.  Same algorithm, same arithmetic per field evaluation (exe_flow_matching.py:206-242, :246-278;
 // jax.experimental.ode.odeint restated in oracle/ode.py); what changes is the schedule:
 //
@@ -990,12 +990,12 @@ struct FTile {
 // RP: the parity-instrumentation instance (Replay, ode.hip); the production instance (RP = false) carries none of it.
 template <int D, bool RP>
 __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int max_attempts, float (&y)[FTile<D>::TPW][4],
-                                      float (&ell)[4], int (&natt)[4], const Replay& rp, int rp_row0) {
+                                      float (&ell)[4], int (&natt)[4], const Replay& rp, int rp_row0, int d_true = D) {
   using S = FS<D>;
   constexpr int TPW = FTile<D>::TPW, LDX = S::LDX;
   const int g = T.g, c = T.c, wave = T.wave;
   float* lds = T.lds;
-  const float inv_n = 1.f / (float)(D + 1);
+  const float inv_n = 1.f / (float)(d_true + 1);      // (d_true < D: a network zero-padded to this instance's tile width, see launch_*)
   float k[7][TPW][4];
 #pragma unroll
   for (int j = 0; j < 7; ++j)
@@ -1247,12 +1247,14 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
 // 2 finish, 3 initial slope) and the interpolation abscissa.  Shared by the tile's main loop (solve2) and its tail (solve2_tail).
 // STICKY: the rows keep the slots they were given when the tail began (RS_RANK = slot or -1); otherwise ranks and the tile's
 // evaluation mode are recomputed from the rows that take part in the next attempt.  Returns "this row takes part in it".
-template <int D, bool RP, bool STICKY, typename AA, typename FA>
+__device__ __forceinline__ int true_dim(const OdeArgs& a) { return a.net.d; }
+__device__ __forceinline__ int true_dim(const struct TailArgs& a);
+template <int D, bool RP, bool STICKY, bool PAD, typename AA, typename FA>
 __device__ __forceinline__ int leaders_end_of_attempt(FTile<D>& T, const AA& a, const FA& f, int b0, int cmode) {
   using S = FS<D>;
   const float rtol = a.rtol, atol = a.atol;
   const int max_attempts = a.max_attempts;
-  const float inv_n = 1.f / (float)(D + 1);
+  const float inv_n = 1.f / (float)((PAD ? true_dim(a) : D) + 1);
   int any = 0;
   // (the tail derives its lane coordinates locally: see solve2_tail)
   int o_l8 = T.o_l8, o_l1 = T.o_l1, ln = T.lane;
@@ -1440,15 +1442,16 @@ struct TailMap {
 // (what the loops need of the kernel's arguments, by value: the loops are functions of their own -- see below -- and a reference to
 // the kernel's argument structs would pin those to memory for the main loop as well)
 struct TailArgs {
-  float rtol, atol; int max_attempts;
+  float rtol, atol; int max_attempts; int d_true;
   float coef, tbeta, clip; const float* fourier; const float* Wp;
   const float* zgen; const float* z2;
   int mode; float ref_std;                                    // FlowArgs::mode, ::ref_std
   Replay rp;
 };
+__device__ __forceinline__ int true_dim(const TailArgs& a) { return a.d_true; }
 // NOT inlined: inlined into solve2, the three loops changed the register allocation of the MAIN loop (its Runge-Kutta stages went
 // to scratch: 50 -> 63 ms).  As functions they get an allocation of their own and the main loop keeps the one it had.
-template <int D, bool RP, int P>
+template <int D, bool RP, int P, bool PAD>
 __device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
   using S = FS<D>;
   using M = TailMap<D, P>;
@@ -1475,7 +1478,7 @@ __device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
   const int sl2 = g & 1;                                      // slot of this lane inside a pass
   const bool is_t = g >= 2;
   float* const lds = T.lds;
-  const float scale = 2.38f / sqrtf((float)D);                                                  // :262
+  const float scale = 2.38f / sqrtf((float)(PAD ? a.d_true : D));                               // :262
   const float rtol = a.rtol, atol = a.atol;
   const float t_coef = a.coef, t_beta = a.tbeta, t_clip = a.clip;
   const float ffreq = a.fourier[16 * wave + c];
@@ -1848,7 +1851,7 @@ __device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
     if (threadIdx.x == 0) RSF(RS_TILE, 0) = 0.f;              // "some row switched solves in this attempt"
     __syncthreads();
     int any = 0;
-    if (wave == 0 && lane < 16) any = leaders_end_of_attempt<D, RP, true>(T, a, f, b0, 3);
+    if (wave == 0 && lane < 16) any = leaders_end_of_attempt<D, RP, true, PAD>(T, a, f, b0, 3);
     (void)__syncthreads_or(any);
     // ---- apply the decision of my slots' rows ----
     const bool some_fin = RSF(RS_TILE, 3) != 0.f;
@@ -1956,15 +1959,14 @@ __device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
 // INIT1 with dt = h0 and unit stage coefficients in slot 0 (the extra evaluation at t0 + h0); their remaining slots are
 // ignored.  Per-row arithmetic (controller, interpolation, step sizes) is that of solve() bit for bit.
 // On return: y = proposal x' at t = 1 of the forward solve, row state holds ell (forward), vol0 (inverse), lq, counts.
-template <int D, bool RP>
+template <int D, bool RP, bool PAD>
 __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const FlowArgs& f, int b0, float (&y)[FTile<D>::TPW][4]) {
   using S = FS<D>;
   constexpr int TPW = FTile<D>::TPW, LDX = S::LDX;
   const int g = T.g, c = T.c, wave = T.wave;
   const float rtol = a.rtol, atol = a.atol;
   const int max_attempts = a.max_attempts;
-  const float inv_n = 1.f / (float)(D + 1);
-  const float scale = 2.38f / sqrtf((float)D);                                                  // :262
+  const float scale = 2.38f / sqrtf((float)(PAD ? a.net.d : D));                                // :262
   float k[7][TPW][4];
 #pragma unroll
   for (int j = 0; j < 7; ++j)
@@ -2106,7 +2108,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
     const unsigned long long n1_ = __builtin_amdgcn_s_memtime();
 #endif
     int any = 0;
-    if (wave == 0 && T.lane < 16) any = leaders_end_of_attempt<D, RP, false>(T, a, f, b0, cmode);
+    if (wave == 0 && T.lane < 16) any = leaders_end_of_attempt<D, RP, false, PAD>(T, a, f, b0, cmode);
     const int go = __syncthreads_or(any);
 #ifdef MFM_STAMPS
     const unsigned long long n2_ = __builtin_amdgcn_s_memtime();
@@ -2191,16 +2193,16 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
       const unsigned long long tl0_ = __builtin_amdgcn_s_memtime();
 #endif
       TailArgs ta;
-      ta.rtol = a.rtol; ta.atol = a.atol; ta.max_attempts = a.max_attempts;
+      ta.rtol = a.rtol; ta.atol = a.atol; ta.max_attempts = a.max_attempts; ta.d_true = a.net.d;
       ta.coef = a.net.T.coef; ta.tbeta = a.net.T.tbeta; ta.clip = a.net.grad_clip; ta.fourier = a.net.fourier; ta.Wp = a.net.Wp;
       ta.zgen = a.zgen; ta.z2 = a.z2; ta.mode = f.mode; ta.ref_std = f.ref_std; ta.rp = a.rp;
 #pragma unroll 1
       for (;;) {
         const int live = __popcll(__ballot(*T.at((T.lane & 15) * 4, S::RS + RS_RANK * 16) >= 0.f) & 0xFFFFull);
         if (live == 0) break;
-        if (TAIL_PASSES >= 3 && live > 4) solve2_tail<D, RP, TAIL_PASSES >= 3 ? 3 : 1>(ta, b0);
-        else if (TAIL_PASSES >= 2 && live > 2) solve2_tail<D, RP, TAIL_PASSES >= 2 ? 2 : 1>(ta, b0);
-        else solve2_tail<D, RP, 1>(ta, b0);
+        if (TAIL_PASSES >= 3 && live > 4) solve2_tail<D, RP, TAIL_PASSES >= 3 ? 3 : 1, PAD>(ta, b0);
+        else if (TAIL_PASSES >= 2 && live > 2) solve2_tail<D, RP, TAIL_PASSES >= 2 ? 2 : 1, PAD>(ta, b0);
+        else solve2_tail<D, RP, 1, PAD>(ta, b0);
       }
 #ifdef MFM_STAMPS
       T.cyc_tail += __builtin_amdgcn_s_memtime() - tl0_;
@@ -2259,7 +2261,7 @@ __device__ __forceinline__ void fill_probe(FTile<D>& T, const float* z, int b0) 
   }
 }
 
-template <int D, bool RP>
+template <int D, bool RP, bool PAD = false>
 __global__ __launch_bounds__(NW * 64) void ode_transform_fast_kernel(OdeArgs a, f32x4* scratch) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TPW = FTile<D>::TPW;
@@ -2278,7 +2280,7 @@ __global__ __launch_bounds__(NW * 64) void ode_transform_fast_kernel(OdeArgs a, 
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[q][i] = a.in[(size_t)(b0 + 4 * T.g + i) * D + col];
     }
-    solve<D, RP>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt, a.rp, b0);
+    solve<D, RP>(T, a.rtol, a.atol, a.max_attempts, y, ell, natt, a.rp, b0, PAD ? a.net.d : D);
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
       const int col = 16 * (T.wave + NW * q) + T.c;
@@ -2296,7 +2298,7 @@ __global__ __launch_bounds__(NW * 64) void ode_transform_fast_kernel(OdeArgs a, 
 }
 
 // One flow-based MH step per chain (random-walk in latent space :264-278, or independent :246-260), PhiFour target.
-template <int D, bool RP>
+template <int D, bool RP, bool PAD = false>
 __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, FlowArgs f, NoiseArgs nz, f32x4* scratch) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using S = FS<D>;
@@ -2316,7 +2318,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
     for (int i = 0; i < 4; ++i) y[q][i] = f.pos[(size_t)(b0 + 4 * g + i) * D + col];                 // :267 / :251
   }
   fill_probe(T, a.z1, b0);               // key_hutch2: probe of the inverse solve (the forward probe is loaded per row)
-  solve2<D, RP>(T, a, f, b0, y);         // inverse solve -> proposal -> forward solve, per row
+  solve2<D, RP, PAD>(T, a, f, b0, y);    // inverse solve -> proposal -> forward solve, per row
   {
     const f32x4 e4 = T.rs_get(RS_ELL), v4 = T.rs_get(RS_VOL0), l4 = T.rs_get(RS_LQ), n0 = T.rs_get(RS_NTOT), n1 = T.rs_get(RS_NATT);
 #pragma unroll
@@ -2339,7 +2341,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float* xr = T.at(T.o_xo, S::XB0 + i * LDX + 128 * q) - col;      // row base: xr[col] is this lane's element
-        part[i] += phi4_term(a.net.T, xr, col);
+        if (!PAD || col < a.net.d) part[i] += phi4_term(a.net.T, xr, col);     // (PAD: columns >= d are the zero padding of a narrower lattice)
         gnew[q][i] = (float)f.beta * phi4_grad(a.net.T, xr, col);
       }
     }
@@ -2416,18 +2418,102 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
 }
 
 // ---- dispatch --------------------------------------------------------------------------------------------------
+// The two instances (tile width D = 128, 256) also serve NARROWER lattices (d a multiple of 16 below D: the reference's own
+// phi-four default is d = 64, multi_modal.py:52-55) by zero padding: x1 gets D - d zero input rows, the gate and the out layer D - d
+// zero output columns (weights AND biases), so the padded columns of the state stay exactly zero through both solves (their field
+// is 0 + 0 * clip(...)), contribute nothing to any norm, divergence or proposal, and the kernels only need the true d in three
+// places: the error norm's 1 / (d + 1), the random-walk scale 2.38 / sqrt(d) and the target sum at the proposal.  The padded
+// weight / bias pack is re-formed from the network's own pack before every launch (0.7 MB: microseconds per 101 iterations);
+// chain states and probes are staged through [n][D] images.  The generic tile needs 85.9 k cycles per evaluation at these widths.
+static int tile_width(const NetDev& n) { return n.d <= 128 ? 128 : 256; }
 static bool shape_ok(const NetDev& n, int hutch) {
   if (!hutch || n.T.kind != MFM_TARGET_PHI4 || n.act != MFM_ACT_RELU) return false;
   if (n.F != F || n.ht1 != H || n.ht2 != H || n.hx1 != H || n.hx2 != H || n.hj1 != H || n.hj2 != H) return false;
-  return n.d == 256 || n.d == 128;
+  return n.d >= 16 && n.d <= 256 && n.d % 16 == 0;
 }
 static int max_wgs() { return ODE_FAST_MAX_WGS; }
 
+// padded parameter pack of a narrower network for instance D: every layer with (true -> padded) shapes, from the network's own pack
+template <int D>
+__global__ void pad_pack_kernel(NetDev n, float* Wp, float* WpT, float* bias) {
+  using S = FS<D>;
+  const int Kpad[8] = {2 * F, H, D, H, H, 2 * H, H, H}, Npad[8] = {H, H, H, H, D, H, H, D};
+  const int woff[8] = {S::W0, S::W1, S::W2, S::W3, S::W4, S::W5, S::W6, S::W7};
+  const int boff[8] = {S::B0, S::B1, S::B2, S::B3, S::B4, S::B5, S::B6, S::B7};
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < S::WTOT; e += gridDim.x * blockDim.x) {
+    int l = 7;
+#pragma unroll
+    for (int j = 7; j >= 1; --j) if (e < woff[j]) l = j - 1;
+    const int r = e - woff[l], k = r / Npad[l], nn = r - k * Npad[l];
+    const LayerDesc& ld = n.L[l];
+    const float w = (k < ld.Kp && nn < ld.Np) ? n.Wp[ld.w_off + pack_index(k, nn, ld.Kp / 16)] : 0.f;
+    Wp[woff[l] + pack_index(k, nn, Kpad[l] / 16)] = w;
+    if (l == 7) WpT[woff[7] + pack_index_T(k, nn, Npad[7] / 16)] = w;
+  }
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < S::BTOT; e += gridDim.x * blockDim.x) {
+    int l = 7;
+#pragma unroll
+    for (int j = 7; j >= 1; --j) if (e < boff[j]) l = j - 1;
+    const int nn = e - boff[l];
+    bias[e] = nn < n.L[l].Np ? n.bias[n.L[l].b_off + nn] : 0.f;
+  }
+}
+// [n][d] -> [n][D] (zero columns) and back
+__global__ void pad_rows_kernel(const float* src, float* dst, int n, int d, int D) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)n * D; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = e / D; const int c = (int)(e - r * D);
+    dst[e] = c < d ? src[r * d + c] : 0.f;
+  }
+}
+__global__ void unpad_rows_kernel(const float* src, float* dst, int n, int d, int D) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)n * d; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = e / d; const int c = (int)(e - r * d);
+    dst[e] = src[r * D + c];
+  }
+}
+static void pad_rows(const float* src, float* dst, int n, int d, int D, hipStream_t s) {
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)(((size_t)n * D + 255) / 256 < 4096 ? ((size_t)n * D + 255) / 256 : 4096)), dim3(256), 0, s, src, dst, n, d, D);
+}
+static void unpad_rows(const float* src, float* dst, int n, int d, int D, hipStream_t s) {
+  hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)(((size_t)n * d + 255) / 256 < 4096 ? ((size_t)n * d + 255) / 256 : 4096)), dim3(256), 0, s, src, dst, n, d, D);
+}
+// arguments of a launch on the padded images (the caller's stay as they are); false: no workspace for this shape / row count
+template <int D>
+static bool pad_args(OdeArgs& a, hipStream_t s) {
+  if (!t_pad) return false;
+  const PadWs& w = *t_pad;
+  if (!w.Wp || w.D != D || (size_t)a.n > w.rows) return false;
+  hipLaunchKernelGGL((pad_pack_kernel<D>), dim3(256), dim3(256), 0, s, a.net, w.Wp, w.WpT, w.bias);
+  a.net.Wp = w.Wp; a.net.WpT = w.WpT; a.net.bias = w.bias;
+  const int d = a.net.d;
+  if (a.z1) { pad_rows(a.z1, w.img[3], a.n, d, D, s); a.z1 = w.img[3]; }
+  if (a.z2) { pad_rows(a.z2, w.img[4], a.n, d, D, s); a.z2 = w.img[4]; }
+  if (a.zgen) { pad_rows(a.zgen, w.img[5], a.n, d, D, s); a.zgen = w.img[5]; }
+  return true;
+}
+
 template <int D, bool RP>
-static int launch_flow_tr(const OdeArgs& a, const FlowArgs& f, const NoiseArgs& nz, f32x4* scratch, hipStream_t stream) {
+static int launch_flow_tr(const OdeArgs& a0, const FlowArgs& f0, const NoiseArgs& nz, f32x4* scratch, hipStream_t stream) {
   const size_t sm = (size_t)FS<D>::TOTAL * sizeof(float);
   (void)hipFuncSetAttribute((const void*)flow_step_fast_kernel<D, RP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL((flow_step_fast_kernel<D, RP>), dim3(a.n / 16), dim3(NW * 64), sm, stream, a, f, nz, scratch);
+  OdeArgs a = a0; FlowArgs f = f0;
+  const int d = a.net.d;
+  if (d != D) {
+    if (!pad_args<D>(a, stream)) return -3;
+    const PadWs& w = *t_pad;
+    pad_rows(f0.pos, w.img[0], a.n, d, D, stream); pad_rows(f0.grad, w.img[1], a.n, d, D, stream);
+    f.pos = w.img[0]; f.grad = w.img[1]; f.proposed = f0.proposed ? w.img[2] : nullptr;
+  }
+  if (d != D) {
+    (void)hipFuncSetAttribute((const void*)flow_step_fast_kernel<D, RP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL((flow_step_fast_kernel<D, RP, true>), dim3(a.n / 16), dim3(NW * 64), sm, stream, a, f, nz, scratch);
+  } else {
+    hipLaunchKernelGGL((flow_step_fast_kernel<D, RP, false>), dim3(a.n / 16), dim3(NW * 64), sm, stream, a, f, nz, scratch);
+  }
+  if (d != D) {
+    unpad_rows(f.pos, f0.pos, a.n, d, D, stream); unpad_rows(f.grad, f0.grad, a.n, d, D, stream);
+    if (f0.proposed) unpad_rows(f.proposed, f0.proposed, a.n, d, D, stream);
+  }
   return 0;
 }
 template <int D>
@@ -2435,11 +2521,24 @@ static int launch_flow_t(const OdeArgs& a, const FlowArgs& f, const NoiseArgs& n
   return a.rp.dt ? launch_flow_tr<D, true>(a, f, nz, scratch, stream) : launch_flow_tr<D, false>(a, f, nz, scratch, stream);
 }
 template <int D, bool RP>
-static int launch_transform_tr(const OdeArgs& a, f32x4* scratch, hipStream_t stream) {
+static int launch_transform_tr(const OdeArgs& a0, f32x4* scratch, hipStream_t stream) {
   const size_t sm = (size_t)FS<D>::TOTAL * sizeof(float);
   (void)hipFuncSetAttribute((const void*)ode_transform_fast_kernel<D, RP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  OdeArgs a = a0;
+  const int d = a.net.d;
+  if (d != D) {
+    if (!pad_args<D>(a, stream)) return -3;
+    pad_rows(a0.in, t_pad->img[0], a.n, d, D, stream);
+    a.in = t_pad->img[0]; a.out = t_pad->img[2];
+  }
   const int tiles = a.n / 16, grid = tiles < max_wgs() ? tiles : max_wgs();
-  hipLaunchKernelGGL((ode_transform_fast_kernel<D, RP>), dim3(grid), dim3(NW * 64), sm, stream, a, scratch);
+  if (d != D) {
+    (void)hipFuncSetAttribute((const void*)ode_transform_fast_kernel<D, RP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL((ode_transform_fast_kernel<D, RP, true>), dim3(grid), dim3(NW * 64), sm, stream, a, scratch);
+    unpad_rows(a.out, a0.out, a.n, d, D, stream);
+  } else {
+    hipLaunchKernelGGL((ode_transform_fast_kernel<D, RP, false>), dim3(grid), dim3(NW * 64), sm, stream, a, scratch);
+  }
   return 0;
 }
 template <int D>

@@ -24,7 +24,7 @@ def _setup(d, B, hidden, F, seed=9, out_scale=0.5):
     return args, dist, model, params, ctx
 
 
-@pytest.mark.parametrize("d,hidden,F", [(256, 128, 128), (128, 128, 128), (64, 32, 16)])     # the two shapes of the shape-specialised solver, one generic
+@pytest.mark.parametrize("d,hidden,F", [(256, 128, 128), (128, 128, 128), (64, 128, 128), (192, 128, 128), (64, 32, 16)])     # the shape-specialised solver at its two tile widths and zero-padded to them (d = 64: the reference's phi-four default), one generic
 def test_ode_transform_and_inverse_match_oracle(d, hidden, F):
     import torch
     B = 32
@@ -89,7 +89,7 @@ def test_ode_identity_flow_at_zero_init():
     ctx.close()
 
 
-@pytest.mark.parametrize("d,hidden,F", [(256, 128, 128), (128, 128, 128), (64, 32, 16)])
+@pytest.mark.parametrize("d,hidden,F", [(256, 128, 128), (128, 128, 128), (64, 128, 128), (192, 128, 128), (64, 32, 16)])
 def test_flow_rwmh_step_matches_oracle(d, hidden, F):
     import torch
     B = 32

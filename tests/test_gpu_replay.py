@@ -84,7 +84,7 @@ def _family_kw(fam):
 
 
 # shape-specialised solver x2, generic tile, and the wide family's host-driven solver (per-layer GEMMs, row kernels) on two shapes
-SHAPES = [(256, 128, 128, None), (128, 128, 128, None), (64, 32, 16, None), (256, 128, 128, "wide"), (64, 48, 16, "wide")]
+SHAPES = [(256, 128, 128, None), (128, 128, 128, None), (64, 128, 128, None), (64, 32, 16, None), (256, 128, 128, "wide"), (64, 48, 16, "wide")]   # (64, 128, 128): the shape-specialised kernels zero-padded to their 128-wide tile
 
 
 @pytest.mark.parametrize("d,hidden,F,fam", SHAPES)
