@@ -231,6 +231,13 @@ int mfm_smc_delta(mfm_ctx* ctx, const double* d_loglik, int n, double target_ess
 int mfm_smc_weights(mfm_ctx* ctx, const double* d_loglik, int n, double delta, double* d_weights, double* h_lognorm);
 int mfm_smc_resample(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const double* d_weights, int n, double* d_scratch,
                      int32_t* d_idx);
+/* the other cumulative-sum schemes of resampling.py: stratified (:55-57) and multinomial (:60-80, sorted uniforms);
+ * d_scratch: 2 n + 2 doubles.  (residual, :83-121, is composed on the host from the multinomial one: mfm_amd/bblackjax/smc/resampling.py) */
+#define MFM_RESAMPLE_SYSTEMATIC 0
+#define MFM_RESAMPLE_STRATIFIED 1
+#define MFM_RESAMPLE_MULTINOMIAL 2
+int mfm_smc_resample_scheme(mfm_ctx* ctx, int scheme, uint32_t key0, uint32_t key1, const double* d_weights, int n,
+                            double* d_scratch, int32_t* d_idx);
 int mfm_gather_rows(mfm_ctx* ctx, const float* d_src, const int32_t* d_idx, int n, int dim, float* d_dst);
 /* ---- N1: self-normalised importance resampling of the final flow samples (exe_flow_matching.py:458-459):
  *      d_idx[j] = jax.random.choice(key, n, (m,), p = exp(d_logw - max d_logw))[j]; d_scratch: n doubles (the cumulative sum,

@@ -57,6 +57,7 @@ _SIGS = {
     "mfm_smc_delta": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]),
     "mfm_smc_weights": (C.c_int, [_P, _P, C.c_int, C.c_double, _P, C.POINTER(C.c_double)]),
     "mfm_smc_resample": (C.c_int, [_P, _U32, _U32, _P, C.c_int, _P, _P]),
+    "mfm_smc_resample_scheme": (C.c_int, [_P, C.c_int, _U32, _U32, _P, C.c_int, _P, _P]),
     "mfm_gather_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "mfm_acc_stats": (C.c_int, [_P, _P, C.c_int, _P]),
     "mfm_choice_logw": (C.c_int, [_P, _U32, _U32, _P, C.c_int, C.c_int, _P, _P]),
@@ -254,6 +255,11 @@ class Context:
     def acc_stats(self, x, out):
         """out[0:2] (float64) = sum, sum of squares of the float32 vector x."""
         _chk(self.lib.mfm_acc_stats(self.h, _ptr(x, F32), x.shape[0], _ptr(out, F64)))
+
+    def smc_resample_scheme(self, scheme, key, weights, scratch, idx):
+        """scheme: 0 systematic, 1 stratified, 2 multinomial (resampling.py); scratch: 2 n + 2 float64."""
+        _chk(self.lib.mfm_smc_resample_scheme(self.h, int(scheme), int(key[0]), int(key[1]), _ptr(weights, F64), weights.shape[0],
+                                              _ptr(scratch, F64), _ptr(idx, I32)))
 
     def gather_rows(self, src, idx, dst):
         _chk(self.lib.mfm_gather_rows(self.h, _ptr(src, F32), _ptr(idx, I32), src.shape[0], src.shape[1], _ptr(dst, F32)))

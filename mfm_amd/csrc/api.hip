@@ -1107,6 +1107,15 @@ extern "C" int mfm_smc_resample(mfm_ctx* x, uint32_t k0, uint32_t k1, const doub
   LAUNCHCHK();
   return MFM_OK;
 }
+extern "C" int mfm_smc_resample_scheme(mfm_ctx* x, int scheme, uint32_t k0, uint32_t k1, const double* d_weights, int n, double* d_scratch, int32_t* d_idx) {
+  if (scheme == MFM_RESAMPLE_SYSTEMATIC) return mfm_smc_resample(x, k0, k1, d_weights, n, d_scratch, d_idx);
+  if (!x || !d_weights || !d_scratch || !d_idx) return fail(MFM_EINVAL, "null argument");
+  if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
+  if (scheme != MFM_RESAMPLE_STRATIFIED && scheme != MFM_RESAMPLE_MULTINOMIAL) return fail(MFM_EINVAL, "unknown resampling scheme %d", scheme);
+  hipLaunchKernelGGL(smc_resample2_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, scheme, Key2{k0, k1}, d_weights, n, d_scratch, d_idx);
+  LAUNCHCHK();
+  return MFM_OK;
+}
 extern "C" int mfm_choice_logw(mfm_ctx* x, uint32_t k0, uint32_t k1, const double* d_logw, int n, int m, double* d_scratch, int32_t* d_idx) {
   if (!x || !d_logw || !d_scratch || !d_idx) return fail(MFM_EINVAL, "null argument");
   if (n <= 0 || m <= 0) return fail(MFM_EINVAL, "n and m must be positive");

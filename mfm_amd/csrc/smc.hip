@@ -88,6 +88,32 @@ __global__ __launch_bounds__(SMC_THREADS) void smc_resample_kernel(Key2 key, con
   }
 }
 
+// The other cumulative-sum schemes of resampling.py: scheme 1 = stratified (:55-57: one uniform PER output, uniform(key, (n,))),
+// scheme 2 = multinomial (:60-80: Chopin's sorted uniforms z[:-1] / z[-1], z = cumsum(-log uniform(key, (n + 1,)))).  cum: 2 n + 2
+// doubles (cumulative weights, then the sorted uniforms' cumulative sum); both sums by ONE thread in index order, as above.
+__global__ __launch_bounds__(SMC_THREADS) void smc_resample2_kernel(int scheme, Key2 key, const double* weights, int n, double* cum, int* idx) {
+  double* z = cum + n;
+  if (scheme == 2)
+    for (int j = threadIdx.x; j <= n; j += SMC_THREADS) z[j] = -log(uniform01(key, (uint32_t)j, (uint32_t)(n + 1)));      // :149
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double c = 0.0;
+    for (int i = 0; i < n; ++i) { c += weights[i]; cum[i] = c; }
+    if (scheme == 2) { double zz = 0.0; for (int j = 0; j <= n; ++j) { zz += z[j]; z[j] = zz; } }                         // :150
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += SMC_THREADS) {
+    const double v = scheme == 2 ? z[j] / z[n]                                                          // :151
+                                 : ((double)j + uniform01(key, (uint32_t)j, (uint32_t)n)) / (double)n;  // :131-133
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cum[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    idx[j] = lo < n - 1 ? lo : n - 1;
+  }
+}
+
 // jax.random.choice(key, n, (m,), replace=True, p = exp(logw - max logw)) -- the self-normalised importance resampling of the
 // final flow samples (exe_flow_matching.py:458-459).  jax: p_cuml = cumsum(p); r = p_cuml[-1] * (1 - uniform(key, (m,)));
 // searchsorted(p_cuml, r) (side = 'left').  Sequential cumulative sum for the same reason as above.

@@ -128,3 +128,26 @@ def dirichlet(key, alpha):
     ls = np.array([_gamma_one_log(keys[i], alpha[i]) for i in range(alpha.shape[0])])
     w = np.exp(ls - ls.max())
     return w / w.sum()
+
+
+def random_bits32(key, size):
+    """``jax._src.prng.threefry_random_bits`` for 32-bit words: ``threefry_2x32(key, iota(size))`` (odd sizes padded)."""
+    odd = size % 2
+    cnt = np.arange(size + odd, dtype=np.uint32)
+    if odd:
+        cnt[-1] = 0
+    half = (size + odd) // 2
+    y0, y1 = _threefry(np.uint32(key[0]), np.uint32(key[1]), cnt[:half], cnt[half:])
+    out = np.concatenate([y0, y1])
+    return out[:-1] if odd else out
+
+
+def permutation_indices(key, n):
+    """Indices p with ``jax.random.permutation(key, x) == x[p]`` (jax 0.4.26 ``_shuffle``: rounds of a STABLE sort by fresh 32-bit
+    keys, ``ceil(3 ln n / ln(2^32 - 1))`` of them)."""
+    p = np.arange(n)
+    rounds = int(np.ceil(3 * np.log(max(1, n)) / np.log(np.iinfo(np.uint32).max)))
+    for _ in range(rounds):
+        key, sub = split(key)
+        p = p[np.argsort(random_bits32(sub, n), kind="stable")]
+    return p

@@ -61,6 +61,47 @@ def systematic(key, weights, num_samples):
     return np.clip(idx, 0, n - 1)
 
 
+def stratified(key, weights, num_samples):
+    n = weights.shape[0]
+    u = prng.uniform(key, (num_samples,))                                                # resampling.py:131
+    cumsum = np.cumsum(weights)
+    linspace = (np.arange(num_samples, dtype=weights.dtype) + u) / num_samples
+    return np.clip(np.searchsorted(cumsum, linspace), 0, n - 1)
+
+
+def _sorted_uniforms(key, n):
+    us = prng.uniform(key, (n + 1,))                                                     # :149
+    z = np.cumsum(-np.log(us))
+    return z[:-1] / z[-1]
+
+
+def multinomial(key, weights, num_samples):
+    n = weights.shape[0]
+    linspace = _sorted_uniforms(key, num_samples)                                        # :76
+    return np.clip(np.searchsorted(np.cumsum(weights), linspace), 0, n - 1)
+
+
+def permutation(key, x):
+    """jax.random.permutation of a 1-d array (jax 0.4.26 ``_shuffle``: stable sorts by fresh 32-bit keys)."""
+    rounds = int(np.ceil(3 * np.log(max(1, x.size)) / np.log(np.iinfo(np.uint32).max)))
+    for _ in range(rounds):
+        key, sub = prng.split(key)
+        x = x[np.argsort(prng.random_bits32(sub, x.size), kind="stable")]
+    return x
+
+
+def residual(key, weights, num_samples):
+    key1, key2 = prng.split(key)                                                         # :96
+    n = weights.shape[0]
+    nw = num_samples * weights
+    integer_part = np.floor(nw).astype(np.int32)
+    sum_int = int(integer_part.sum())
+    residual_sample = multinomial(key1, (nw - integer_part) / (num_samples - sum_int), num_samples)
+    residual_sample = permutation(key2, residual_sample)                                 # :114
+    integer_idx = np.repeat(np.arange(n + 1), np.concatenate([integer_part, [num_samples - sum_int]]))[:num_samples]
+    return np.where(np.arange(num_samples) >= sum_int, residual_sample, integer_idx)     # :122
+
+
 def init(particles):
     n = particles.shape[0]
     return dict(particles=particles, weights=np.ones(n) / n, lmbda=0.0)                 # tempered.py:45-50

@@ -33,6 +33,14 @@ def test_smc_pieces_match_oracle():
     idx = torch.empty(256, dtype=torch.int32, device="cuda"); scr = torch.empty(256, dtype=torch.float64, device="cuda")
     ctx.smc_resample(key, _dev(wn), scr, idx)
     np.testing.assert_array_equal(idx.cpu().numpy(), smc.systematic(key, wn, 256))       # integer output: bit-exact
+    # the other schemes of resampling.py (stratified, multinomial: one kernel; residual: composed on the host from the multinomial one)
+    from mfm_amd.bblackjax.smc import base as smc_base, resampling as R
+    from types import SimpleNamespace
+    smc_base._ENGINE[0] = SimpleNamespace(ctx=ctx)
+    for name in ("stratified", "multinomial", "residual", "systematic"):
+        got = getattr(R, name)(key, _dev(wn), 256).cpu().numpy()
+        np.testing.assert_array_equal(got, getattr(smc, name)(key, wn, 256), err_msg=name)
+    smc_base._ENGINE[0] = None
     src = _dev(rng.standard_normal((256, 64)).astype(np.float32)); dst = torch.empty_like(src)
     ctx.gather_rows(src, idx, dst)
     np.testing.assert_array_equal(dst.cpu().numpy(), src.cpu().numpy()[idx.cpu().numpy()])

@@ -60,3 +60,32 @@ def test_smc_run_tempers_towards_one_and_is_deterministic():
     assert a["samples"].shape == (2 * 128, 2)
     w = a["state"]["weights"]
     assert abs(w.sum() - 1.0) < 1e-12
+
+
+def test_the_other_resampling_schemes_are_resampling_schemes():
+    """stratified / multinomial / residual (resampling.py:55-121) restated: indices are in range and sorted where the scheme
+    sorts them, every particle's expected count is N w (checked over many keys), residual repeats each particle at least
+    floor(N w) times, and jax.random.permutation's restatement is a permutation that a second call with the same key repeats."""
+    from oracle import smc
+    rng = np.random.default_rng(5)
+    n = 64
+    w = rng.random(n) ** 3
+    w /= w.sum()
+    counts = {k: np.zeros(n) for k in ("stratified", "multinomial", "residual")}
+    reps = 300
+    for r in range(reps):
+        key = prng.PRNGKey(1000 + r)
+        for name in counts:
+            idx = getattr(smc, name)(key, w, n)
+            assert idx.shape == (n,) and idx.min() >= 0 and idx.max() < n
+            if name != "residual":
+                assert (np.diff(idx) >= 0).all()                      # searchsorted of an increasing sequence
+            else:
+                assert (np.bincount(idx, minlength=n) >= np.floor(n * w)).all()
+            counts[name] += np.bincount(idx, minlength=n)
+    for name, c in counts.items():
+        err = np.abs(c / reps - n * w)
+        assert err.max() < 4 * np.sqrt(n * w.max() / reps) + 0.05, (name, err.max())
+    p = smc.permutation(prng.PRNGKey(3), np.arange(1000))
+    assert sorted(p.tolist()) == list(range(1000)) and (p != np.arange(1000)).sum() > 900
+    np.testing.assert_array_equal(p, smc.permutation(prng.PRNGKey(3), np.arange(1000)))
