@@ -53,6 +53,7 @@ struct NoiseWs {
   std::vector<Key2> gn, st;                     // keys of the slots
   int n_armed = 0;                              // slots the NEXT flow step will fill
   int n_valid = 0, cur_gn = 0, cur_st = 0;      // slots filled by the last flow step, consumption cursors
+  bool no_mala0 = false;                        // slot 0 was keyed by the flow step that filled it: its MALA draws were not produced
 };
 
 // slots of mfm_get_counters
@@ -502,7 +503,7 @@ static int noise_take(mfm_ctx* x, Key2 key, bool step) {
   int& cur = step ? w->cur_st : w->cur_gn;
   const std::vector<Key2>& ks = step ? w->st : w->gn;
   for (int j = cur; j < w->n_valid; ++j)
-    if (ks[j].k0 == key.k0 && ks[j].k1 == key.k1) { cur = j + 1; return j; }      // same stream as the producer: ordered
+    if (ks[j].k0 == key.k0 && ks[j].k1 == key.k1 && !(!step && j == 0 && w->no_mala0)) { cur = j + 1; return j; }      // same stream as the producer: ordered
   return -1;
 }
 
@@ -941,6 +942,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
       nz.n_total = (uint32_t)x->cfg.n_chain_total; nz.chain_offset = (uint32_t)x->cfg.chain_offset; nz.B = B; nz.d = x->cfg.dim;
       nz.mala_n = w->mala_n; nz.mala_u = w->mala_u; nz.fm_x0 = w->fm_x0; nz.fm_eps = w->fm_eps; nz.fm_t = w->fm_t;
       nz.counter = w->counter; nz.groups = (B + 7) / 8; nz.n_items = nz.groups * w->n_armed;
+      nz.skip_mala0 = w->gn[0].k0 == k0 && w->gn[0].k1 == k1; w->no_mala0 = nz.skip_mala0 != 0;      // (slot 0 = this flow iteration's own keys: its MALA draws are never used)
       HIPCHK(hipMemsetAsync(w->counter, 0, sizeof(int), x->stream));
       w->n_valid = w->n_armed; w->cur_gn = w->cur_st = 0;
     }

@@ -17,13 +17,15 @@ struct NoiseArgs {
   double* mala_n; double* mala_u;             // [slot][B][d], [slot][B]
   double* fm_x0; double* fm_eps; float* fm_t; // [slot][B][d] x 2, [slot][B]
   int* counter; int n_items, groups;          // work items of 8 chains (one wavefront each): item = slot * groups + group
+  int skip_mala0;                             // slot 0 is keyed by the flow step that produces it (its own iteration's training batch): nobody
+                                              // will ask for that key's MALA draws
 };
 
 // all draws of chain row b in slot `slot`, by one wavefront
 __device__ __forceinline__ void noise_row(const NoiseArgs& a, int slot, int b, int lane) {
   const uint32_t bg = a.chain_offset + (uint32_t)b, d = (uint32_t)a.d;
   const size_t row = ((size_t)slot * a.B + b) * a.d, one = (size_t)slot * a.B + b;
-  {
+  if (!(a.skip_mala0 && slot == 0)) {
     const Key2 kg{a.gn[2 * slot], a.gn[2 * slot + 1]};
     const Key2 kb = split_at(kg, a.n_total, bg);                                  // exe_flow_matching.py:303
     const Key2 k_int = split_at(kb, 2, 0), k_rmh = split_at(kb, 2, 1);            // mala.py:93
