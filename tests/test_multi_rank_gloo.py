@@ -10,15 +10,15 @@ import torch.distributed as td
 import torch.multiprocessing as mp
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, n_total):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     td.init_process_group("gloo", rank=rank, world_size=world)
     from mfm_amd import engine
     from oracle import flow, fm, loop, mala, prng, targets
     from oracle.vfield import VectorFieldNet
     from tests import gpu_util as gu
-    n_total, d = 64, 16
-    n_local, off, _ = engine.shard(n_total, rank, world)
+    d = 16
+    _, off, n_local = engine.shard(n_total, rank, world)      # rows on the GPU (a multiple of 16), first global id, CHAINS of this rank
     dist = targets.PhiFour(d)
     x = dist.initialize_model(prng.PRNGKey(3), n_total, start=off, count=n_local)
     model = VectorFieldNet(prng.normal(prng.PRNGKey(4), (8,)), dist, [16, 16], [16, 16], [16, 16])
@@ -67,15 +67,19 @@ def _worker(rank, world, port, out):
     td.destroy_process_group()
 
 
-def test_two_ranks_match_single_process(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("n_total", [64, 40])      # 40: 20 chains per rank, shards padded to 32 rows on the GPU (engine.shard)
+def test_two_ranks_match_single_process(tmp_path, n_total):
     out = str(tmp_path / "r0.npz")
-    port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() + n_total) % 2000
+    mp.spawn(_worker, args=(2, port, out, n_total), nprocs=2, join=True)
     z = np.load(out)
     from oracle import flow, fm, mala, prng, targets
     from oracle.vfield import VectorFieldNet
     from tests import gpu_util as gu
-    n_total, d = 64, 16
+    d = 16
     dist = targets.PhiFour(d)
     x = dist.initialize_model(prng.PRNGKey(3), n_total)
     model = VectorFieldNet(prng.normal(prng.PRNGKey(4), (8,)), dist, [16, 16], [16, 16], [16, 16])
@@ -83,7 +87,7 @@ def test_two_ranks_match_single_process(tmp_path):
     key = prng.PRNGKey(5)
     vg = targets.Tempered(dist, 1.0).value_and_grad
     st, info, _ = mala.kernel(prng.split(key, n_total), mala.init(x, vg), vg, 1e-3)
-    np.testing.assert_array_equal(z["pos"], st.position[:32])                # rank 0's chains == chains 0..31
+    np.testing.assert_array_equal(z["pos"], st.position[:n_total // 2])      # rank 0's chains == the first half
     loss, grads = fm.loss_and_grad(model, params, key, st.position, 1e-4)
     np.testing.assert_allclose(z["l"][0], loss, rtol=1e-12)
     gf = gu.flat_params(grads).astype(np.float64)              # float32 gradients summed over two shards
