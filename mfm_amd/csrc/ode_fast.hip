@@ -177,54 +177,6 @@ __device__ __forceinline__ void run_job(const float* arow, __amdgpu_buffer_rsrc_
 // M-rows, and the four g-groups are summed at the end of the job (gsum).  Same weights, same LDS images, a quarter of the
 // matrix-pipe time per k-block.  M-rows: values of ranks 0, 1, then their tangent rows.
 __device__ __forceinline__ f32x4 mfma1(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
-template <int NTL, int LDA>
-__device__ __forceinline__ void exec_group_m(const float* arow, const f32x4 (&bf)[4], f32x4 (&acc)[NTL][4]) {
-  constexpr int KPG = 4 / NTL;
-  f32x4 a[KPG];
-#pragma unroll
-  for (int u = 0; u < KPG; ++u) a[u] = *reinterpret_cast<const f32x4*>(arow + u * 16);
-#pragma unroll
-  for (int u = 0; u < KPG; ++u)
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int t = 0; t < NTL; ++t) acc[t][s] = mfma1(a[u][s], bf[u * NTL + t][s], acc[t][s]);      // four independent chains per tile
-}
-template <int NTL, int KB, int LDA, int T1OFF, int NTLN, int T1OFFN>
-__device__ __forceinline__ void run_job_m(const float* arow, __amdgpu_buffer_rsrc_t wr, int w, int wnext, int lane,
-                                          f32x4 (&P)[4], f32x4 (&Q)[4], f32x4 (&acc)[NTL][4]) {
-#ifdef MICRO_DEBUG_16      // development probe: the same job through the 16 x 16 x 4 path, rows 0..3 broadcast from the g = 0 lanes
-  {
-    const float* a16 = arow + ((lane & 12) * LDA) - 4 * (lane >> 4) + 4 * (lane >> 4);      // row (lane & 15) of the 16-row image
-    f32x4 a2[NTL][1];
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) a2[t][0] = f32x4{0, 0, 0, 0};
-    run_job<1, NTL, KB, LDA, T1OFF, NTLN, T1OFFN>(a16, wr, w, wnext, lane, P, Q, a2);
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][0][r] = 0.25f * __shfl(a2[t][0][r], lane & 15, 64);     // gsum adds the four copies
-      acc[t][1] = acc[t][2] = acc[t][3] = f32x4{0, 0, 0, 0};
-    }
-    return;
-  }
-#endif
-  constexpr int KPG = 4 / NTL, G = KB / KPG;
-  static_assert(G % 2 == 0, "even number of fragment groups per job");
-#pragma unroll
-  for (int gi = 0; gi < G; gi += 2) {
-    load_group<NTL, T1OFF>(Q, wr, w + (gi + 1) * KPG * 1024, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    exec_group_m<NTL, LDA>(arow + gi * KPG * 16, P, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    if (gi + 2 < G) load_group<NTL, T1OFF>(P, wr, w + (gi + 2) * KPG * 1024, lane);
-    else load_group<NTLN, T1OFFN>(P, wr, wnext, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    exec_group_m<NTL, LDA>(arow + (gi + 1) * KPG * 16, Q, acc);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
 __device__ static const float C5[5] = {1.f / 5, 3.f / 10, 4.f / 5, 8.f / 9, 1.f};     // stage times of DP_TAB rows 2..6
 
 // Row-state fields beyond ode.hip's RS_* (0..15), used by the flow step's per-row solve phases (solve2): every chain of a
@@ -545,9 +497,6 @@ struct FTile {
         for (int i = 0; i < 4; ++i) tt_elem(q, i);
       }
     };
-#ifndef MFM_X1_RING
-#define MFM_X1_RING 0
-#endif
 #ifndef MFM_TT_MODE
 #define MFM_TT_MODE 3        // 0: waves 0-3 before their x1 job, waves 4-7 after theirs (stagger); 1: every wave before; 2: every wave after
                              // (same-trajectory A/B, tools/flow_ab.py, round 2: 52.75 / 52.95 / 53.03 ms: none of them overlaps anything --
@@ -610,14 +559,8 @@ struct FTile {
         for (int gi = 0; gi < G; ++gi) {
           f32x4 (&B)[4] = (gi & 1) ? Q : P;
           f32x4 (&N)[4] = (gi & 1) ? P : Q;
-#if MFM_X1_RING
-          // fragment ring: the slot of fragment f is refilled with fragment f + 8 as soon as its MFMAs are issued (twice the
-          // distance of the group ping-pong with the same eight fragment registers)
-          if (gi == 0) load_group<1, 0>(N, wr, w0 + 4 * 1024, lane);
-#else
           if (gi + 1 < G) load_group<1, 0>(N, wr, w0 + (gi + 1) * 4 * 1024, lane);
           else load_group<1, 0>(N, wr, wnx, lane);
-#endif
           __builtin_amdgcn_sched_barrier(0);
           f32x4 an = *reinterpret_cast<const f32x4*>(arow + gi * 64);
 #pragma unroll
@@ -635,13 +578,6 @@ struct FTile {
               if (slot == 7) piece(gi, 2, ox[gi & 1]);
               if (slot == 9) piece(gi, 3, ox[gi & 1]);
               if (slot == 12) piece(gi, 4, ox[gi & 1]);
-#if MFM_X1_RING
-              if (s4 == 3) {
-                const int fn = gi * 4 + u + 8;                          // fragment that takes this slot
-                if (fn < 4 * G) { B[u] = bload(wr, lane * 16, w0 + fn * 1024); asm volatile("" ::: "memory"); }
-                else if (fn < 4 * G + 4) { B[u] = bload(wr, lane * 16, wnx + (fn - 4 * G) * 1024); asm volatile("" ::: "memory"); }
-              }
-#endif
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -885,106 +821,8 @@ struct FTile {
     return v;
   }
 
-  // ---- MICRO field evaluation: at most 2 rows of the tile still integrate (run_job_m) ---------------------------------------
-  // Same data flow as eval_c on a 4-row image: X[cur] rows 0, 1 = stage inputs of ranks 0, 1, rows 2, 3 = their probes; every
-  // layer buffer rows 0, 1 = values, rows 2, 3 = tangents.  After gsum every lane holds all four M-rows of its column; lane
-  // group g finishes M-row g (g < 2: value of rank g; g >= 2: tangent of rank g - 2, masked by the value's pre-activation it
-  // holds itself -- no cross-lane exchange).  Time-branch inputs come from the single-tile time batch (rps = 3).
-  __device__ __forceinline__ void eval_m(int slot, int cur, int dst, bool next_is_tbatch, f32x4 (&P)[4], f32x4 (&Q)[4], float (&kv)[TPW][4],
-                                         const f32x4 sg, const f32x4 rk) {
-    const int xsel = cur ? S::XB1 * 4 : S::XB0 * 4, xoth = cur ? S::XB0 * 4 : S::XB1 * 4;
-    const int rank = g & 1;
-    const bool is_t = g >= 2;
-    const int am = c & 12;                            // the 16 x 16 path reads A row (lane & 15); this one row (c & 3)
-    const int a_x = o_xa + xsel - am * LDX * 4, a_h = o_ha - am * LDH * 4, a_h2 = o_ha2 - am * LDH * 4;
-    const int e_h = o_he - 3 * g * LDH * 4, e_h2 = o_he2 - 3 * g * LDH * 4;      // epilogue row g instead of rows 4 g + i
-    float gt[TPW];
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) gt[q] = tgather(slot, rank, 3, q);
-    const float j1t = tgather(slot, rank, 3, 2);
-    float gc[TPW], hz[TPW], zz[TPW];
-    auto target_terms = [&]() {
-      const float icoef = 1.f / coef;
-#pragma unroll
-      for (int q = 0; q < TPW; ++q) {
-        const float* xr = at(o_xc + xsel, rank * LDX + 128 * q);
-        const float* zr = xr + 2 * LDX;
-        const float x = xr[0], z = zr[0];
-        const float graw = -tbeta * (coef * (2.f * x - xr[-1] - xr[1]) - x * (1.f - x * x) * icoef);
-        const float hv = -tbeta * (coef * (2.f * z - zr[-1] - zr[1]) - (1.f - 3.f * x * x) * z * icoef);
-        gc[q] = clip > 0.f ? fminf(fmaxf(graw, -clip), clip) : graw;
-        hz[q] = (!(clip > 0.f) || fabsf(graw) <= clip) ? hv : 0.f;
-        zz[q] = z;
-      }
-    };
-    // finish one layer: M-row g of this lane's column -> the next layer's A image
-    auto act_store = [&](f32x4 (&acc)[1][4], float add, float* dstp) {
-      const f32x4 pre = gsum((acc[0][0] + acc[0][1]) + (acc[0][2] + acc[0][3]));
-      const float pv = (rank ? pre[1] : pre[0]) + add, pt = rank ? pre[3] : pre[2];
-      *dstp = is_t ? (pv > 0.f ? pt : 0.f) : fmaxf(pv, 0.f);
-    };
-    auto zero = [&](f32x4 (&acc)[1][4]) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc[0][s] = f32x4{0, 0, 0, 0};
-    };
-    if (wave < NW / 2) target_terms();
-    {   // x1 on [values ; probes]
-      f32x4 acc[1][4]; zero(acc);
-      run_job_m<1, D / 16, LDX, 0, 1, 0>(at(a_x, 0), wr, W(S::W2, wave, D / 16), W(S::W3, wave, 8), lane, P, Q, acc);
-      if (wave >= NW / 2) target_terms();
-      act_store(acc, bias(S::B2), at(e_h, 0));
-    }
-    __syncthreads();
-    {   // x2
-      f32x4 acc[1][4]; zero(acc);
-      run_job_m<1, 8, LDH, 0, 1, 0>(at(a_h, 0), wr, W(S::W3, wave, 8), W(S::W5, wave, 16, 0), lane, P, Q, acc);
-      act_store(acc, bias(S::B3), at(e_h, 32 * LDH));
-    }
-    __syncthreads();
-    {   // j1: the st half + bias of the value rows arrive from the time batch
-      f32x4 acc[1][4]; zero(acc);
-      run_job_m<1, 8, LDH, 0, 1, 0>(at(a_h, 32 * LDH), wr, W(S::W5, wave, 16, 0), W(S::W6, wave, 8), lane, P, Q, acc);
-      act_store(acc, j1t, at(e_h2, 0));
-    }
-    __syncthreads();
-    {   // j2
-      f32x4 acc[1][4]; zero(acc);
-      run_job_m<1, 8, LDH, 0, TPW, OUT_T1OFF>(at(a_h2, 0), wr, W(S::W6, wave, 8), W(S::W7, wave, 8), lane, P, Q, acc);
-      act_store(acc, bias(S::B6), at(e_h2, 32 * LDH));
-    }
-    __syncthreads();
-    {   // out
-      f32x4 acc[TPW][4];
-#pragma unroll
-      for (int q = 0; q < TPW; ++q)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[q][s] = f32x4{0, 0, 0, 0};
-      const int wnext = next_is_tbatch ? W(S::W0, wave, 16) : W(S::W2, wave, D / 16);
-      run_job_m<TPW, 8, LDH, OUT_T1OFF, 1, 0>(at(a_h2, 32 * LDH), wr, W(S::W7, wave, 8), wnext, lane, P, Q, acc);
-      float dpv = 0.f;
-#pragma unroll
-      for (int q = 0; q < TPW; ++q) {
-        const f32x4 pre = gsum((acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]));
-        const float pv = rank ? pre[1] : pre[0], pt = rank ? pre[3] : pre[2];
-        if (is_t) dpv += zz[q] * (pt + gt[q] * hz[q]);                                                  // z . J z of rank
-        else *at(o_xc + xoth, rank * LDX + 128 * q) = pv + bias(S::B7 + 128 * q) + gt[q] * gc[q];      // v of rank
-      }
-      dpv = group16_sum_dpp(dpv);
-      if (is_t && c == 0) *at((64 + wave) * 4, S::DLP + dst * 128 + rank * 8) = dpv;      // M-row 8 + rank of the partial sums (as eval_c)
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int q = 0; q < TPW; ++q)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = rk[i] >= 0.f ? *at(o_xc + xoth, (int)rk[i] * LDX + 128 * q) : 0.f;
-        kv[q][i] = sg[i] > 0.f ? v : -v;
-      }
-  }
 };
 
-// (eval_m is a member of FTile: see above)
 // Integrate the augmented ODE from t = 0 to 1 (see ode_solve in ode.hip: same state machine, same controller).
 // Requires: Z filled (probe), halo pads of X0 / X1 / Z zero, biases in LDS.
 // RP: the parity-instrumentation instance (Replay, ode.hip); the production instance (RP = false) carries none of it.
@@ -1394,7 +1232,7 @@ __device__ __forceinline__ int leaders_end_of_attempt(FTile<D>& T, const AA& a, 
 //     two-pass accumulation, no sine stash), its results (gate, st contribution to j1) in LDS, read back by plain ds_read;
 //     three barriers instead of six; sincos only for the pairs that exist (<= 3 per lane instead of 20).
 // Arithmetic: per-row controller, interpolation and step sizes are those of the main loop bit for bit (leaders_end_of_attempt); the
-// evaluation is eval_m's (4 x 4 x 1 MFMA, k-sum per 16-lane group then over the groups), the time batch sums K = 256 in the even /
+// evaluation runs on the 4 x 4 x 1 MFMA (k-sum per 16-lane group, then over the groups), the time batch sums K = 256 in the even /
 // odd k-block order of the single-tile batch, now over both halves at once (a float reassociation of the first time layer).
 template <int D, int P>
 struct TailMap {
@@ -1403,7 +1241,7 @@ struct TailMap {
   static constexpr int MT = (10 * P + 15) / 16;               // M tiles of the time batch: M-row NS * stage + slot
   static constexpr int LDF = 2 * F + 8;                       // Fourier image [16 MT][cos 128 | sin 128]
   static constexpr int LDT = D + H + 8;                       // time-batch results [10 P][gate D | j1t H]
-  static constexpr int IMG = 4 * P * S::LDH;                  // one image of the x branch: pass p owns rows 4 p .. 4 p + 3 (as eval_m)
+  static constexpr int IMG = 4 * P * S::LDH;                  // one image of the x branch: pass p owns rows 4 p .. 4 p + 3
   // area U (dead once the batch is done, then the four x-branch images): the Fourier image, later t1 | st side by side
   static constexpr int USZ = (16 * MT * LDF > 2 * 16 * MT * S::LDH ? 16 * MT * LDF : 2 * 16 * MT * S::LDH) > 4 * IMG
                            ? (16 * MT * LDF > 2 * 16 * MT * S::LDH ? 16 * MT * LDF : 2 * 16 * MT * S::LDH) : 4 * IMG;
