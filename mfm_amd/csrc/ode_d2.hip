@@ -263,7 +263,11 @@ struct TileR {
   float* lds;
   int lane, wave, g, c, sign, par;
   float w1[2], b1x, b3, b5, b6, b7[2], b4[2];
-  f32x4 W3f[8], W5f[8], W6f[8], W7f;
+  f32x4 W3f[8], W5f[8], W6f[8];
+  float w7c[2];                // W_out[col][0..1] at this lane's column of the last hidden layer (D2_OUT_MFMA: its k-block as an MFMA fragment instead)
+#ifdef D2_OUT_MFMA
+  f32x4 W7f;
+#endif
 
   __device__ __forceinline__ void init(const NetDev* net, float* l) {
     n = net; L = layout_r(); lds = l; par = 0;
@@ -285,7 +289,12 @@ struct TileR {
       W5f[kb] = P5[(wave * 16 + kb) * 64 + lane];          // rows 0..127 of the [sx | st] input: the x half
       W6f[kb] = P6[(wave * 8 + kb) * 64 + lane];
     }
+#ifdef D2_OUT_MFMA
     W7f = P7[wave * 64 + lane];
+#else
+    (void)P7;
+#endif
+    w7c[0] = N.Wp[N.L[7].w_off + pack_index(col, 0, N.L[7].Kp / 16)]; w7c[1] = N.Wp[N.L[7].w_off + pack_index(col, 1, N.L[7].Kp / 16)];
     __syncthreads();
   }
 
@@ -418,6 +427,7 @@ struct TileR {
     __syncthreads();
     hidden(lds + L.cat, W5f, f32x4{lds[L.ct + (4 * slot + g) * 128 + col], 0.f, 0.f, 0.f}, 0.f, lds + L.j1);
     __syncthreads();
+#ifdef D2_OUT_MFMA
     hidden(lds + L.j1, W6f, zero, b6, lds + L.j2);
     __syncthreads();
     {
@@ -430,6 +440,28 @@ struct TileR {
       if (c == 1) { p[1] = acc[0]; p[3] = acc[2]; }
     }
     __syncthreads();
+#else
+    {
+      // Round 4: the out layer (hj2 -> 2) rides in the LAST hidden layer's epilogue.  Each lane holds value / e1-tangent / e2-tangent
+      // of chain g at ONE column of j2: its share of out_0, out_1, d out_0 / d e1, d out_1 / d e2 is a product with W_out[col][.],
+      // the wave's 16 columns are summed over the 16 lanes of the group (DPP row sums), the eight waves through LDS as before.
+      // One barrier and one matrix phase less per evaluation (a float reassociation of the out layer's k-sum).
+      const float* arow = lds + L.j1 + c * R_LD + 4 * g;
+      f32x4 acc = zero;
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + kb * 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], W6f[kb][s], acc, 0, 0, 0);
+      }
+      const float pre = acc[0] + b6;
+      const float v = act_f(pre, act()), t1v = mask_pre(pre, acc[1], act()), t2v = mask_pre(pre, acc[2], act());
+      const float s0 = group16_sum_dpp(v * w7c[0]), s1 = group16_sum_dpp(v * w7c[1]);
+      const float s2 = group16_sum_dpp(t1v * w7c[0]), s3 = group16_sum_dpp(t2v * w7c[1]);
+      if (c == 0) *reinterpret_cast<f32x4*>(lds + L.part + (g * NW + wave) * 4) = f32x4{s0, s1, s2, s3};
+    }
+    __syncthreads();
+#endif
     float o0 = 0.f, o1 = 0.f, j11 = 0.f, j22 = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
