@@ -179,6 +179,32 @@ __device__ __forceinline__ void run_job(const float* arow, __amdgpu_buffer_rsrc_
 __device__ __forceinline__ f32x4 mfma1(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 __device__ static const float C5[5] = {1.f / 5, 3.f / 10, 4.f / 5, 8.f / 9, 1.f};     // stage times of DP_TAB rows 2..6
 
+// sin(pi x), cos(pi x) for |x| <= 1 (the Fourier features' argument is reduced to half a turn in float64 before it gets here):
+// x = k / 2 + r with |r| <= 1 / 4, degree-9 / degree-10 Taylor polynomials in r (truncation < 2e-9), quadrant by k.  Max error
+// 9e-8 on [-1, 1] (0.75 ulp of 1: as the library's sincospif, which carries the general range reduction and special cases).
+#ifndef MFM_LIB_SINCOSPI
+__device__ __forceinline__ void sincospi_half_turn(float x, float* sn, float* cs) {
+  const float k = rintf(2.f * x);
+  const float r = __builtin_fmaf(-0.5f, k, x), r2 = r * r;
+  float sp = 0.08214588661112823f;                                  // pi^9 / 9!
+  sp = __builtin_fmaf(sp, r2, -0.5992645293207921f);                // -pi^7 / 7!
+  sp = __builtin_fmaf(sp, r2, 2.5501640398773455f);                 // pi^5 / 5!
+  sp = __builtin_fmaf(sp, r2, -5.16771278004997f);                  // -pi^3 / 3!
+  sp = __builtin_fmaf(sp, r2, 3.141592653589793f) * r;
+  float cp = -0.02580689139001406f;                                 // -pi^10 / 10!
+  cp = __builtin_fmaf(cp, r2, 0.23533063035889312f);                // pi^8 / 8!
+  cp = __builtin_fmaf(cp, r2, -1.3352627688545893f);                // -pi^6 / 6!
+  cp = __builtin_fmaf(cp, r2, 4.058712126416768f);                  // pi^4 / 4!
+  cp = __builtin_fmaf(cp, r2, -4.934802200544679f);                 // -pi^2 / 2!
+  cp = __builtin_fmaf(cp, r2, 1.f);
+  const int q = (int)k & 3;
+  *sn = q == 0 ? sp : (q == 1 ? cp : (q == 2 ? -sp : -cp));
+  *cs = q == 0 ? cp : (q == 1 ? -sp : (q == 2 ? -cp : sp));
+}
+#else
+__device__ __forceinline__ void sincospi_half_turn(float x, float* sn, float* cs) { sincospif(x, sn, cs); }
+#endif
+
 // Row-state fields beyond ode.hip's RS_* (0..15), used by the flow step's per-row solve phases (solve2): every chain of a
 // tile runs its OWN sequence inverse solve -> proposal -> forward solve; the tile only shares the attempt clock.
 enum { RS_MODE = 16, RS_SOLVE = 17, RS_SIGN = 18, RS_VOL0 = 19, RS_NTOT = 20, RS_LQ = 21, RS_SW = 22, RS_TILE = 23,
@@ -302,7 +328,7 @@ struct FTile {
         const double te = sg4[i] > 0.f ? (double)tt : 1.0 - (double)tt;          // :229
         double ft = f * te;
         ft -= rint(ft);
-        sincospif(2.f * (float)ft, &sv[s][i], &cv[s][i]);                      // :70-71
+        sincospi_half_turn(2.f * (float)ft, &sv[s][i], &cv[s][i]);             // :70-71
       }
     }
   }
@@ -1447,7 +1473,7 @@ __device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
                 double ft = fq * te;
                 ft -= rint(ft);
                 float sn, cs;
-                sincospif(2.f * (float)ft, &sn, &cs);                                // :70-71
+                sincospi_half_turn(2.f * (float)ft, &sn, &cs);                       // :70-71
                 lds[M::FH2 + m * LDF + colw] = cs; lds[M::FH2 + m * LDF + F + colw] = sn;
               }
             }
