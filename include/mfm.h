@@ -38,6 +38,7 @@ enum { MFM_FLOW_RWMH = 0, MFM_FLOW_IMH = 1 };                      /* exe_flow_m
 enum { MFM_FAMILY_AUTO = 0, MFM_FAMILY_TILE = 1, MFM_FAMILY_WIDE = 2 };
 enum { MFM_ACT_RELU = 0, MFM_ACT_TANH = 1, MFM_ACT_ELU = 2, MFM_ACT_GELU = 3, MFM_ACT_SWISH = 4 };   /* exe_flow_matching.py:39-45 */
 
+#define MFM_MAX_DEPTH 3
 typedef struct mfm_config {
   int32_t dim;                 /* args.dim */
   int32_t fourier_dim;         /* args.fourier_dim  (multi_modal.py:156) */
@@ -69,6 +70,12 @@ typedef struct mfm_config {
                                   16 chains, so the host pads its shard to n_chain_local (a multiple of 16) and names here how many of
                                   those rows are chains: rows >= n_chain_valid are integrated like any other but contribute nothing to
                                   the flow-matching loss and its gradient (exe_flow_matching.py:171-178) */
+  /* args.hidden_t / hidden_x / hidden_xt are lists of any length (multi_modal.py:178-180, nargs='+'; the loops at
+     exe_flow_matching.py:74-85).  depth_* = 0 reads the two widths above (a two-layer branch).  1 .. MFM_MAX_DEPTH: that many hidden
+     layers, widths hidden_*[0], hidden_*[1], then hidden_*3.  Anything but (2, 2, 2) runs on the wide family (one GEMM launch per
+     layer): MFM_FAMILY_TILE then fails with MFM_EUNSUPPORTED. */
+  int32_t depth_t, depth_x, depth_xt;
+  int32_t hidden_t3, hidden_x3, hidden_xt3;
 } mfm_config;
 
 const char* mfm_last_error(void);

@@ -32,7 +32,12 @@ class Config(C.Structure):
         ("weight_decay", C.c_double), ("update_clip", C.c_double),
         ("learning_iter", C.c_int32), ("warmup_steps", C.c_int32), ("max_eval_samples", C.c_int32),
         ("kernel_family", C.c_int32), ("activation", C.c_int32), ("ref_std", C.c_double), ("n_chain_valid", C.c_int32),
+        ("depth_t", C.c_int32), ("depth_x", C.c_int32), ("depth_xt", C.c_int32),
+        ("hidden_t3", C.c_int32), ("hidden_x3", C.c_int32), ("hidden_xt3", C.c_int32),
     ]
+
+
+MAX_DEPTH = 3          # include/mfm.h: MFM_MAX_DEPTH
 
 
 _P = C.c_void_p
@@ -155,8 +160,13 @@ class Context:
         defaults.update(kw)
         defaults.setdefault("n_chain_total", defaults["n_chain_local"])
         for k, v in defaults.items():
-            if k in ("hidden_t", "hidden_x", "hidden_xt"):
-                setattr(cfg, k, (C.c_int32 * 2)(*[int(h) for h in v]))
+            if k in ("hidden_t", "hidden_x", "hidden_xt"):      # lists of 1 .. MAX_DEPTH widths (exe_flow_matching.py:74-85)
+                hs = [int(h) for h in v]
+                if not 1 <= len(hs) <= MAX_DEPTH:
+                    raise MfmError(f"{k}: {len(hs)} hidden layers; the kernels take 1 to {MAX_DEPTH} per branch")
+                setattr(cfg, k, (C.c_int32 * 2)(*(hs + hs)[:2]))
+                setattr(cfg, "depth_" + k[7:], len(hs))
+                setattr(cfg, k + "3", hs[2] if len(hs) > 2 else 0)
             else:
                 setattr(cfg, k, v)
         self.cfg = cfg

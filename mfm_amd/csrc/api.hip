@@ -147,15 +147,35 @@ extern "C" int mfm_profile_read(mfm_ctx* x, double ms[8], int64_t counts[8]) {
   return MFM_OK;
 }
 
+// hidden widths of one branch as a list: depth 0 = the two-element array of the configuration (include/mfm.h)
+static int branch_widths(int depth, const int32_t two[2], int32_t third, int out[MLP_MAX_DEPTH]) {
+  const int n = depth == 0 ? 2 : depth;
+  for (int i = 0; i < MLP_MAX_DEPTH; ++i) out[i] = 0;
+  if (n < 1 || n > MLP_MAX_DEPTH) return -1;
+  for (int i = 0; i < n && i < 2; ++i) out[i] = two[i];
+  if (n > 2) out[2] = third;
+  return n;
+}
+
 static void build_net(const mfm_config& c, NetDev& n) {
   memset(&n, 0, sizeof n);
   n.d = c.dim; n.dp = ceil16(c.dim); n.F = c.fourier_dim; n.F2p = ceil16(2 * c.fourier_dim);
-  n.ht1 = c.hidden_t[0]; n.ht2 = c.hidden_t[1]; n.hx1 = c.hidden_x[0]; n.hx2 = c.hidden_x[1];
-  n.hj1 = c.hidden_xt[0]; n.hj2 = c.hidden_xt[1];
-  const int K[8] = {2 * c.fourier_dim, n.ht1, c.dim, n.hx1, n.ht2, n.hx2 + n.ht2, n.hj1, n.hj2};
-  const int N[8] = {n.ht1, n.ht2, n.hx1, n.hx2, c.dim, n.hj1, n.hj2, c.dim};
+  int ht[MLP_MAX_DEPTH], hx[MLP_MAX_DEPTH], hj[MLP_MAX_DEPTH];
+  n.nT = branch_widths(c.depth_t, c.hidden_t, c.hidden_t3, ht);
+  n.nX = branch_widths(c.depth_x, c.hidden_x, c.hidden_x3, hx);
+  n.nJ = branch_widths(c.depth_xt, c.hidden_xt, c.hidden_xt3, hj);
+  n.ht1 = ht[0]; n.ht2 = ht[n.nT - 1]; n.hx1 = hx[0]; n.hx2 = hx[n.nX - 1]; n.hj1 = hj[0]; n.hj2 = hj[n.nJ - 1];
+  // flax creation order (exe_flow_matching.py:74-86): time branch, x branch, gate, joint branch, output
+  int K[MLP_MAXL], N[MLP_MAXL], nl = 0, prev = 2 * c.fourier_dim;
+  for (int i = 0; i < n.nT; ++i) { K[nl] = prev; N[nl] = ht[i]; prev = ht[i]; ++nl; }
+  prev = c.dim;
+  for (int i = 0; i < n.nX; ++i) { K[nl] = prev; N[nl] = hx[i]; prev = hx[i]; ++nl; }
+  K[nl] = n.ht2; N[nl] = c.dim; ++nl;
+  prev = n.hx2 + n.ht2;
+  for (int i = 0; i < n.nJ; ++i) { K[nl] = prev; N[nl] = hj[i]; prev = hj[i]; ++nl; }
+  K[nl] = n.hj2; N[nl] = c.dim; ++nl;
   int wo = 0, bo = 0, mo = 0;
-  for (int l = 0; l < 8; ++l) {
+  for (int l = 0; l < nl; ++l) {
     LayerDesc& L = n.L[l];
     L.K = K[l]; L.N = N[l]; L.Kp = ceil16(K[l]); L.Np = ceil16(N[l]);
     L.w_off = wo; wo += L.Kp * L.Np;
@@ -163,6 +183,7 @@ static void build_net(const mfm_config& c, NetDev& n) {
     L.m_w = mo; mo += K[l] * N[l];
     L.m_b = mo; mo += N[l];
   }
+  for (int l = nl; l < MLP_MAXL; ++l) { n.L[l].m_w = n.L[l].m_b = mo; n.L[l].w_off = wo; n.L[l].b_off = bo; }      // never selected by a parameter index
   n.n_packed = wo; n.n_bias = bo; n.n_params = mo;
   n.grad_clip = c.grad_clip;
   n.act = c.activation;
@@ -195,9 +216,16 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
 
 static int create_impl(const mfm_config& c, mfm_ctx* x) {
   if (c.dim <= 0 || c.fourier_dim <= 0) return fail(MFM_EINVAL, "dim / fourier_dim must be positive");
-  const int hs[6] = {c.hidden_t[0], c.hidden_t[1], c.hidden_x[0], c.hidden_x[1], c.hidden_xt[0], c.hidden_xt[1]};
-  for (int h : hs)
-    if (h <= 0 || h % 16) return fail(MFM_EUNSUPPORTED, "hidden widths must be positive multiples of 16 (got %d)", h);
+  {
+    int hs[3][MLP_MAX_DEPTH];
+    const int nd[3] = {branch_widths(c.depth_t, c.hidden_t, c.hidden_t3, hs[0]), branch_widths(c.depth_x, c.hidden_x, c.hidden_x3, hs[1]),
+                       branch_widths(c.depth_xt, c.hidden_xt, c.hidden_xt3, hs[2])};
+    for (int b = 0; b < 3; ++b) {
+      if (nd[b] < 0) return fail(MFM_EUNSUPPORTED, "a branch has 1 to %d hidden layers (depth_t / depth_x / depth_xt = %d / %d / %d)", MLP_MAX_DEPTH, c.depth_t, c.depth_x, c.depth_xt);
+      for (int i = 0; i < nd[b]; ++i)
+        if (hs[b][i] <= 0 || hs[b][i] % 16) return fail(MFM_EUNSUPPORTED, "hidden widths must be positive multiples of 16 (got %d)", hs[b][i]);
+    }
+  }
   if (c.n_chain_local <= 0 || c.n_chain_local % 16)
     return fail(MFM_EUNSUPPORTED, "n_chain_local must be a positive multiple of 16 (got %d)", c.n_chain_local);
   const int n_valid = c.n_chain_valid > 0 ? c.n_chain_valid : c.n_chain_local;
@@ -226,7 +254,12 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
   if (x->cfg.ref_std == 0.0) x->cfg.ref_std = 1.0;           // zero-initialised config: the default 'stdgauss'
   if (!(x->cfg.ref_std > 0.0)) return fail(MFM_EINVAL, "ref_std must be positive");
   bool use_wide = c.kernel_family == MFM_FAMILY_WIDE;
-  {
+  const bool two_layer = n.nT == 2 && n.nX == 2 && n.nJ == 2;
+  if (!two_layer) {        // the fused tile kernels are written layer by layer for two hidden layers per branch; the wide family loops over them
+    if (c.kernel_family == MFM_FAMILY_TILE)
+      return fail(MFM_EUNSUPPORTED, "hidden lists of %d / %d / %d layers (t / x / xt) run on the wide kernel family only", n.nT, n.nX, n.nJ);
+    use_wide = true;
+  } else {
     const FmLds L = fm_lds_layout(n, true);
     size_t sm_ode; int tpw_ode;
     const bool fits = (size_t)L.total * 4 <= 160 * 1024 && (n.dp / 16 + MLP_WAVES_FM - 1) / MLP_WAVES_FM <= 2 && ode_check(n, sm_ode, tpw_ode) == 0;

@@ -5,6 +5,8 @@
 //   0 t1 (2F -> ht1)   1 t2 (ht1 -> ht2)   2 x1 (d -> hx1)   3 x2 (hx1 -> hx2)
 //   4 gate (ht2 -> d, zero-init)   5 j1 (hx2 + ht2 -> hj1)   6 j2 (hj1 -> hj2)   7 out (hj2 -> d, zero-init)
 //   v = out + gate * clip(grad log pi(x))
+// (hidden lists of another length -- :74-85 loop over them -- keep the order t.., x.., gate, joint.., out: NetDev::nT / nX / nJ;
+//  only the wide family, which launches one GEMM per layer, runs them)
 //
 // One workgroup = 8 wavefronts (2 per SIMD) owns a tile of 16 chains (one MFMA M-tile; 32 rows when value + tangent are pushed
 // together).  Activations of the tile stay in LDS between layers; weights are streamed L2 -> VGPR once per
@@ -22,7 +24,9 @@
 #include "common.cuh"
 #include "targets.cuh"
 
-#define MLP_NLAYER 8
+#define MLP_NLAYER 8              // layers of the network with TWO hidden layers per branch: what the fused tile kernels are written for
+#define MLP_MAX_DEPTH 3           // hidden layers per branch the wide family takes (exe_flow_matching.py:74-85 loops over lists of any length)
+#define MLP_MAXL (3 * MLP_MAX_DEPTH + 2)
 #define MLP_WAVES_FM 8            // waves per workgroup of the flow-matching kernels (2 per SIMD)
 #define MLP_ROWS 16
 
@@ -36,8 +40,9 @@ struct LayerDesc {
 
 struct NetDev {
   int d, dp, F, F2p;
-  int ht1, ht2, hx1, hx2, hj1, hj2;   // multiples of 16
-  LayerDesc L[MLP_NLAYER];
+  int ht1, ht2, hx1, hx2, hj1, hj2;   // multiples of 16: FIRST and LAST hidden width of the t / x / joint branch (the two widths of a two-layer branch)
+  LayerDesc L[MLP_MAXL];              // flax creation order: t[0..nT), x[0..nX), gate, joint[0..nJ), out; unused slots: K = N = 0, m_w = m_b = n_params
+  int nT, nX, nJ;                     // hidden layers per branch (2, 2, 2: the layer numbering above; anything else: wide family only)
   int n_params;          // canonical flat size
   int n_packed;          // floats in Wp (= in WpT)
   int n_bias;            // floats in bias

@@ -143,7 +143,7 @@ __device__ __forceinline__ void adamw_element_t(const AdamArgs& a, int p, bool a
   // locate (layer, kernel/bias, k, nn)
   int layer = 0;
 #pragma unroll
-  for (int l = 1; l < MLP_NLAYER; ++l) if (p >= n.L[l].m_w) layer = l;
+  for (int l = 1; l < MLP_MAXL; ++l) if (p >= n.L[l].m_w) layer = l;
   const LayerDesc& ld = n.L[layer];
   const bool is_bias = p >= ld.m_b;
   if (apply) {
@@ -246,7 +246,7 @@ void launch_reduce_adamw(const AdamArgs& a, OptState* st_next, float* out, const
 // (4 consecutive `in` at one `out`: one B fragment element run) and the transposed packing (4 consecutive `out` at one `in`)
 // are then all 128-bit accesses, where adamw_kernel scatters three 4-byte stores per parameter -- that matters for the
 // pines widths (8.65 M parameters, 34.6 MB per copy).  Biases are handled one element per thread after the blocks.
-struct AdamBlocks { int first[MLP_NLAYER + 1]; int n_blocks; int n_bias_items; };
+struct AdamBlocks { int first[MLP_MAXL + 1]; int n_blocks; int n_bias_items; };
 __global__ __launch_bounds__(256) void adamw_vec_kernel(AdamArgs a, AdamBlocks bl) {
   const NetDev& n = a.net;
   const AdamRaw raw = adam_load(a);                 // state reads issued here, first used after the operand loads below
@@ -260,13 +260,13 @@ __global__ __launch_bounds__(256) void adamw_vec_kernel(AdamArgs a, AdamBlocks b
       const float bc1 = (float)(1.0 - pow(a.b1, (double)c1)), bc2 = (float)(1.0 - pow(a.b2, (double)c1));
       const float lr = lr_schedule(a.lr0, a.learning_iter, a.warmup, count);
       int p = it - bl.n_blocks, layer = 0;
-      for (int l = 0; l < MLP_NLAYER; ++l) { if (p < n.L[l].N) { layer = l; break; } p -= n.L[l].N; }
+      for (int l = 0; l < MLP_MAXL; ++l) { if (p < n.L[l].N) { layer = l; break; } p -= n.L[l].N; }
       adamw_element(a, n.L[layer].m_b + p, apply, bc1, bc2, lr);
       continue;
     }
     int layer = 0;
 #pragma unroll
-    for (int l = 1; l < MLP_NLAYER; ++l) if (it >= bl.first[l]) layer = l;
+    for (int l = 1; l < MLP_MAXL; ++l) if (it >= bl.first[l]) layer = l;
     const LayerDesc& ld = n.L[layer];
     const int e = it - bl.first[layer], nb4 = ld.N >> 2, kb4 = e / nb4, k0 = 4 * kb4, n0 = 4 * (e - kb4 * nb4);
     // every operand is loaded unconditionally and up front: the loads then fly together with the optimizer-state reads the
@@ -328,11 +328,11 @@ void launch_adamw(const AdamArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(finite_decide_kernel, grid, block, 0, stream, a.grads, a.n_slabs, n, a.st, a.flag, a.lr0, a.learning_iter, a.warmup, a.max_err);
   bool vec = true;
   AdamBlocks bl; memset(&bl, 0, sizeof bl);
-  for (int l = 0; l < MLP_NLAYER; ++l) {
+  for (int l = 0; l < MLP_MAXL; ++l) {
     vec &= (a.net.L[l].K % 4 == 0) && (a.net.L[l].N % 4 == 0);
     bl.first[l] = bl.n_blocks; bl.n_blocks += (a.net.L[l].K / 4) * (a.net.L[l].N / 4); bl.n_bias_items += a.net.L[l].N;
   }
-  bl.first[MLP_NLAYER] = bl.n_blocks;
+  bl.first[MLP_MAXL] = bl.n_blocks;
   if (vec) {
     const int items = bl.n_blocks + bl.n_bias_items, nbv = (items + 255) / 256;
     hipLaunchKernelGGL(adamw_vec_kernel, dim3(nbv < cap ? nbv : cap), block, 0, stream, a, bl);
@@ -347,7 +347,7 @@ __global__ void pack_kernel(NetDev n, const float* master, float* Wp, float* WpT
   if (p >= n.n_params) return;
   int layer = 0;
 #pragma unroll
-  for (int l = 1; l < MLP_NLAYER; ++l) if (p >= n.L[l].m_w) layer = l;
+  for (int l = 1; l < MLP_MAXL; ++l) if (p >= n.L[l].m_w) layer = l;
   const LayerDesc& ld = n.L[layer];
   const float w = master[p];
   if (p >= ld.m_b) bias[ld.b_off + (p - ld.m_b)] = w;

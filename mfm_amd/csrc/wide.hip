@@ -416,7 +416,7 @@ static void launch_gemm(const Gemm& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------------
 struct WgLayer { const float* A; int lda; const float* Z; int ldz; int K, N, Kp, Np, m_w, m_b; };
 struct WgJob { int layer, kt, nt; };
-struct WgArgs { WgLayer L[MLP_NLAYER]; const WgJob* jobs; int n_jobs; int rows; float* grads;
+struct WgArgs { WgLayer L[MLP_MAXL]; const WgJob* jobs; int n_jobs; int rows; float* grads;
                 int* bad;      // non-null: raise *bad when a gradient element is not finite (the optimizer's apply_if_finite check)
                 int n_full; }; // jobs [0, n_full) run one per wave (4 per workgroup); jobs [n_full, n_jobs) one per WORKGROUP, rows split over its waves
 
@@ -1235,16 +1235,20 @@ __global__ void transpose_kernel(const float* src, int R, int C, float* dst) {  
 // ---------------------------------------------------------------------------------------------------------------------
 struct Ctx {
   int R;                                   // row capacity of one pass (multiple of 16)
-  int d, dp, F2p, ht1, ht2, hx1, hx2, hj1, hj2, cat;
+  int d, dp, F2p, cat;
+  // topology (NetDev::nT / nX / nJ hidden layers per branch): ids of the layers in NetDev::L and their widths
+  int nT, nX, nJ, nl, lt[MLP_MAX_DEPTH], lx[MLP_MAX_DEPTH], lj[MLP_MAX_DEPTH], l_gate, l_out;
+  int ht[MLP_MAX_DEPTH], hx[MLP_MAX_DEPTH], hj[MLP_MAX_DEPTH];
   float* pool = nullptr; size_t pool_floats = 0;
-  // forward activations
-  float *ffat, *t1, *catv, *cond, *x1, *j1, *j2, *gate, *out, *tgt, *gc, *kv;
+  // forward activations.  The LAST hidden layer of the t branch and of the x branch write their half of catv = [sx | st]
+  // (exe_flow_matching.py:83); ta[i] / xa[i] hold the layers in front of it (i < nT - 1, i < nX - 1), ja[i] every joint layer
+  float *ffat, *ta[MLP_MAX_DEPTH], *catv, *cond, *xa[MLP_MAX_DEPTH], *ja[MLP_MAX_DEPTH], *gate, *out, *tgt, *gc, *kv;
   // tangent twins
-  float *zp, *tz1, *kz, *hz, *x1T, *catT, *j1T, *j2T, *outT;
-  // backward
-  float *dv, *dg, *dj2, *dj1, *dcat, *dx1, *dt1;
-  // pre-activations of the six hidden layers (allocated for gelu / swish only): t1, [sx | st], x1, j1, j2
-  float *pt1 = nullptr, *pcat = nullptr, *px1 = nullptr, *pj1 = nullptr, *pj2 = nullptr;
+  float *zp, *tz1, *kz, *hz, *xaT[MLP_MAX_DEPTH], *catT, *jaT[MLP_MAX_DEPTH], *outT;
+  // backward (gradients with respect to the pre-activations, same shapes as the activations)
+  float *dv, *dg, *dja[MLP_MAX_DEPTH], *dcat, *dxa[MLP_MAX_DEPTH], *dta[MLP_MAX_DEPTH];
+  // pre-activations of the hidden layers (allocated for gelu / swish only)
+  float *pta[MLP_MAX_DEPTH] = {}, *pcat = nullptr, *pxa[MLP_MAX_DEPTH] = {}, *pja[MLP_MAX_DEPTH] = {};
   // ODE
   float *Y, *K, *rsf; int* rsi; RowState rs;
   float *vol0, *lqref; int* natt_tot;
@@ -1253,8 +1257,8 @@ struct Ctx {
   int* n_active = nullptr; int* h_active = nullptr;
   // row compaction of the host-driven solver (solve): map, inverse map, the compact copy of z W_x1, the probe constants in use
   int *cmap = nullptr, *cpos = nullptr; float* tz1c = nullptr; const float* tz1_use = nullptr; const int* cmap_use = nullptr;
-  // time-branch batch of an attempt (five stage times): Fourier rows, t1, [sx | st], gate, each 5 R rows
-  float *ffat5 = nullptr, *t15 = nullptr, *cat5 = nullptr, *gate5 = nullptr;
+  // time-branch batch of an attempt (five stage times): Fourier rows, the t layers, [sx | st], gate, each 5 R rows
+  float *ffat5 = nullptr, *ta5[MLP_MAX_DEPTH] = {}, *cat5 = nullptr, *gate5 = nullptr;
   // exact-trace log-det (no --hutch): set by mfm_create; buffers allocated by the first solve that needs them
   bool exact = false; const float* master = nullptr;
   float *jtA = nullptr, *jtB = nullptr, *jtE = nullptr, *jtET = nullptr, *jtWo = nullptr, *jtP = nullptr; int jt_chains = 0;
@@ -1264,31 +1268,37 @@ static int create(const NetDev& n, int rows_cap, Ctx** out) {
   Ctx* w = new Ctx();
   *out = w;            // handed over at once: whatever a failure below leaves allocated is freed by the caller's destroy()
   w->R = (rows_cap + 15) & ~15;
-  w->d = n.d; w->dp = n.dp; w->F2p = n.F2p; w->ht1 = n.ht1; w->ht2 = n.ht2; w->hx1 = n.hx1; w->hx2 = n.hx2; w->hj1 = n.hj1; w->hj2 = n.hj2;
+  w->d = n.d; w->dp = n.dp; w->F2p = n.F2p;
+  w->nT = n.nT; w->nX = n.nX; w->nJ = n.nJ;
+  {
+    int l = 0;
+    for (int i = 0; i < n.nT; ++i) { w->lt[i] = l; w->ht[i] = n.L[l].Np; ++l; }
+    for (int i = 0; i < n.nX; ++i) { w->lx[i] = l; w->hx[i] = n.L[l].Np; ++l; }
+    w->l_gate = l++;
+    for (int i = 0; i < n.nJ; ++i) { w->lj[i] = l; w->hj[i] = n.L[l].Np; ++l; }
+    w->l_out = l++;
+    w->nl = l;
+  }
   w->cat = n.hx2 + n.ht2;
   const size_t R = w->R;
   size_t o = 0;
   auto take = [&](size_t cnt) { size_t r = o; o += (cnt + 63) & ~(size_t)63; return r; };
-  const size_t o_ffat = take(R * n.F2p), o_t1 = take(R * n.ht1), o_cat = take(R * w->cat), o_cond = take(R * n.dp), o_x1 = take(R * n.hx1),
-               o_j1 = take(R * n.hj1), o_j2 = take(R * n.hj2), o_gate = take(R * n.dp), o_out = take(R * n.dp), o_tgt = take(R * n.dp),
-               o_gc = take(R * n.dp), o_kv = take(R * n.dp), o_zp = take(R * n.dp), o_tz1 = take(R * n.hx1), o_kz = take(R * n.dp),
-               o_hz = take(R * n.dp), o_x1T = take(R * n.hx1), o_catT = take(R * w->cat), o_j1T = take(R * n.hj1), o_j2T = take(R * n.hj2),
-               o_outT = take(R * n.dp), o_dv = take(R * n.dp), o_dg = take(R * n.dp), o_dj2 = take(R * n.hj2), o_dj1 = take(R * n.hj1),
-               o_dcat = take(R * w->cat), o_dx1 = take(R * n.hx1), o_dt1 = take(R * n.ht1), o_Y = take(R * n.dp), o_K = take(7 * R * n.dp),
-               o_rsf = take(12 * R), o_vol0 = take(R), o_lq = take(R);
   const bool need_pre = n.act >= MFM_ACT_GELU;
-  const size_t o_pt1 = need_pre ? take(R * n.ht1) : 0, o_pcat = need_pre ? take(R * w->cat) : 0, o_px1 = need_pre ? take(R * n.hx1) : 0,
-               o_pj1 = need_pre ? take(R * n.hj1) : 0, o_pj2 = need_pre ? take(R * n.hj2) : 0;
+  struct Slot { float** p; size_t off; };
+  std::vector<Slot> slots;
+  auto want = [&](float*& p, size_t width) { slots.push_back(Slot{&p, take(R * width)}); };
+  want(w->ffat, n.F2p); want(w->catv, w->cat); want(w->cond, n.dp); want(w->gate, n.dp); want(w->out, n.dp); want(w->tgt, n.dp);
+  want(w->gc, n.dp); want(w->kv, n.dp); want(w->zp, n.dp); want(w->tz1, w->hx[0]); want(w->kz, n.dp); want(w->hz, n.dp);
+  want(w->catT, w->cat); want(w->outT, n.dp); want(w->dv, n.dp); want(w->dg, n.dp); want(w->dcat, w->cat);
+  if (need_pre) want(w->pcat, w->cat);
+  for (int i = 0; i + 1 < n.nT; ++i) { want(w->ta[i], w->ht[i]); want(w->dta[i], w->ht[i]); if (need_pre) want(w->pta[i], w->ht[i]); }
+  for (int i = 0; i + 1 < n.nX; ++i) { want(w->xa[i], w->hx[i]); want(w->xaT[i], w->hx[i]); want(w->dxa[i], w->hx[i]); if (need_pre) want(w->pxa[i], w->hx[i]); }
+  for (int i = 0; i < n.nJ; ++i) { want(w->ja[i], w->hj[i]); want(w->jaT[i], w->hj[i]); want(w->dja[i], w->hj[i]); if (need_pre) want(w->pja[i], w->hj[i]); }
+  want(w->Y, n.dp); want(w->K, 7 * (size_t)n.dp); want(w->rsf, 12); want(w->vol0, 1); want(w->lqref, 1);
   w->pool_floats = o;
   if (hipMalloc((void**)&w->pool, o * sizeof(float)) != hipSuccess) return -4;
   (void)hipMemset(w->pool, 0, o * sizeof(float));
-  float* p = w->pool;
-  w->ffat = p + o_ffat; w->t1 = p + o_t1; w->catv = p + o_cat; w->cond = p + o_cond; w->x1 = p + o_x1; w->j1 = p + o_j1; w->j2 = p + o_j2;
-  w->gate = p + o_gate; w->out = p + o_out; w->tgt = p + o_tgt; w->gc = p + o_gc; w->kv = p + o_kv; w->zp = p + o_zp; w->tz1 = p + o_tz1;
-  w->kz = p + o_kz; w->hz = p + o_hz; w->x1T = p + o_x1T; w->catT = p + o_catT; w->j1T = p + o_j1T; w->j2T = p + o_j2T; w->outT = p + o_outT;
-  w->dv = p + o_dv; w->dg = p + o_dg; w->dj2 = p + o_dj2; w->dj1 = p + o_dj1; w->dcat = p + o_dcat; w->dx1 = p + o_dx1; w->dt1 = p + o_dt1;
-  w->Y = p + o_Y; w->K = p + o_K; w->rsf = p + o_rsf; w->vol0 = p + o_vol0; w->lqref = p + o_lq;
-  if (need_pre) { w->pt1 = p + o_pt1; w->pcat = p + o_pcat; w->px1 = p + o_px1; w->pj1 = p + o_pj1; w->pj2 = p + o_pj2; }
+  for (const Slot& sl : slots) *sl.p = w->pool + sl.off;
   w->rs.t = w->rsf; w->rs.dt = w->rsf + R; w->rs.h0 = w->rsf + 2 * R; w->rs.d1 = w->rsf + 3 * R; w->rs.ell = w->rsf + 4 * R; w->rs.kl = w->rsf + 5 * R;
   if (hipMalloc((void**)&w->rsi, 3 * R * sizeof(int)) != hipSuccess) return -4;
   w->rs.natt = w->rsi; w->rs.done = w->rsi + R; w->natt_tot = w->rsi + 2 * R;
@@ -1299,16 +1309,20 @@ static int create(const NetDev& n, int rows_cap, Ctx** out) {
   if (hipMalloc((void**)&w->cmap, 2 * R * sizeof(int)) != hipSuccess) return -4;
   w->cpos = w->cmap + R;
   (void)hipMemset(w->cmap, 0, 2 * R * sizeof(int));
-  if (hipMalloc((void**)&w->tz1c, R * n.hx1 * sizeof(float)) != hipSuccess) return -4;
+  if (hipMalloc((void**)&w->tz1c, R * w->hx[0] * sizeof(float)) != hipSuccess) return -4;
   w->tz1_use = nullptr;
   {
-    const size_t n5 = 5 * R * ((size_t)n.F2p + n.ht1 + w->cat + n.dp);
+    size_t wt = 0;
+    for (int i = 0; i + 1 < n.nT; ++i) wt += w->ht[i];
+    const size_t n5 = 5 * R * ((size_t)n.F2p + wt + w->cat + n.dp);
     if (hipMalloc((void**)&w->ffat5, n5 * sizeof(float)) != hipSuccess) return -4;
     (void)hipMemset(w->ffat5, 0, n5 * sizeof(float));
-    w->t15 = w->ffat5 + 5 * R * n.F2p; w->cat5 = w->t15 + 5 * R * n.ht1; w->gate5 = w->cat5 + 5 * R * w->cat;
+    float* p = w->ffat5 + 5 * R * n.F2p;
+    for (int i = 0; i + 1 < n.nT; ++i) { w->ta5[i] = p; p += 5 * R * w->ht[i]; }
+    w->cat5 = p; w->gate5 = w->cat5 + 5 * R * w->cat;
   }
   std::vector<WgJob> jobs;
-  for (int l = 0; l < MLP_NLAYER; ++l)
+  for (int l = 0; l < w->nl; ++l)
     for (int nt = 0; nt * 64 < n.L[l].Np; ++nt)
       for (int kt = 0; kt * 64 < n.L[l].Kp; ++kt) jobs.push_back(WgJob{l, kt, nt});
   w->n_jobs = (int)jobs.size();
@@ -1364,33 +1378,45 @@ static void target_eval(Ctx* w, const NetDev& n, const float* X, const float* Z,
   hipLaunchKernelGGL(target_kernel, dim3(grid_el((size_t)rows * n.dp)), dim3(256), 0, s, t);
 }
 
-// time branch: ffat -> t1 -> st (into [sx | st]) -> gate
-static void time_branch(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
-  Gemm g = fwd(n, 0, w->ffat, n.F2p, w->t1, n.ht1, 0, rows, 1); g.P = w->pt1; launch_gemm(g, s);
-  g = fwd(n, 1, w->t1, n.ht1, w->catv, w->cat, n.hx2, rows, 1); g.P = w->pcat; launch_gemm(g, s);
-  launch_gemm(fwd(n, 4, w->catv + n.hx2, w->cat, w->gate, n.dp, 0, rows, 0), s);
+// time branch (exe_flow_matching.py:73-75,81): Fourier rows -> the t layers (the last one into the st half of [sx | st]) -> gate.
+// `ta`: the buffers of the layers in front of the last; `pre`: keep the pre-activations (gelu / swish backward pass)
+static void time_branch_on(Ctx* w, const NetDev& n, const float* ffat, float* const* ta, float* cat, float* gate, bool pre, int rows, hipStream_t s) {
+  for (int i = 0; i < w->nT; ++i) {
+    const bool last = i + 1 == w->nT;
+    Gemm g = fwd(n, w->lt[i], i == 0 ? ffat : ta[i - 1], i == 0 ? n.F2p : w->ht[i - 1], last ? cat : ta[i], last ? w->cat : w->ht[i], last ? n.hx2 : 0, rows, 1);
+    if (pre) g.P = last ? w->pcat : w->pta[i];
+    launch_gemm(g, s);
+  }
+  launch_gemm(fwd(n, w->l_gate, cat + n.hx2, w->cat, gate, n.dp, 0, rows, 0), s);
 }
-// x branch + joint layers on value rows X (and tangent rows: z in w->zp, z W_x1 in w->tz1)
+static void time_branch(Ctx* w, const NetDev& n, int rows, hipStream_t s) { time_branch_on(w, n, w->ffat, w->ta, w->catv, w->gate, true, rows, s); }
+// x branch + joint layers (:77-79,83-86) on value rows X (and tangent rows: z in w->zp, z W_x1 in w->tz1)
 static void x_branch(Ctx* w, const NetDev& n, const float* X, bool tangent, int rows, hipStream_t s) {
-  Gemm g = fwd(n, 2, X, n.dp, w->x1, n.hx1, 0, rows, 1); g.P = w->px1;
-  if (tangent) { g.YT = w->x1T; g.TS = w->tz1_use ? w->tz1_use : w->tz1; g.ldts = n.hx1; }
-  launch_gemm(g, s);
-  g = fwd(n, 3, w->x1, n.hx1, w->catv, w->cat, 0, rows, 1); g.P = w->pcat;
-  if (tangent) { g.XT = w->x1T; g.KBT = g.KB; g.YT = w->catT; }
-  launch_gemm(g, s);
-  g = fwd(n, 5, w->catv, w->cat, w->j1, n.hj1, 0, rows, 1); g.P = w->pj1;
-  if (tangent) { g.XT = w->catT; g.KBT = n.hx2 / 16; g.YT = w->j1T; }          // the st half of the tangent is zero
-  launch_gemm(g, s);
-  g = fwd(n, 6, w->j1, n.hj1, w->j2, n.hj2, 0, rows, 1); g.P = w->pj2;
-  if (tangent) { g.XT = w->j1T; g.KBT = g.KB; g.YT = w->j2T; }
-  launch_gemm(g, s);
-  g = fwd(n, 7, w->j2, n.hj2, w->out, n.dp, 0, rows, 0);
-  if (tangent) { g.XT = w->j2T; g.KBT = g.KB; g.YT = w->outT; }
+  for (int i = 0; i < w->nX; ++i) {
+    const bool last = i + 1 == w->nX;
+    Gemm g = fwd(n, w->lx[i], i == 0 ? X : w->xa[i - 1], i == 0 ? n.dp : w->hx[i - 1], last ? w->catv : w->xa[i], last ? w->cat : w->hx[i], 0, rows, 1);
+    g.P = last ? w->pcat : w->pxa[i];
+    if (tangent) {
+      g.YT = last ? w->catT : w->xaT[i];
+      if (i == 0) { g.TS = w->tz1_use ? w->tz1_use : w->tz1; g.ldts = w->hx[0]; }
+      else { g.XT = w->xaT[i - 1]; g.KBT = g.KB; }
+    }
+    launch_gemm(g, s);
+  }
+  for (int i = 0; i < w->nJ; ++i) {
+    Gemm g = fwd(n, w->lj[i], i == 0 ? w->catv : w->ja[i - 1], i == 0 ? w->cat : w->hj[i - 1], w->ja[i], w->hj[i], 0, rows, 1);
+    g.P = w->pja[i];
+    if (tangent) { g.XT = i == 0 ? w->catT : w->jaT[i - 1]; g.KBT = i == 0 ? n.hx2 / 16 : g.KB; g.YT = w->jaT[i]; }      // the st half of the tangent is zero
+    launch_gemm(g, s);
+  }
+  const int jl = w->nJ - 1;
+  Gemm g = fwd(n, w->l_out, w->ja[jl], w->hj[jl], w->out, n.dp, 0, rows, 0);
+  if (tangent) { g.XT = w->jaT[jl]; g.KBT = g.KB; g.YT = w->outT; }
   launch_gemm(g, s);
 }
 // once per solve: z W_x1 (no bias) and, LGCP, K^-1 z
 static void probe_setup(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
-  Gemm g = fwd(n, 2, w->zp, n.dp, w->tz1, n.hx1, 0, rows, 0);
+  Gemm g = fwd(n, w->lx[0], w->zp, n.dp, w->tz1, w->hx[0], 0, rows, 0);
   g.bias = nullptr;
   launch_gemm(g, s);
   if (n.T.kind == MFM_TARGET_LGCP) launch_gemm(kinv(n, w->zp, w->kz, rows, false), s);
@@ -1427,14 +1453,17 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
     g.mask = pre ? prebuf : out; g.ldm = ld; g.mcol = col; g.mask_kind = n.act; g.mask_is_pre = pre ? 1 : 0;
     return g;
   };
-  launch_gemm(masked(bwd(n, 7, w->dv, n.dp, w->dj2, n.hj2, 0, rows), w->j2, w->pj2, n.hj2, 0), s);
-  launch_gemm(masked(bwd(n, 6, w->dj2, n.hj2, w->dj1, n.hj1, 0, rows), w->j1, w->pj1, n.hj1, 0), s);
-  // d [sx | st] through j1 (not yet through the activations of sx / st)
-  launch_gemm(bwd(n, 5, w->dj1, n.hj1, w->dcat, w->cat, 0, rows), s);
+  const int jl = w->nJ - 1, xl = w->nX - 1, tl = w->nT - 1;
+  launch_gemm(masked(bwd(n, w->l_out, w->dv, n.dp, w->dja[jl], w->hj[jl], 0, rows), w->ja[jl], w->pja[jl], w->hj[jl], 0), s);
+  for (int i = jl; i >= 1; --i)
+    launch_gemm(masked(bwd(n, w->lj[i], w->dja[i], w->hj[i], w->dja[i - 1], w->hj[i - 1], 0, rows), w->ja[i - 1], w->pja[i - 1], w->hj[i - 1], 0), s);
+  // d [sx | st] through the first joint layer (not yet through the activations of sx / st)
+  launch_gemm(bwd(n, w->lj[0], w->dja[0], w->hj[0], w->dcat, w->cat, 0, rows), s);
   // st half: += dgate W_gate^T, then through the activation of st (GEMM epilogue); sx half: through the activation of sx
-  // by one thin elementwise pass (it is both the input of the x2 data-gradient GEMM and the dZ of x2's weight gradient)
+  // by one thin elementwise pass (it is both the input of the data-gradient GEMM of the x branch's last layer and the dZ of that
+  // layer's weight gradient)
   {
-    Gemm g = bwd(n, 4, w->dg, n.dp, w->dcat, w->cat, n.hx2, rows);
+    Gemm g = bwd(n, w->l_gate, w->dg, n.dp, w->dcat, w->cat, n.hx2, rows);
     g.add = w->dcat; g.lda = w->cat; g.acol = n.hx2;
     launch_gemm(masked(g, w->catv, w->pcat, w->cat, n.hx2), s);
   }
@@ -1442,18 +1471,23 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
     ElemMask e; e.rows = rows; e.cols = n.hx2; e.ld = w->cat; e.x = w->dcat; e.m = pre ? w->pcat : w->catv; e.kind = n.act; e.is_pre = pre ? 1 : 0;
     hipLaunchKernelGGL(elem_mask_kernel, dim3(grid_el((size_t)rows * n.hx2 / 4)), dim3(256), 0, s, e);
   }
-  launch_gemm(masked(bwd(n, 3, w->dcat, w->cat, w->dx1, n.hx1, 0, rows), w->x1, w->px1, n.hx1, 0), s);
-  launch_gemm(masked(bwd(n, 1, w->dcat + n.hx2, w->cat, w->dt1, n.ht1, 0, rows), w->t1, w->pt1, n.ht1, 0), s);
+  for (int i = xl; i >= 1; --i)          // x branch, towards its first layer (the gradient with respect to x itself is not needed)
+    launch_gemm(masked(bwd(n, w->lx[i], i == xl ? w->dcat : w->dxa[i], i == xl ? w->cat : w->hx[i], w->dxa[i - 1], w->hx[i - 1], 0, rows),
+                       w->xa[i - 1], w->pxa[i - 1], w->hx[i - 1], 0), s);
+  for (int i = tl; i >= 1; --i)          // t branch
+    launch_gemm(masked(bwd(n, w->lt[i], i == tl ? w->dcat + n.hx2 : w->dta[i], i == tl ? w->cat : w->ht[i], w->dta[i - 1], w->ht[i - 1], 0, rows),
+                       w->ta[i - 1], w->pta[i - 1], w->ht[i - 1], 0), s);
   // ---- weight gradients, straight into the canonical flat gradient vector ----
   WgArgs a; memset(&a, 0, sizeof a);
-  const float* A[MLP_NLAYER] = {w->ffat, w->t1, w->cond, w->x1, w->catv + n.hx2, w->catv, w->j1, w->j2};
-  const int lda[MLP_NLAYER] = {n.F2p, n.ht1, n.dp, n.hx1, w->cat, w->cat, n.hj1, n.hj2};
-  const float* Z[MLP_NLAYER] = {w->dt1, w->dcat + n.hx2, w->dx1, w->dcat, w->dg, w->dj1, w->dj2, w->dv};
-  const int ldz[MLP_NLAYER] = {n.ht1, w->cat, n.hx1, w->cat, n.dp, n.hj1, n.hj2, n.dp};
-  for (int l = 0; l < MLP_NLAYER; ++l) {
+  auto wg = [&](int l, const float* A, int lda, const float* Z, int ldz) {
     const LayerDesc& L = n.L[l];
-    a.L[l] = WgLayer{A[l], lda[l], Z[l], ldz[l], L.K, L.N, L.Kp, L.Np, L.m_w, L.m_b};
-  }
+    a.L[l] = WgLayer{A, lda, Z, ldz, L.K, L.N, L.Kp, L.Np, L.m_w, L.m_b};
+  };
+  for (int i = 0; i <= tl; ++i) wg(w->lt[i], i == 0 ? w->ffat : w->ta[i - 1], i == 0 ? n.F2p : w->ht[i - 1], i == tl ? w->dcat + n.hx2 : w->dta[i], i == tl ? w->cat : w->ht[i]);
+  for (int i = 0; i <= xl; ++i) wg(w->lx[i], i == 0 ? w->cond : w->xa[i - 1], i == 0 ? n.dp : w->hx[i - 1], i == xl ? w->dcat : w->dxa[i], i == xl ? w->cat : w->hx[i]);
+  wg(w->l_gate, w->catv + n.hx2, w->cat, w->dg, n.dp);
+  for (int i = 0; i <= jl; ++i) wg(w->lj[i], i == 0 ? w->catv : w->ja[i - 1], i == 0 ? w->cat : w->hj[i - 1], w->dja[i], w->hj[i]);
+  wg(w->l_out, w->ja[jl], w->hj[jl], w->dv, n.dp);
   a.jobs = w->jobs; a.n_jobs = w->n_jobs; a.rows = rows; a.grads = d_grads; a.bad = c.bad;
   // what does not fill the chip's 2048 wave slots a whole number of times, if it is a tail of at most one workgroup per CU
   const int rem = w->n_jobs % 2048;
@@ -1464,15 +1498,16 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
 }
 
 // ---- exact trace of d nn_xt / d x for the `rows` (compact) rows of the evaluation x_branch has just run: see jt_seed_kernel ----
-constexpr int JT_ROWS_CAP = 131072;      // tangent rows per pass (128 chains x hx1 = 1024): two buffers of rows x max(hx2, hj1, hj2) floats
+constexpr int JT_ROWS_CAP = 131072;      // tangent rows per pass (128 chains x hx1 = 1024): two buffers of rows x (widest layer behind x1) floats
 static int jt_alloc(Ctx* w, const NetDev& n) {
   if (w->jtA) return 0;
   int chains = JT_ROWS_CAP / n.hx1;
   if (chains < 1) chains = 1;
   if (chains > w->R) chains = w->R;
   const size_t rows = (size_t)chains * n.hx1;
-  size_t hmax = n.hx2 > n.hj1 ? n.hx2 : n.hj1;
-  if ((size_t)n.hj2 > hmax) hmax = n.hj2;
+  size_t hmax = 0;
+  for (int i = 1; i < w->nX; ++i) if ((size_t)w->hx[i] > hmax) hmax = w->hx[i];
+  for (int i = 0; i < w->nJ; ++i) if ((size_t)w->hj[i] > hmax) hmax = w->hj[i];
   if (hipMalloc((void**)&w->jtA, rows * hmax * sizeof(float)) != hipSuccess) return -4;
   if (hipMalloc((void**)&w->jtB, rows * hmax * sizeof(float)) != hipSuccess) return -4;
   if (hipMalloc((void**)&w->jtE, (size_t)n.hj2 * n.hx1 * sizeof(float)) != hipSuccess) return -4;
@@ -1485,32 +1520,46 @@ static int jt_alloc(Ctx* w, const NetDev& n) {
 // E^T, E = W_out W_x1 (the parameters do not change inside a solve): rows of the canonical out kernel [hj2][d] as the "activations"
 // of the x1 layer's packed weights, then a transpose so that jt_trace_kernel reads row i of E^T beside tangent row i
 static void jt_setup(Ctx* w, const NetDev& n, hipStream_t s) {
-  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_el((size_t)n.hj2 * n.dp)), dim3(256), 0, s, w->master + n.L[7].m_w, n.hj2, n.d, n.dp, w->jtWo);
-  Gemm g = fwd(n, 2, w->jtWo, n.dp, w->jtE, n.hx1, 0, n.hj2, 0);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_el((size_t)n.hj2 * n.dp)), dim3(256), 0, s, w->master + n.L[w->l_out].m_w, n.hj2, n.d, n.dp, w->jtWo);
+  Gemm g = fwd(n, w->lx[0], w->jtWo, n.dp, w->jtE, n.hx1, 0, n.hj2, 0);
   g.bias = nullptr;
   launch_gemm(g, s);
   hipLaunchKernelGGL(transpose_kernel, dim3((n.hx1 + 31) / 32, (n.hj2 + 31) / 32), dim3(256), 0, s, w->jtE, n.hj2, n.hx1, w->jtET);
 }
+// The layers a tangent of x1's output passes on its way to the output layer: the rest of the x branch, then the joint branch (whose
+// first layer sees the tangent through its sx rows only).  The FIRST of them is applied element-wise by jt_seed_kernel (tangent row
+// i of a chain starts as act'(x1)_i times row i of that layer's kernel), the others are GEMMs with the chain's mask in the epilogue.
 static void exact_trace(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
   const bool pre = n.act >= MFM_ACT_GELU;       // act' from the stored pre-activations (gelu, swish) or from the stored outputs
+  struct Hop { int layer; const float* m; int ldm; int width; bool joint0; };
+  Hop hops[2 * MLP_MAX_DEPTH]; int nh = 0;
+  for (int i = 1; i < w->nX; ++i) {
+    const bool last = i + 1 == w->nX;
+    hops[nh++] = Hop{w->lx[i], last ? (pre ? w->pcat : w->catv) : (pre ? w->pxa[i] : w->xa[i]), last ? w->cat : w->hx[i], w->hx[i], false};
+  }
+  for (int i = 0; i < w->nJ; ++i) hops[nh++] = Hop{w->lj[i], pre ? w->pja[i] : w->ja[i], w->hj[i], w->hj[i], i == 0};
+  // act'(x1): the first x layer's output sits in [sx | st] when it is the branch's only layer
+  const float* m1 = w->nX == 1 ? (pre ? w->pcat : w->catv) : (pre ? w->pxa[0] : w->xa[0]);
+  const int ld1 = w->nX == 1 ? w->cat : w->hx[0];
   for (int r0 = 0; r0 < rows; r0 += w->jt_chains) {
     const int C = rows - r0 < w->jt_chains ? rows - r0 : w->jt_chains;
     const int trows = C * n.hx1;
+    float *cur = w->jtA, *nxt = w->jtB;
     JtSeed sd; memset(&sd, 0, sizeof sd);
-    sd.chains = C; sd.hx1 = n.hx1; sd.hx2 = n.hx2; sd.row0 = r0; sd.W = w->master + n.L[3].m_w;
-    sd.m1 = pre ? w->px1 : w->x1; sd.ld1 = n.hx1; sd.m2 = pre ? w->pcat : w->catv; sd.ld2 = w->cat; sd.kind = n.act; sd.is_pre = pre; sd.X = w->jtA;
-    hipLaunchKernelGGL(jt_seed_kernel, dim3(grid_el((size_t)trows * n.hx2 / 4)), dim3(256), 0, s, sd);
-    Gemm g; memset(&g, 0, sizeof g);           // tangent rows x the sx rows of the joint layer, masked by the chain's act'(j1)
-    g.W = n.Wp + n.L[5].w_off; g.KBW = n.L[5].Kp / 16; g.KB = n.hx2 / 16; g.NT = n.L[5].Np / 16;
-    g.X = w->jtA; g.ldx = n.hx2; g.Y = w->jtB; g.ldy = n.hj1; g.rows = trows;
-    g.mask = (pre ? w->pj1 : w->j1) + (size_t)r0 * n.hj1; g.ldm = n.hj1; g.mask_kind = n.act; g.mask_is_pre = pre; g.mask_rdiv = n.hx1;
-    launch_gemm(g, s);
-    memset(&g, 0, sizeof g);                   // ... x the second joint layer, masked by act'(j2)
-    g.W = n.Wp + n.L[6].w_off; g.KB = n.L[6].Kp / 16; g.NT = n.L[6].Np / 16;
-    g.X = w->jtB; g.ldx = n.hj1; g.Y = w->jtA; g.ldy = n.hj2; g.rows = trows;
-    g.mask = (pre ? w->pj2 : w->j2) + (size_t)r0 * n.hj2; g.ldm = n.hj2; g.mask_kind = n.act; g.mask_is_pre = pre; g.mask_rdiv = n.hx1;
-    launch_gemm(g, s);
-    JtTrace t; t.hx1 = n.hx1; t.hj2 = n.hj2; t.row0 = r0; t.Y = w->jtA; t.ET = w->jtET; t.trp = w->jtP;
+    sd.chains = C; sd.hx1 = n.hx1; sd.hx2 = hops[0].width; sd.row0 = r0; sd.W = w->master + n.L[hops[0].layer].m_w;      // rows [0, hx1) of the canonical kernel
+    sd.m1 = m1; sd.ld1 = ld1; sd.m2 = hops[0].m; sd.ld2 = hops[0].ldm; sd.kind = n.act; sd.is_pre = pre; sd.X = cur;
+    hipLaunchKernelGGL(jt_seed_kernel, dim3(grid_el((size_t)trows * hops[0].width / 4)), dim3(256), 0, s, sd);
+    for (int h = 1; h < nh; ++h) {
+      const LayerDesc& L = n.L[hops[h].layer];
+      Gemm g; memset(&g, 0, sizeof g);           // tangent rows x the layer (the sx rows of the first joint layer), masked by the chain's act'
+      g.W = n.Wp + L.w_off; g.KB = L.Kp / 16; g.NT = L.Np / 16;
+      if (hops[h].joint0) { g.KBW = L.Kp / 16; g.KB = n.hx2 / 16; }
+      g.X = cur; g.ldx = hops[h - 1].width; g.Y = nxt; g.ldy = hops[h].width; g.rows = trows;
+      g.mask = hops[h].m + (size_t)r0 * hops[h].ldm; g.ldm = hops[h].ldm; g.mask_kind = n.act; g.mask_is_pre = pre; g.mask_rdiv = n.hx1;
+      launch_gemm(g, s);
+      float* t = cur; cur = nxt; nxt = t;
+    }
+    JtTrace t; t.hx1 = n.hx1; t.hj2 = n.hj2; t.row0 = r0; t.Y = cur; t.ET = w->jtET; t.trp = w->jtP;
     hipLaunchKernelGGL(jt_trace_kernel, dim3(JT_SLICES, C), dim3(256), 0, s, t);
   }
 }
@@ -1596,9 +1645,7 @@ static int solve(Ctx* w, const NetDev& n, const SolveArgs& c, float* xstage, hip
       stage_prep(ob, 2);
       {
         const int r5 = 5 * rc;
-        launch_gemm(fwd(n, 0, w->ffat5, n.F2p, w->t15, n.ht1, 0, r5, 1), s);
-        launch_gemm(fwd(n, 1, w->t15, n.ht1, w->cat5, w->cat, n.hx2, r5, 1), s);
-        launch_gemm(fwd(n, 4, w->cat5 + n.hx2, w->cat, w->gate5, n.dp, 0, r5, 0), s);
+        time_branch_on(w, n, w->ffat5, w->ta5, w->cat5, w->gate5, false, r5, s);
       }
       float* const cat_keep = w->catv;
       for (int phase = 2; phase < 8; ++phase) {

@@ -119,8 +119,9 @@ class Engine:
         self.n_total = int(args.num_chain)
         self.n_local, self.offset, self.n_valid = shard(self.n_total, self.rank, self.world)
         self.dim = int(args.dim)
-        if len(args.hidden_x) != 2 or len(args.hidden_t) != 2 or len(args.hidden_xt) != 2:
-            raise NotImplementedError("the fused MLP kernels are built for two hidden layers per branch")
+        for name in ("hidden_x", "hidden_t", "hidden_xt"):       # exe_flow_matching.py:74-85 loop over lists of any length
+            if not 1 <= len(getattr(args, name)) <= _lib.MAX_DEPTH:
+                raise NotImplementedError(f"--{name}: {len(getattr(args, name))} hidden layers; the kernels take 1 to {_lib.MAX_DEPTH} per branch")
         if getattr(args, "non_linearity", "relu") not in _lib.ACTIVATIONS:
             raise NotImplementedError(f"unknown non_linearity {args.non_linearity!r} (exe_flow_matching.py:39-45)")
         ref_vars = {"stdgauss": 1.0, "widegauss": 5.0}                               # exe_flow_matching.py:48-54, distributions.py:80-97

@@ -37,10 +37,21 @@ ref_dists = {"stdgauss": lambda dim: IndepGaussian(dim), "widegauss": lambda dim
 
 # ---- parameters: flax-style pytree <-> canonical flat vector (include/mfm.h) ---------------------------------------
 def layer_shapes(dim, fourier_dim, hidden_x, hidden_t, hidden_xt):
-    F2 = 2 * fourier_dim
-    return [(F2, hidden_t[0]), (hidden_t[0], hidden_t[1]), (dim, hidden_x[0]), (hidden_x[0], hidden_x[1]),
-            (hidden_t[1], dim), (hidden_x[1] + hidden_t[1], hidden_xt[0]), (hidden_xt[0], hidden_xt[1]),
-            (hidden_xt[1], dim)]
+    """(in, out) of the Dense layers in flax creation order (``exe_flow_matching.py:74-86``): the time branch, the x branch, the
+    gate, the joint branch, the output; the hidden lists have any length >= 1."""
+    shapes, prev = [], 2 * fourier_dim
+    for h in hidden_t:
+        shapes.append((prev, h)); prev = h
+    ht, prev = prev, dim
+    for h in hidden_x:
+        shapes.append((prev, h)); prev = h
+    hx = prev
+    shapes.append((ht, dim))
+    prev = hx + ht
+    for h in hidden_xt:
+        shapes.append((prev, h)); prev = h
+    shapes.append((prev, dim))
+    return shapes
 
 
 def flatten_params(params):
@@ -82,8 +93,9 @@ class VectorFieldNet:
         shapes = self.shapes()
         keys = jr.split(rng_key, len(shapes))
         out = {}
+        gate = len(self.hidden_t) + len(self.hidden_x)
         for i, (fi, fo) in enumerate(shapes):
-            if i in (4, 7):
+            if i in (gate, len(shapes) - 1):
                 W = np.zeros((fi, fo), np.float32)
             else:
                 W = (jr.truncated_normal(keys[i], -2.0, 2.0, (fi, fo)) * np.sqrt(1.0 / fi) / 0.87962566103423978).astype(np.float32)

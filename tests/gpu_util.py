@@ -64,10 +64,17 @@ def make_ctx(dist, args, n_local=None, n_total=None, offset=0, fourier=None, par
     return ctx
 
 
+def hidden_lists(hidden):
+    """An int: two layers of that width per branch (the reference's default depth); a triple of lists: (hidden_x, hidden_t, hidden_xt)."""
+    if isinstance(hidden, int):
+        return dict(hidden_x=[hidden, hidden], hidden_t=[hidden, hidden], hidden_xt=[hidden, hidden])
+    hx, ht, hxt = hidden
+    return dict(hidden_x=list(hx), hidden_t=list(ht), hidden_xt=list(hxt))
+
+
 def phi4_setup(d=256, B=64, seed=1, hutch=True, hidden=128, F=128, **kw):
     args = loop.default_args(example="phi-four", dim=d, num_chain=B, hutchs=hutch, step_size=1e-4, seed=seed,
-                             fourier_dim=F, hidden_x=[hidden, hidden], hidden_t=[hidden, hidden],
-                             hidden_xt=[hidden, hidden], **kw)
+                             fourier_dim=F, **hidden_lists(hidden), **kw)
     dist = targets.PhiFour(d)
     k, model, state, lr_fn, _, _ = loop.setup(dist, args)
     return args, dist, k, model, state
@@ -86,7 +93,7 @@ def lgcp_setup(n=8, B=32, seed=1, hidden=32, F=16, hutch=True, **kw):
     d = n * n
     counts = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mfm_amd", "data", "pines_counts.npz"))[f"counts_{n}"]
     args = loop.default_args(example="pines", dim=d, num_chain=B, hutchs=hutch, step_size=0.01, seed=seed, fourier_dim=F,
-                             hidden_x=[hidden, hidden], hidden_t=[hidden, hidden], hidden_xt=[hidden, hidden], **kw)
+                             **hidden_lists(hidden), **kw)
     dist = targets.LogGaussianCoxPines(d, counts)
     k, model, state, lr_fn, _, _ = loop.setup(dist, args)
     return args, dist, k, model, state

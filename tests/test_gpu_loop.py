@@ -15,7 +15,9 @@ def _run_both(example, d, B, iters, K, hutch=True, width=32, fourier_dim=16, **k
     from mfm_amd import distributions as D, exe_flow_matching as E
     from oracle import loop, targets
     common = dict(example=example, dim=d, num_chain=B, learning_iter=iters, mcmc_per_flow_steps=float(K), hutchs=hutch,
-                  fourier_dim=fourier_dim, hidden_x=[width, width], hidden_t=[width, width], hidden_xt=[width, width], seed=1024, eval_iter=1, **kw)
+                  fourier_dim=fourier_dim, seed=1024, eval_iter=1, **kw)
+    from tests import gpu_util as gu
+    common.update(gu.hidden_lists(width))
     if example == "phi-four":
         dg, do = D.PhiFour(d), targets.PhiFour(d)
         tg = to = None

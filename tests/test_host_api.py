@@ -23,6 +23,37 @@ def test_library_exports_every_symbol_declared_in_header():
     assert _lib.load().mfm_version() == 1
 
 
+def test_ctypes_config_mirrors_the_header_struct_field_for_field():
+    """mfm_config crosses the C ABI by value layout: the ctypes mirror must list the header's members in order, with the same types."""
+    from mfm_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mfm.h")).read()
+    body = hdr[hdr.index("typedef struct mfm_config {"):hdr.index("} mfm_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    ctype = {"int32_t": ctypes.c_int32, "float": ctypes.c_float, "double": ctypes.c_double}
+    fields = []
+    for ty, names in re.findall(r"\b(int32_t|float|double)\s+([^;]+);", body):
+        for nm in names.split(","):
+            m = re.fullmatch(r"\s*(\w+)\s*(?:\[(\d+)\])?\s*", nm)
+            fields.append((m.group(1), ctype[ty] * int(m.group(2)) if m.group(2) else ctype[ty]))
+    mirror = [(n, t) for n, t in _lib.Config._fields_]
+    assert [n for n, _ in fields] == [n for n, _ in mirror]
+    for (n, t), (_, tm) in zip(fields, mirror):
+        assert ctypes.sizeof(t) == ctypes.sizeof(tm) and (t is tm or getattr(t, "_type_", None) is getattr(tm, "_type_", 0)), n
+    assert _lib.MAX_DEPTH == int(re.search(r"#define MFM_MAX_DEPTH (\d+)", hdr).group(1))
+
+
+def test_layer_shapes_follow_the_hidden_lists_of_any_length():
+    """exe_flow_matching.py:74-86: Dense layers in creation order for hidden lists of length 1, 2 and 3; host mirror == oracle."""
+    from mfm_amd import exe_flow_matching as E
+    from oracle import targets
+    from oracle.vfield import VectorFieldNet
+    assert E.layer_shapes(6, 4, [16, 32], [48, 64], [80, 96]) == [(8, 48), (48, 64), (6, 16), (16, 32), (64, 6), (96, 80), (80, 96), (96, 6)]
+    for hx, ht, hxt in (([16], [32], [48]), ([16, 32, 48], [16], [32, 32]), ([16, 16, 16], [32, 32, 32], [48, 48, 48])):
+        m = VectorFieldNet(np.zeros(4), targets.PhiFour(6), hx, ht, hxt)
+        assert E.layer_shapes(6, 4, hx, ht, hxt) == m.layer_shapes()
+        assert len(m.layer_shapes()) == len(hx) + len(ht) + len(hxt) + 2
+
+
 def test_no_gpu_fails_loudly():
     import torch
     from mfm_amd import _lib
