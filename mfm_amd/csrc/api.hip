@@ -344,7 +344,6 @@ extern "C" int mfm_set_target(mfm_ctx* x, int kind, const double* p, size_t np) 
     const int K = (int)p[0];
     if (K <= 0 || K > MFM_GMM_MAX_MODES || np != (size_t)(1 + 2 * K * d + K)) return fail(MFM_EINVAL, "bad GMM parameter block");
     if (d > 8) return fail(MFM_EUNSUPPORTED, "GMM targets support dim <= 8 (the reference forces dim = 2)");
-    if (x->wide) return fail(MFM_EUNSUPPORTED, "the wide kernel family serves the PhiFour and LGCP targets");
     std::vector<float> mode(K * d), sd(K * d), lw(K);
     for (int i = 0; i < K * d; ++i) { mode[i] = (float)p[1 + i]; sd[i] = (float)p[1 + K * d + i]; }
     for (int k = 0; k < K; ++k) {

@@ -633,6 +633,42 @@ __global__ __launch_bounds__(256) void target_kernel(TgtArgs a) {
   }
 }
 
+// The Gaussian mixtures (distributions.py:42-77; d <= 8, the reference forces 2): one thread per chain row walks the modes
+// (targets.cuh: gmm_eval).  Tangent mode: H z by the closed form; diag mode: H_jj from one unit tangent per coordinate.
+__global__ __launch_bounds__(256) void target_gmm_kernel(TgtArgs a) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= a.rows) return;
+  const size_t o = (size_t)row * a.dp;
+  const size_t zo = a.cmap ? (size_t)a.cmap[row] * a.dp : o;
+  float x[8], z[8], g[8], hv[8], hd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { x[j] = j < a.d ? a.X[o + j] : 0.f; z[j] = (a.Z && !a.diag && j < a.d) ? a.Z[zo + j] : 0.f; g[j] = hv[j] = hd[j] = 0.f; }
+  double lp;
+  gmm_eval<8>(a.T, x, &lp, g, (a.Z && !a.diag) ? z : nullptr, hv);
+  if (a.diag) {
+    for (int j = 0; j < a.d; ++j) {
+      float e[8], t[8], g2[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { e[i] = i == j ? 1.f : 0.f; t[i] = 0.f; }
+      gmm_eval<8>(a.T, x, &lp, g2, e, t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (i == j) hd[i] = t[i];
+    }
+  }
+  for (int col = 0; col < a.dp; ++col) {
+    float gc = 0.f, hz = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j == col && col < a.d) {
+        gc = clipf(g[j], a.clip);
+        const bool inside = !(a.clip > 0.f) || fabsf(g[j]) <= a.clip;
+        hz = inside ? (a.diag ? hd[j] : hv[j]) : 0.f;
+      }
+    a.GC[o + col] = gc;
+    if (a.HZ) a.HZ[o + col] = hz;
+  }
+}
+
 // x[r][c] *= act'(.) for c < cols (in place, float4 wide): the sx half of d[sx | st]
 struct ElemMask { int rows, cols, ld; float* x; const float* m; int kind, is_pre; };
 __global__ void elem_mask_kernel(ElemMask a) {
@@ -1049,6 +1085,7 @@ __global__ __launch_bounds__(256) void flow_accept_kernel(FlowGlue a) {
   if (b >= a.rows) return;
   const float* y = a.Y + (size_t)b * a.dp;
   double lpn;
+  float gmm_g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (a.T.kind == MFM_TARGET_PHI4) {
     double part = 0.0;
     for (int col = lane; col < a.d; col += 64) {
@@ -1061,6 +1098,13 @@ __global__ __launch_bounds__(256) void flow_accept_kernel(FlowGlue a) {
       part += -(double)a.T.tbeta * (0.5 * (double)a.T.coef * u + q * q / (4.0 * (double)a.T.coef));
     }
     lpn = a.beta * wave_sum(part);
+  } else if (a.T.kind == MFM_TARGET_GMM) {      // every lane walks the modes of its chain's row (d <= 8): tempered density beta * logprob
+    float xg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xg[j] = j < a.d ? y[j] : 0.f;
+    double lp;
+    gmm_eval<8>(a.T, xg, &lp, gmm_g);
+    lpn = a.beta * lp;
   } else {
     double lik = 0.0, quad = 0.0;
     for (int col = lane; col < a.d; col += 64) {
@@ -1084,6 +1128,10 @@ __global__ __launch_bounds__(256) void flow_accept_kernel(FlowGlue a) {
       if (a.T.kind == MFM_TARGET_PHI4) {
         const float xl = col > 0 ? y[col - 1] : 0.f, xr = col + 1 < a.d ? y[col + 1] : 0.f;
         gv = (float)a.beta * (-a.T.tbeta * (a.T.coef * (2.f * xv - xl - xr) - xv * (1.f - xv * xv) / a.T.coef));
+      } else if (a.T.kind == MFM_TARGET_GMM) {
+        gv = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j == col) gv = (float)a.beta * gmm_g[j];
       } else {
         gv = (float)a.beta * (a.T.counts[col] - a.T.poisson_a * expf(xv)) - a.KV[(size_t)b * a.dp + col];
       }
@@ -1375,6 +1423,7 @@ static void target_eval(Ctx* w, const NetDev& n, const float* X, const float* Z,
   t.T = n.T; t.clip = n.grad_clip; t.rows = rows; t.d = n.d; t.dp = n.dp; t.X = X; t.Z = Z; t.KV = w->kv; t.KZ = w->kz; t.GC = w->gc; t.HZ = (Z || diag) ? w->hz : nullptr;
   t.diag = diag ? 1 : 0;
   t.cmap = w->cmap_use;
+  if (n.T.kind == MFM_TARGET_GMM) { hipLaunchKernelGGL(target_gmm_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, t); return; }
   hipLaunchKernelGGL(target_kernel, dim3(grid_el((size_t)rows * n.dp)), dim3(256), 0, s, t);
 }
 

@@ -81,8 +81,7 @@ def phi4_setup(d=256, B=64, seed=1, hutch=True, hidden=128, F=128, **kw):
 
 
 def gmm4_setup(B=64, seed=1, hidden=32, F=16, **kw):
-    args = loop.default_args(example="4-mode", dim=2, num_chain=B, step_size=0.2, seed=seed, fourier_dim=F,
-                             hidden_x=[hidden, hidden], hidden_t=[hidden, hidden], hidden_xt=[hidden, hidden], **kw)
+    args = loop.default_args(example="4-mode", dim=2, num_chain=B, step_size=0.2, seed=seed, fourier_dim=F, **hidden_lists(hidden), **kw)
     dist = targets.GaussianMixture(8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4)
     k, model, state, lr_fn, _, _ = loop.setup(dist, args)
     return args, dist, k, model, state

@@ -199,3 +199,74 @@ def test_phi4_loop_with_other_depths_matches_oracle(width):
     s = ex["engine"].ctx.opt_state()
     assert (s["step"], s["count"]) == (out["state"].step, out["state"].count)
     ex["engine"].close()
+
+
+# ---- the Gaussian mixtures (d = 2) on the wide family: what `--example 4-mode --hidden_x h h h` needs -----------------------------------
+GMM_CASES = [("2-2-2", ([32, 32], [32, 32], [32, 32])), ("3-3-3", THREE), ("1-1-1", ONE), ("x1-t3-j2", MIXED)]
+
+
+def _gmm_ctx(hidden, B, **kw):
+    from mfm_amd import _lib
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.gmm4_setup(B=B, hidden=hidden, F=16, **kw)
+    params = gu.rand_params(model, seed=9, out_scale=0.3)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, family=_lib.FAMILY_WIDE)
+    return args, dist, model, params, ctx
+
+
+@pytest.mark.parametrize("name,hidden", GMM_CASES)
+def test_gmm_loss_gradient_field_and_jvp_on_the_wide_family(name, hidden):
+    import torch
+    from tests import gpu_util as gu
+    B, d = 32, 2
+    args, dist, model, params, ctx = _gmm_ctx(hidden, B)
+    x32 = dist.init_params.astype(np.float32)
+    key = prng.PRNGKey(11)
+    loss_o, grads_o = fm.loss_and_grad(model, params, key, x32.astype(np.float64), args.sigma)
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.full((ctx.n_params,), float("nan"), device="cuda")
+    ctx.fm_loss_grad(key, _dev(x32), loss, grads)
+    assert abs(loss.item() - loss_o) <= 2e-5 * abs(loss_o), (loss.item(), loss_o)
+    for i, (gg, go) in enumerate(zip(gu.unflat_params(model, grads.cpu().numpy()), grads_o)):
+        for kk in ("kernel", "bias"):
+            assert _relerr(gg[kk], go[kk].astype(np.float64)) < 2e-4, (i, kk, _relerr(gg[kk], go[kk]))
+    rng = np.random.default_rng(1)
+    t = rng.uniform(0, 1, B).astype(np.float32); z = rng.standard_normal((B, d)).astype(np.float32)
+    v_o, jv_o = model.forward(params, x32.astype(np.float64), t.astype(np.float64), tangent=z.astype(np.float64))
+    v = torch.empty(B, d, device="cuda"); jv = torch.empty(B, d, device="cuda")
+    ctx.vf_apply(_dev(x32), _dev(t), v, _dev(z), jv)
+    assert _relerr(v.cpu().numpy(), v_o) < 2e-5 and _relerr(jv.cpu().numpy(), jv_o) < 2e-5
+    ctx.close()
+
+
+@pytest.mark.parametrize("hutch", [True, False])
+@pytest.mark.parametrize("name,hidden", GMM_CASES)
+def test_gmm_flow_step_on_prescribed_steps_on_the_wide_family(name, hidden, hutch):
+    """Hutchinson and exact trace (the mixtures' default): H z / the diagonal of H of the mixture's log-density in the gate term."""
+    from tests.test_gpu_replay import _flow_replay_raw
+    B = 32
+    args, dist, model, params, ctx = _gmm_ctx(hidden, B, hutchs=hutch)
+    r = _flow_replay_raw(ctx, model, params, args, dist, 0.7, dist.init_params.astype(np.float32), prng.PRNGKey(31))
+    so, dg, info_o = r["so"], r["diag"], r["info_o"]
+    np.testing.assert_array_equal(r["n_g"], r["n_o"])
+    e_p = np.abs(r["prop"] - info_o.proposed_position).max()
+    e_v = max(np.abs(dg[:, 0] - so["vol0"]).max(), np.abs(dg[:, 1] - so["volp"]).max())
+    e_a = np.abs(dg[:, 3] - so["log_alpha"]).max()
+    print(f"gmm {name} hutch={hutch} flow step (wide): attempts {r['n_o'].mean():.0f}, |dx'| {e_p:.2e}, |dvol| {e_v:.2e}, |d log alpha| {e_a:.2e}")
+    assert r["n_o"].mean() > 10
+    assert e_p < 1e-4 * max(1.0, np.abs(info_o.proposed_position).max()) and e_v < 1e-3 and e_a < 5e-3      # the bounds of tests/test_gpu_d2tile.py
+    assert (r["isacc"] == info_o.is_accepted).mean() > 0.9
+    same = r["isacc"] == info_o.is_accepted
+    np.testing.assert_allclose(r["logp"][same], r["new_o"].logdensity[same], rtol=1e-4, atol=5e-3)
+    ctx.close()
+
+
+def test_four_mode_loop_with_three_hidden_layers_matches_oracle():
+    """``multi_modal.py --example 4-mode --hidden_x h h h --hidden_t h h h --hidden_xt h h h`` (exact trace, n_ts = 5)."""
+    from tests.test_gpu_loop import _run_both
+    out, res, ex = _run_both("4-mode", 2, 64, 12, 3, hutch=False, width=([32, 32, 32], [32, 32, 32], [32, 32, 32]), step_size=0.2)
+    tr, m = out["trace"], ex["metrics"]
+    np.testing.assert_allclose(m[:3, 0], tr["loss"][:3], rtol=1e-5)
+    np.testing.assert_allclose(m[:, 0], tr["loss"], rtol=5e-2)
+    np.testing.assert_allclose(ex["betas"], tr["beta"], rtol=2e-3)
+    assert np.isfinite(res).all()
+    ex["engine"].close()
