@@ -164,20 +164,23 @@ static void build_net(const mfm_config& c, NetDev& n) {
   n.nT = branch_widths(c.depth_t, c.hidden_t, c.hidden_t3, ht);
   n.nX = branch_widths(c.depth_x, c.hidden_x, c.hidden_x3, hx);
   n.nJ = branch_widths(c.depth_xt, c.hidden_xt, c.hidden_xt3, hj);
-  n.ht1 = ht[0]; n.ht2 = ht[n.nT - 1]; n.hx1 = hx[0]; n.hx2 = hx[n.nX - 1]; n.hj1 = hj[0]; n.hj2 = hj[n.nJ - 1];
+  // buffer widths: padded to 16 (a hidden unit of the padding has zero weights and bias on both sides: act(0) = 0 for all five
+  // activations, and its tangent / gradient meet zero weights -- exact)
+  n.ht1 = ceil16(ht[0]); n.ht2 = ceil16(ht[n.nT - 1]); n.hx1 = ceil16(hx[0]); n.hx2 = ceil16(hx[n.nX - 1]); n.hj1 = ceil16(hj[0]); n.hj2 = ceil16(hj[n.nJ - 1]);
   // flax creation order (exe_flow_matching.py:74-86): time branch, x branch, gate, joint branch, output
   int K[MLP_MAXL], N[MLP_MAXL], nl = 0, prev = 2 * c.fourier_dim;
   for (int i = 0; i < n.nT; ++i) { K[nl] = prev; N[nl] = ht[i]; prev = ht[i]; ++nl; }
   prev = c.dim;
   for (int i = 0; i < n.nX; ++i) { K[nl] = prev; N[nl] = hx[i]; prev = hx[i]; ++nl; }
-  K[nl] = n.ht2; N[nl] = c.dim; ++nl;
-  prev = n.hx2 + n.ht2;
+  K[nl] = ht[n.nT - 1]; N[nl] = c.dim; ++nl;
+  prev = hx[n.nX - 1] + ht[n.nT - 1];
+  const int joint0 = nl;
   for (int i = 0; i < n.nJ; ++i) { K[nl] = prev; N[nl] = hj[i]; prev = hj[i]; ++nl; }
-  K[nl] = n.hj2; N[nl] = c.dim; ++nl;
+  K[nl] = hj[n.nJ - 1]; N[nl] = c.dim; ++nl;
   int wo = 0, bo = 0, mo = 0;
   for (int l = 0; l < nl; ++l) {
     LayerDesc& L = n.L[l];
-    L.K = K[l]; L.N = N[l]; L.Kp = ceil16(K[l]); L.Np = ceil16(N[l]);
+    L.K = K[l]; L.N = N[l]; L.Kp = l == joint0 ? n.hx2 + n.ht2 : ceil16(K[l]); L.Np = ceil16(N[l]);      // [sx | st]: both halves padded (mlp.cuh: packed_row)
     L.w_off = wo; wo += L.Kp * L.Np;
     L.b_off = bo; bo += L.Np;
     L.m_w = mo; mo += K[l] * N[l];
@@ -216,14 +219,17 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
 
 static int create_impl(const mfm_config& c, mfm_ctx* x) {
   if (c.dim <= 0 || c.fourier_dim <= 0) return fail(MFM_EINVAL, "dim / fourier_dim must be positive");
+  bool ragged = false;          // a hidden width that is not a multiple of 16: zero-padded, wide family
   {
     int hs[3][MLP_MAX_DEPTH];
     const int nd[3] = {branch_widths(c.depth_t, c.hidden_t, c.hidden_t3, hs[0]), branch_widths(c.depth_x, c.hidden_x, c.hidden_x3, hs[1]),
                        branch_widths(c.depth_xt, c.hidden_xt, c.hidden_xt3, hs[2])};
     for (int b = 0; b < 3; ++b) {
       if (nd[b] < 0) return fail(MFM_EUNSUPPORTED, "a branch has 1 to %d hidden layers (depth_t / depth_x / depth_xt = %d / %d / %d)", MLP_MAX_DEPTH, c.depth_t, c.depth_x, c.depth_xt);
-      for (int i = 0; i < nd[b]; ++i)
-        if (hs[b][i] <= 0 || hs[b][i] % 16) return fail(MFM_EUNSUPPORTED, "hidden widths must be positive multiples of 16 (got %d)", hs[b][i]);
+      for (int i = 0; i < nd[b]; ++i) {
+        if (hs[b][i] <= 0) return fail(MFM_EINVAL, "hidden widths must be positive (got %d)", hs[b][i]);
+        ragged |= hs[b][i] % 16 != 0;
+      }
     }
   }
   if (c.n_chain_local <= 0 || c.n_chain_local % 16)
@@ -255,9 +261,10 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
   if (!(x->cfg.ref_std > 0.0)) return fail(MFM_EINVAL, "ref_std must be positive");
   bool use_wide = c.kernel_family == MFM_FAMILY_WIDE;
   const bool two_layer = n.nT == 2 && n.nX == 2 && n.nJ == 2;
-  if (!two_layer) {        // the fused tile kernels are written layer by layer for two hidden layers per branch; the wide family loops over them
+  if (!two_layer || ragged) {   // the fused tile kernels are written layer by layer for two hidden layers per branch, widths in whole MFMA tiles
     if (c.kernel_family == MFM_FAMILY_TILE)
-      return fail(MFM_EUNSUPPORTED, "hidden lists of %d / %d / %d layers (t / x / xt) run on the wide kernel family only", n.nT, n.nX, n.nJ);
+      return fail(MFM_EUNSUPPORTED, "hidden lists of %d / %d / %d layers (t / x / xt)%s run on the wide kernel family only", n.nT, n.nX, n.nJ,
+                  ragged ? " with widths that are not multiples of 16" : "");
     use_wide = true;
   } else {
     const FmLds L = fm_lds_layout(n, true);

@@ -40,7 +40,7 @@ struct LayerDesc {
 
 struct NetDev {
   int d, dp, F, F2p;
-  int ht1, ht2, hx1, hx2, hj1, hj2;   // multiples of 16: FIRST and LAST hidden width of the t / x / joint branch (the two widths of a two-layer branch)
+  int ht1, ht2, hx1, hx2, hj1, hj2;   // multiples of 16 (padded; the true widths are the layers' N): FIRST and LAST hidden width of the t / x / joint branch (the two widths of a two-layer branch)
   LayerDesc L[MLP_MAXL];              // flax creation order: t[0..nT), x[0..nX), gate, joint[0..nJ), out; unused slots: K = N = 0, m_w = m_b = n_params
   int nT, nX, nJ;                     // hidden layers per branch (2, 2, 2: the layer numbering above; anything else: wide family only)
   int n_params;          // canonical flat size
@@ -93,6 +93,14 @@ __host__ __device__ __forceinline__ int pack_index(int k, int n, int KB) {
 __host__ __device__ __forceinline__ int pack_index_T(int k, int n, int NB) {
   int kt = k >> 4, c = k & 15, nb = n >> 4, r = n & 15, g = r >> 2, s = r & 3;
   return (((kt * NB + nb) * 64) + g * 16 + c) * 4 + s;
+}
+
+// Row of a layer's PACKED K axis that canonical input row k feeds.  Hidden widths that are not multiples of 16 are zero-padded to one
+// (wide family only); the first joint layer reads [sx | st] with BOTH halves padded, so its st rows sit behind the padded sx half.
+__host__ __device__ __forceinline__ int packed_row(const NetDev& n, int layer, int k) {
+  if (layer != n.nT + n.nX + 1) return k;
+  const LayerDesc& lx = n.L[n.nT + n.nX - 1];
+  return k < lx.N ? k : k - lx.N + lx.Np;
 }
 
 // ---- the tile GEMM -------------------------------------------------------------------------------------------

@@ -162,7 +162,7 @@ __device__ __forceinline__ void adamw_element_t(const AdamArgs& a, int p, bool a
     a.bias[ld.b_off + (p - ld.m_b)] = w;
   } else {
     const int e = p - ld.m_w, k = e / ld.N, nn = e - k * ld.N;
-    int kk = k;
+    const int kk = packed_row(n, layer, k);
     a.Wp[ld.w_off + pack_index(kk, nn, ld.Kp / 16)] = w;
     a.WpT[ld.w_off + pack_index_T(kk, nn, ld.Np / 16)] = w;
   }
@@ -333,6 +333,7 @@ void launch_adamw(const AdamArgs& a, hipStream_t stream) {
     bl.first[l] = bl.n_blocks; bl.n_blocks += (a.net.L[l].K / 4) * (a.net.L[l].N / 4); bl.n_bias_items += a.net.L[l].N;
   }
   bl.first[MLP_MAXL] = bl.n_blocks;
+  vec &= packed_row(a.net, a.net.nT + a.net.nX + 1, a.net.L[a.net.nT + a.net.nX + 1].K - 1) == a.net.L[a.net.nT + a.net.nX + 1].K - 1;      // no row remap (mlp.cuh)
   if (vec) {
     const int items = bl.n_blocks + bl.n_bias_items, nbv = (items + 255) / 256;
     hipLaunchKernelGGL(adamw_vec_kernel, dim3(nbv < cap ? nbv : cap), block, 0, stream, a, bl);
@@ -353,8 +354,9 @@ __global__ void pack_kernel(NetDev n, const float* master, float* Wp, float* WpT
   if (p >= ld.m_b) bias[ld.b_off + (p - ld.m_b)] = w;
   else {
     const int e = p - ld.m_w, k = e / ld.N, nn = e - k * ld.N;
-    Wp[ld.w_off + pack_index(k, nn, ld.Kp / 16)] = w;
-    WpT[ld.w_off + pack_index_T(k, nn, ld.Np / 16)] = w;
+    const int kk = packed_row(n, layer, k);
+    Wp[ld.w_off + pack_index(kk, nn, ld.Kp / 16)] = w;
+    WpT[ld.w_off + pack_index_T(kk, nn, ld.Np / 16)] = w;
   }
 }
 void launch_pack(const NetDev& n, const float* master, float* Wp, float* WpT, float* bias, hipStream_t stream) {

@@ -414,7 +414,8 @@ static void launch_gemm(const Gemm& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Weight gradients: dW[k][n] = sum_r A[r][k] dZ[r][n], db[n] = sum_r dZ[r][n]; one wave per 64 x 64 block of dW.
 // ---------------------------------------------------------------------------------------------------------------------
-struct WgLayer { const float* A; int lda; const float* Z; int ldz; int K, N, Kp, Np, m_w, m_b; };
+struct WgLayer { const float* A; int lda; const float* Z; int ldz; int K, N, Kp, Np, m_w, m_b;
+                 int ks_true, ks_pad; };      // input columns [ks_true, ks_pad) are padding, column c >= ks_pad is canonical row c - ks_pad + ks_true (the first joint layer, mlp.cuh: packed_row)
 struct WgJob { int layer, kt, nt; };
 struct WgArgs { WgLayer L[MLP_MAXL]; const WgJob* jobs; int n_jobs; int rows; float* grads;
                 int* bad;      // non-null: raise *bad when a gradient element is not finite (the optimizer's apply_if_finite check)
@@ -512,7 +513,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int k = 64 * J.kt + 4 * (4 * g + i) + s;
+      int k = 64 * J.kt + 4 * (4 * g + i) + s;
+      if (k >= L.ks_true) {
+        if (k < L.ks_pad) continue;
+        k -= L.ks_pad - L.ks_true;
+      }
       if (k >= L.K) continue;
 #pragma unroll
       for (int u = 0; u < 4; ++u) if (zc + u < L.N) chk += 0.f * acc[s][u][i];
@@ -1232,15 +1237,24 @@ __global__ __launch_bounds__(256) void lgcp_accept_kernel(LgcpMala a) {
 // the hx1 rows of a chain to its mask row) and is contracted with column i of E (jt_trace_kernel).  Per chain and evaluation
 // 2 hx1 (hx2 hj1 + hj1 hj2) flop -- 4.3 GFLOP at hidden 1024, whatever d is (d-tangent form: 10 GFLOP at d = 1600).  The gate term
 // of the field, gate_i clip(g_i(x)), adds gate_i 1[|g_i| <= clip] H_ii (target_kernel's diag mode; stage_finish sums it).
-struct JtSeed { int chains, hx1, hx2, row0; const float* W; const float* m1; int ld1; const float* m2; int ld2; int kind, is_pre; float* X; };
+struct JtSeed { int chains, hx1, hx2, row0; const float* W; int rows_w, cols_w;      // canonical kernel [rows_w][cols_w] (true sizes; hx1 / hx2: padded)
+                const float* m1; int ld1; const float* m2; int ld2; int kind, is_pre; float* X; };
 __global__ __launch_bounds__(256) void jt_seed_kernel(JtSeed a) {
   const int c4 = a.hx2 / 4;
   const size_t tot = (size_t)a.chains * a.hx1 * c4;
+  const bool vec = (a.cols_w & 3) == 0;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * 256) {
     const int j4 = (int)(idx % c4);
     const size_t r = idx / c4;
     const int i = (int)(r % a.hx1), b = (int)(r / a.hx1);
-    f32x4 v = *reinterpret_cast<const f32x4*>(a.W + (size_t)i * a.hx2 + 4 * j4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < a.rows_w) {           // a padded unit of x1 has no row (and act'(0) is not 0 for every activation)
+      if (vec && 4 * j4 + 3 < a.cols_w) v = *reinterpret_cast<const f32x4*>(a.W + (size_t)i * a.cols_w + 4 * j4);
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * j4 + j < a.cols_w) v[j] = a.W[(size_t)i * a.cols_w + 4 * j4 + j];
+      }
+    }
     const float s1 = a.m1[(size_t)(a.row0 + b) * a.ld1 + i];
     const f32x4 s2 = *reinterpret_cast<const f32x4*>(a.m2 + (size_t)(a.row0 + b) * a.ld2 + 4 * j4);
 #pragma unroll
@@ -1530,7 +1544,9 @@ static int fm(Ctx* w, const NetDev& n, const FmCall& c, bool train, float* d_gra
   WgArgs a; memset(&a, 0, sizeof a);
   auto wg = [&](int l, const float* A, int lda, const float* Z, int ldz) {
     const LayerDesc& L = n.L[l];
-    a.L[l] = WgLayer{A, lda, Z, ldz, L.K, L.N, L.Kp, L.Np, L.m_w, L.m_b};
+    const bool j0 = l == w->lj[0];
+    const LayerDesc& Lx = n.L[w->lx[w->nX - 1]];
+    a.L[l] = WgLayer{A, lda, Z, ldz, L.K, L.N, L.Kp, L.Np, L.m_w, L.m_b, j0 ? Lx.N : L.Kp, j0 ? Lx.Np : L.Kp};
   };
   for (int i = 0; i <= tl; ++i) wg(w->lt[i], i == 0 ? w->ffat : w->ta[i - 1], i == 0 ? n.F2p : w->ht[i - 1], i == tl ? w->dcat + n.hx2 : w->dta[i], i == tl ? w->cat : w->ht[i]);
   for (int i = 0; i <= xl; ++i) wg(w->lx[i], i == 0 ? w->cond : w->xa[i - 1], i == 0 ? n.dp : w->hx[i - 1], i == xl ? w->dcat : w->dxa[i], i == xl ? w->cat : w->hx[i]);
@@ -1562,6 +1578,7 @@ static int jt_alloc(Ctx* w, const NetDev& n) {
   if (hipMalloc((void**)&w->jtE, (size_t)n.hj2 * n.hx1 * sizeof(float)) != hipSuccess) return -4;
   if (hipMalloc((void**)&w->jtET, (size_t)n.hj2 * n.hx1 * sizeof(float)) != hipSuccess) return -4;
   if (hipMalloc((void**)&w->jtWo, (size_t)n.hj2 * n.dp * sizeof(float)) != hipSuccess) return -4;
+  (void)hipMemset(w->jtWo, 0, (size_t)n.hj2 * n.dp * sizeof(float));
   if (hipMalloc((void**)&w->jtP, (size_t)w->R * JT_SLICES * sizeof(float)) != hipSuccess) return -4;
   w->jt_chains = chains;
   return 0;
@@ -1569,7 +1586,8 @@ static int jt_alloc(Ctx* w, const NetDev& n) {
 // E^T, E = W_out W_x1 (the parameters do not change inside a solve): rows of the canonical out kernel [hj2][d] as the "activations"
 // of the x1 layer's packed weights, then a transpose so that jt_trace_kernel reads row i of E^T beside tangent row i
 static void jt_setup(Ctx* w, const NetDev& n, hipStream_t s) {
-  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_el((size_t)n.hj2 * n.dp)), dim3(256), 0, s, w->master + n.L[w->l_out].m_w, n.hj2, n.d, n.dp, w->jtWo);
+  const int hj_true = n.L[w->l_out].K;          // rows of the canonical out kernel (jtWo's rows beyond them stay zero: jt_alloc)
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_el((size_t)hj_true * n.dp)), dim3(256), 0, s, w->master + n.L[w->l_out].m_w, hj_true, n.d, n.dp, w->jtWo);
   Gemm g = fwd(n, w->lx[0], w->jtWo, n.dp, w->jtE, n.hx1, 0, n.hj2, 0);
   g.bias = nullptr;
   launch_gemm(g, s);
@@ -1596,6 +1614,7 @@ static void exact_trace(Ctx* w, const NetDev& n, int rows, hipStream_t s) {
     float *cur = w->jtA, *nxt = w->jtB;
     JtSeed sd; memset(&sd, 0, sizeof sd);
     sd.chains = C; sd.hx1 = n.hx1; sd.hx2 = hops[0].width; sd.row0 = r0; sd.W = w->master + n.L[hops[0].layer].m_w;      // rows [0, hx1) of the canonical kernel
+    sd.rows_w = n.L[w->lx[0]].N; sd.cols_w = n.L[hops[0].layer].N;
     sd.m1 = m1; sd.ld1 = ld1; sd.m2 = hops[0].m; sd.ld2 = hops[0].ldm; sd.kind = n.act; sd.is_pre = pre; sd.X = cur;
     hipLaunchKernelGGL(jt_seed_kernel, dim3(grid_el((size_t)trows * hops[0].width / 4)), dim3(256), 0, s, sd);
     for (int h = 1; h < nh; ++h) {

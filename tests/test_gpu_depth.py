@@ -14,7 +14,9 @@ ONE = ([32], [32], [32])
 THREE = ([32, 48, 32], [48, 32, 16], [64, 32, 48])
 MIXED = ([48], [32, 16, 32], [32, 64])          # one x layer: its output IS sx; three t layers; two joint layers
 MIXED2 = ([32, 48], [16], [32, 16, 32])
-DEPTHS = {"1-1-1": ONE, "3-3-3": THREE, "x1-t3-j2": MIXED, "x2-t1-j3": MIXED2}
+RAGGED = ([20, 50], [30, 24], [100, 36])        # widths that are not multiples of 16 (multi_modal.py:178-180 takes any int): zero-padded
+RAGGED3 = ([24, 40, 20], [10], [50])
+DEPTHS = {"1-1-1": ONE, "3-3-3": THREE, "x1-t3-j2": MIXED, "x2-t1-j3": MIXED2, "ragged": RAGGED, "ragged-x3-t1-j1": RAGGED3}
 
 
 def _dev(x, dtype=None):
@@ -148,7 +150,7 @@ def test_transform_on_prescribed_steps_matches_oracle(depth, direction, hutch):
     ctx.close()
 
 
-@pytest.mark.parametrize("depth,hutch", [("1-1-1", False), ("3-3-3", True), ("x1-t3-j2", True), ("x2-t1-j3", False)])
+@pytest.mark.parametrize("depth,hutch", [("1-1-1", False), ("3-3-3", True), ("x1-t3-j2", True), ("x2-t1-j3", False), ("ragged", False), ("ragged-x3-t1-j1", True)])
 def test_flow_step_on_prescribed_steps_matches_oracle(depth, hutch):
     from tests import gpu_util as gu
     from tests.test_gpu_replay import _flow_replay_raw
@@ -174,9 +176,9 @@ def test_flow_step_on_prescribed_steps_matches_oracle(depth, hutch):
     ctx.close()
 
 
-@pytest.mark.parametrize("width", [([32, 32, 32], [32, 32, 32], [32, 32, 32]), ([32], [32], [32])], ids=["three", "one"])
+@pytest.mark.parametrize("width", [([32, 32, 32], [32, 32, 32], [32, 32, 32]), ([32], [32], [32]), ([100, 100], [100, 100], [100, 100])], ids=["three", "one", "hundred"])
 def test_phi4_loop_with_other_depths_matches_oracle(width):
-    """``multi_modal.py --example phi-four --hidden_x h h h --hidden_t h h h --hidden_xt h h h`` (and one layer per branch) through the
+    """``multi_modal.py --example phi-four --hidden_x h h h --hidden_t h h h --hidden_xt h h h`` (one layer per branch; width 100) through the
     Python front end against the oracle's loop: traces before the first flow step at rounding, then the bounds of tests/test_gpu_loop.py."""
     from tests.test_gpu_loop import _run_both
     out, res, ex = _run_both("phi-four", 64, 64, 12, 3, width=width, step_size=1e-4)
@@ -202,7 +204,7 @@ def test_phi4_loop_with_other_depths_matches_oracle(width):
 
 
 # ---- the Gaussian mixtures (d = 2) on the wide family: what `--example 4-mode --hidden_x h h h` needs -----------------------------------
-GMM_CASES = [("2-2-2", ([32, 32], [32, 32], [32, 32])), ("3-3-3", THREE), ("1-1-1", ONE), ("x1-t3-j2", MIXED)]
+GMM_CASES = [("2-2-2", ([32, 32], [32, 32], [32, 32])), ("3-3-3", THREE), ("1-1-1", ONE), ("x1-t3-j2", MIXED), ("ragged", RAGGED)]
 
 
 def _gmm_ctx(hidden, B, **kw):
