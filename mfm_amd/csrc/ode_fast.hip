@@ -1041,7 +1041,13 @@ __device__ __forceinline__ void solve(FTile<D>& T, float rtol, float atol, int m
         const float ratio = sqrtf((e2 + rr * rr) * inv_n);
         bool acc = active && ratio <= 1.f;
         const float dfac = ratio < 1.f ? 1.f : 0.2f;
+#ifdef MFM_LIB_POW
         const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
+#else
+    // ratio^(-1/5) through the hardware's log2 / exp2 (1 ulp each; ratio is a non-negative finite number or NaN here): the library's
+    // powf spends ~150 dependent instructions on cases this call cannot meet, on ONE wave while the other seven wait at the barrier
+        const float fac = fminf(10.f, fmaxf(0.9f * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(ratio)), dfac));
+#endif
         float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
         if constexpr (RP) {
           if (active) {
@@ -1180,7 +1186,11 @@ __device__ __forceinline__ int leaders_end_of_attempt(FTile<D>& T, const AA& a, 
     const float ratio = sqrtf((e2 + rr * rr) * inv_n);
     bool acc = active && ratio <= 1.f;
     const float dfac = ratio < 1.f ? 1.f : 0.2f;
+#ifdef MFM_LIB_POW
     const float fac = fminf(10.f, fmaxf(0.9f * powf(ratio, -0.2f), dfac));
+#else
+    const float fac = fminf(10.f, fmaxf(0.9f * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(ratio)), dfac));      // (see solve)
+#endif
     float ndt = fmaxf(ratio == 0.f ? dti * 10.f : dti * fac, 0.f);
     if constexpr (RP) {
       if (active) {
@@ -1779,6 +1789,10 @@ __device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
   if (g_flow_dbg && threadIdx.x == 0) {      // cumulative over the launches of a process: tools/flow_cycles.py takes differences
     unsigned long long* o = g_flow_dbg + blockIdx.x * 64;
     o[54 + 2 * (P - 1)] += __builtin_amdgcn_s_memtime() - tp0_; o[55 + 2 * (P - 1)] += tp_att_;
+    if (P == 1) {                             // inside the one-pass tail: its evaluations and time batches (second half of the buffer)
+      unsigned long long* o4 = g_flow_dbg + (blockIdx.x + gridDim.x) * 64;
+      o4[54] += T.n_em; o4[55] += T.cyc_em; o4[56] += T.n_t1; o4[57] += T.cyc_t1;
+    }
   }
 #endif
   // ---- leave: the rows that are still live are ranked again and their state goes to STG[new rank]; a row that ended here leaves

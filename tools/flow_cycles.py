@@ -3,7 +3,7 @@ share of the solver loop outside the field evaluation, shader clock, attempt sta
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["MFM_LIB"] = os.path.join(ROOT, "mfm_amd/lib/libmfm_hip_stamps.so")
+os.environ["MFM_LIB"] = os.path.join(ROOT, "mfm_amd/lib/" + os.environ.get("MFM_CYC_LIB", "libmfm_hip_stamps.so") + "")
 import numpy as np, torch
 import bench
 from mfm_amd import exe_flow_matching as E, random as jr
@@ -80,6 +80,12 @@ for count in range(1, 304):
         for P in (1, 2, 3):
             cc, nn = tl_now[:, 2 * (P - 1)], tl_now[:, 2 * (P - 1) + 1]
             if nn.sum() > 0: print(f"   tail loop P = {P}: attempts per WG mean {nn.mean():.1f}, cycles per attempt {cc.sum() / nn.sum() / 1e3:.1f}k")
+        t4 = dall[1][:, 54:58].copy()
+        t4_now = t4 - t4_prev if "t4_prev" in globals() else t4
+        t4_prev = t4
+        if t4_now[:, 0].sum() > 0:
+            print(f"   inside the P = 1 tail: cycles per evaluation {t4_now[:, 1].sum() / t4_now[:, 0].sum() / 1e3:.2f}k, per time batch {t4_now[:, 3].sum() / max(t4_now[:, 2].sum(), 1) / 1e3:.2f}k "
+                  f"(6 evaluations + 1 batch = {(6 * t4_now[:, 1].sum() / t4_now[:, 0].sum() + t4_now[:, 3].sum() / max(t4_now[:, 2].sum(), 1)) / 1e3:.1f}k of the attempt)")
         print(f"   tile done (before the noise work): mean {done.mean()/1e6:.1f}M max {done.max()/1e6:.1f}M mean/max {done.mean()/done.max():.3f} | time in the tail loops: mean {d[:,52].mean()/1e6:.1f}M")
         natt_main = d[:, 5] + d[:, 28]
         for nm, dd in (("wave 0", d), ("wave 4", d4)):
