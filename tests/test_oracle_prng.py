@@ -84,3 +84,20 @@ def test_32_bit_draws_match_values_published_in_the_jax_documentation():
     assert abs(float(prng.normal32(key)) - (-0.18471177)) < 1e-7
     _, subkey = prng.split(key)
     assert prng.normal32(subkey) == np.float32(1.3694694)
+    # the jax quickstart's first example, ``random.normal(random.PRNGKey(0), (10,))``: TEN draws of one key -- pins the counter layout of a
+    # multi-element request (threefry over iota, the two output words laid end to end), which the scalar values above cannot see
+    quick = np.array([-0.3721109, 0.26423115, -0.18252768, -0.7368197, -0.44030377, -0.1521442, -0.67135346, -0.5908641, 0.73168886, 0.5673026])
+    np.testing.assert_allclose(prng.normal32(prng.PRNGKey(0), (10,)), quick, rtol=0, atol=1.5e-7)      # (erfinv's last bits, as above)
+    assert abs(float(prng.normal32(prng.PRNGKey(0))) - (-0.20584226)) < 1e-7                              # ``random.normal(key)``, same page
+
+
+def test_64_bit_draws_use_the_counter_layout_the_published_32_bit_vector_pins():
+    """The reference runs with jax_enable_x64 (``multi_modal.py:14``): 64-bit draws take TWO 32-bit words per element from the same
+    counter construction.  No published values exist for that mode; what can be checked is that the 64-bit path is the 32-bit path's
+    construction on twice the words: the high words of ``random_bits64`` of n elements are the first n words of ``random_bits32`` of 2 n."""
+    k = prng.PRNGKey(7)
+    for n in (10, 7, 1):
+        b64 = np.asarray(prng.random_bits64(k, n), dtype=np.uint64)
+        b32 = prng.random_bits32(k, 2 * n)
+        np.testing.assert_array_equal((b64 >> np.uint64(32)).astype(np.uint32), b32[:n])
+        np.testing.assert_array_equal((b64 & np.uint64(0xFFFFFFFF)).astype(np.uint32), b32[n:])
