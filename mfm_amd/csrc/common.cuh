@@ -20,6 +20,7 @@ struct Switches {
   int d2_tile = 0;          // 0: automatic; 16: generic tile; 4: 4-chain tiles; 5: "4s", the streamed 4-chain tile
   bool wide_nolds = false, wide_no_small_tiles = false, wide_wm1 = false, wide_ring8 = false, wide_wgrad_nosplit = false;
   bool wide_nocompact = false, wide_no_tbatch = false;
+  int flow_live = 0;        // chains per workgroup of the shape-specialised flow step: 0 automatic, 16 / 8 / 4 / 2 forced (ode_fast.hip: flow_live_rows)
 };
 static Switches g_sw;
 static void switches_read() {
@@ -34,6 +35,7 @@ static void switches_read() {
   s.wide_nolds = on("MFM_WIDE_NOLDS"); s.wide_no_small_tiles = on("MFM_WIDE_NO_SMALL_TILES"); s.wide_wm1 = on("MFM_WIDE_WM1");
   s.wide_ring8 = on("MFM_WIDE_RING8"); s.wide_wgrad_nosplit = on("MFM_WIDE_WGRAD_NOSPLIT");
   s.wide_nocompact = on("MFM_WIDE_NOCOMPACT"); s.wide_no_tbatch = on("MFM_WIDE_NO_TBATCH");
+  if (const char* e = getenv("MFM_FLOW_LIVE")) s.flow_live = atoi(e);
   g_sw = s;
 }
 

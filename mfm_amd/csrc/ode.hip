@@ -31,12 +31,26 @@ static thread_local const PadWs* t_pad = nullptr;      // the padded images of t
                                                         // kept out of the kernel arguments (two more words there cost the headline kernel 2 %)
 #define ODE_FAST_MAX_WGS 1024                 // grid cap of the shape-specialised transform kernel (it loops over tiles)
 #define ODE_FAST_SCR_F4 (5 * 8 * 3 * 64)      // float4 of time-branch scratch per workgroup (ode_fast.hip)
+// Chains per workgroup of the flow step.  A tile of 16 chains per workgroup is the cheapest per chain (233 k cycles per attempted step
+// for 16 rows), but a launch with fewer tiles than CUs leaves the rest of the chip idle while every tile walks its ~330 attempts in
+// lock-step: the same chains spread over more workgroups, 8 / 4 / 2 per tile with the other rows marked done, run in the tile's
+// compact (198 k per attempt), two-pass (152 k) or one-pass (92 k) layout from the second attempt on.  The reference's phi-four default
+// is 1024 chains (multi_modal.py:52-55): 64 tiles -> 256 workgroups of 4.  A row's arithmetic depends on the layout its tile runs in
+// (float reassociations), so the choice is a function of the chain count only.  MFM_FLOW_LIVE forces it (tests, A/B).
+static int flow_live_rows(int n_chains) {
+  if (g_sw.flow_live == 16 || g_sw.flow_live == 8 || g_sw.flow_live == 4 || g_sw.flow_live == 2) return g_sw.flow_live;
+  int live = 16;
+  while (live > 2 && n_chains / (live / 2) <= 256) live /= 2;
+  return live;
+}
+
 static int ode_ws_alloc(const NetDev& n, const mfm_config& c, OdeWs& w) {
   w.rows = (size_t)(c.max_eval_samples > c.n_chain_local ? c.max_eval_samples : c.n_chain_local);
   if (hipMalloc((void**)&w.noise, 3 * w.rows * n.d * sizeof(float)) != hipSuccess) return -4;
   const size_t t_all = w.rows / 16, t_chain = (size_t)c.n_chain_local / 16;
   w.fast_wgs = t_all < ODE_FAST_MAX_WGS ? t_all : ODE_FAST_MAX_WGS;
-  if (w.fast_wgs < t_chain) w.fast_wgs = t_chain;        // the flow step runs one workgroup per tile of 16 chains
+  const size_t t_flow = (size_t)c.n_chain_local / flow_live_rows(c.n_chain_local);      // the flow step runs one workgroup per 16 (8 / 4 / 2) chains
+  if (w.fast_wgs < t_flow) w.fast_wgs = t_flow;
   memset(&w.pad, 0, sizeof w.pad);
   if (c.hutch && n.nT == 2 && n.nX == 2 && n.nJ == 2 && n.T.kind == MFM_TARGET_PHI4 && n.act == MFM_ACT_RELU && n.F == 128 && n.ht1 == 128 && n.ht2 == 128 && n.hx1 == 128 &&
       n.hx2 == 128 && n.hj1 == 128 && n.hj2 == 128 && n.d >= 16 && n.d < 256 && n.d != 128 && n.d % 16 == 0) {

@@ -1146,7 +1146,7 @@ __device__ __forceinline__ int leaders_end_of_attempt(FTile<D>& T, const AA& a, 
   };
   if (mode == (float)RM_INIT0) {
     // f0 sits in k[1] (slot 0 of the attempt): initial step size, part 1
-    if (R1(RS_SOLVE) != 0.f && f.mode == MFM_FLOW_IMH)                 // ref.logprob(u0) - ref.logprob(up)  (:254-255)
+    if (R1(RS_SOLVE) != 0.f && (f.mode & 0xFF) == MFM_FLOW_IMH)        // ref.logprob(u0) - ref.logprob(up)  (:254-255); (bits 8..: flow_live_rows)
       R1(RS_LQ) = -0.5f * (sum8(S::RED + 4 * 128) - sum8(S::RED + 5 * 128)) / (f.ref_std * f.ref_std);
     const float dl0 = dlsum(S::DLP + 1 * 128);
     const float a1 = dl0 / atol;
@@ -1838,7 +1838,7 @@ __device__ __noinline__ void solve2_tail(TailArgs a, int b0) {
 // ignored.  Per-row arithmetic (controller, interpolation, step sizes) is that of solve() bit for bit.
 // On return: y = proposal x' at t = 1 of the forward solve, row state holds ell (forward), vol0 (inverse), lq, counts.
 template <int D, bool RP, bool PAD>
-__device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const FlowArgs& f, int b0, float (&y)[FTile<D>::TPW][4]) {
+__device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const FlowArgs& f, int b0, float (&y)[FTile<D>::TPW][4], int live, int fmode) {
   using S = FS<D>;
   constexpr int TPW = FTile<D>::TPW, LDX = S::LDX;
   const int g = T.g, c = T.c, wave = T.wave;
@@ -1858,6 +1858,12 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
 #pragma unroll
     for (int fld = 0; fld < 24; ++fld) T.rs_put(fld, z4);      // mode INIT0, solve 0, t = 0, dt = 0
     T.rs_put(RS_SIGN, m1);                                     // inverse solve first (:267 / :251)
+    if (live < 16) {          // rows without a chain: done from the start, so that the tile runs in the layout of its live rows
+      float md[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) md[i] = 4 * g + i < live ? 0.f : (float)RM_DONE;
+      T.rs_put(RS_MODE, md);
+    }
     if (threadIdx.x == 0) *T.at(0, S::RS + RS_TILE * 16 + 2) = 1.f;      // every row starts in an initial-step phase
   }
   f32x4 P[4], Q[4];
@@ -2025,7 +2031,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
             const int col = 16 * (wave + NW * q) + c;
             const size_t o = (size_t)(b0 + 4 * g + i) * D + col;
             const float nz = a.zgen[o];
-            if (f.mode == MFM_FLOW_RWMH) yn = yn + scale * nz;                                        // :268
+            if (fmode == MFM_FLOW_RWMH) yn = yn + scale * nz;                                         // :268
             else { const float up = f.ref_std * nz; r0[i] += yn * yn; r1[i] += up * up; yn = up; }      // :249
             *T.at(T.o_xo, S::ZB + i * LDX + 128 * q) = a.z2[o];                                        // key_hutch1
 #pragma unroll
@@ -2035,7 +2041,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
         }
       }
       if (tile_sw) {                         // tile-uniform
-        if (f.mode == MFM_FLOW_IMH) { T.part_put(S::RED + 4 * 128, r0); T.part_put(S::RED + 5 * 128, r1); }
+        if (fmode == MFM_FLOW_IMH) { T.part_put(S::RED + 4 * 128, r0); T.part_put(S::RED + 5 * 128, r1); }
         __syncthreads();                     // the new probe rows are visible
         load_group<1, 0>(P, T.wtr, T.W(S::W7, wave, D / 16), T.lane);
         T.precompute_w7z(P, Q);              // W_out z and z W_x1 of every row (unchanged rows recompute the same values)
@@ -2073,7 +2079,7 @@ __device__ __forceinline__ void solve2(FTile<D>& T, const OdeArgs& a, const Flow
       TailArgs ta;
       ta.rtol = a.rtol; ta.atol = a.atol; ta.max_attempts = a.max_attempts; ta.d_true = a.net.d;
       ta.coef = a.net.T.coef; ta.tbeta = a.net.T.tbeta; ta.clip = a.net.grad_clip; ta.fourier = a.net.fourier; ta.Wp = a.net.Wp;
-      ta.zgen = a.zgen; ta.z2 = a.z2; ta.mode = f.mode; ta.ref_std = f.ref_std; ta.rp = a.rp;
+      ta.zgen = a.zgen; ta.z2 = a.z2; ta.mode = fmode; ta.ref_std = f.ref_std; ta.rp = a.rp;
 #pragma unroll 1
       for (;;) {
         const int live = __popcll(__ballot(*T.at((T.lane & 15) * 4, S::RS + RS_RANK * 16) >= 0.f) & 0xFFFFull);
@@ -2128,14 +2134,18 @@ __device__ __forceinline__ void tile_init(FTile<D>& T, const NetDev& n, float* l
   __syncthreads();
 }
 
+// (`live` < 16: the tile carries chains in its first `live` rows only; the other rows read the last of them -- finite values, never used)
 template <int D>
-__device__ __forceinline__ void fill_probe(FTile<D>& T, const float* z, int b0) {
+__device__ __forceinline__ void fill_probe(FTile<D>& T, const float* z, int b0, int live = 16) {
   using S = FS<D>;
 #pragma unroll
   for (int q = 0; q < FTile<D>::TPW; ++q) {
     const int col = 16 * (T.wave + NW * q) + T.c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *T.at(T.o_xo, S::ZB + i * S::LDX + 128 * q) = z[(size_t)(b0 + 4 * T.g + i) * D + col];
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * T.g + i;
+      *T.at(T.o_xo, S::ZB + i * S::LDX + 128 * q) = z[(size_t)(b0 + (r < live ? r : live - 1)) * D + col];
+    }
   }
 }
 
@@ -2186,17 +2196,23 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
   const unsigned long long fc0_ = __builtin_amdgcn_s_memtime(), fr0_ = __builtin_amdgcn_s_memrealtime();
 #endif
   tile_init(T, a.net, lds, scratch + (size_t)blockIdx.x * SCR_F4_PER_WG);
-  const int b0 = blockIdx.x * 16, g = T.g, c = T.c, wave = T.wave;
+  // f.mode = flow kernel (bits 0..7) | chains per workgroup (bits 8..; 0 = 16): with fewer tiles than CUs the launch gives every
+  // workgroup 8 / 4 / 2 chains in the first rows of its tile and marks the other rows done (flow_live_rows)
+  const int live = (f.mode >> 8) ? (f.mode >> 8) : 16, fmode = f.mode & 0xFF;
+  const int b0 = blockIdx.x * live, g = T.g, c = T.c, wave = T.wave;
+  int rsrc[4];                           // chain a row READS (rows without a chain: the last one of the workgroup)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rsrc[i] = b0 + (4 * g + i < live ? 4 * g + i : live - 1);
   float y[TPW][4], ell[4], vol0[4], lq_ref[4];
   int natt_tot[4];
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     const int col = 16 * (wave + NW * q) + c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[q][i] = f.pos[(size_t)(b0 + 4 * g + i) * D + col];                 // :267 / :251
+    for (int i = 0; i < 4; ++i) y[q][i] = f.pos[(size_t)rsrc[i] * D + col];                          // :267 / :251
   }
-  fill_probe(T, a.z1, b0);               // key_hutch2: probe of the inverse solve (the forward probe is loaded per row)
-  solve2<D, RP, PAD>(T, a, f, b0, y);    // inverse solve -> proposal -> forward solve, per row
+  fill_probe(T, a.z1, b0, live);         // key_hutch2: probe of the inverse solve (the forward probe is loaded per row)
+  solve2<D, RP, PAD>(T, a, f, b0, y, live, fmode);    // inverse solve -> proposal -> forward solve, per row
   {
     const f32x4 e4 = T.rs_get(RS_ELL), v4 = T.rs_get(RS_VOL0), l4 = T.rs_get(RS_LQ), n0 = T.rs_get(RS_NTOT), n1 = T.rs_get(RS_NATT);
 #pragma unroll
@@ -2244,7 +2260,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
   float aprob[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int b = b0 + 4 * g + i;
+    const int b = rsrc[i];
     const Key2 kb = split_at(f.key, f.n_total, f.chain_offset + (uint32_t)b);             // :303
     const double lp_old = f.logp[b];
     const double la = lpn[i] - (double)ell[i] - lp_old - (double)vol0[i] + (double)lq_ref[i];
@@ -2253,7 +2269,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
     acc[i] = u <= ap;                     // NaN compares false -> reject
     aprob[i] = (float)ap;
     if constexpr (RP) {
-      if (a.rp.diag && wave == 0 && c == 0) { double* o = a.rp.diag + 4 * (size_t)b; o[0] = vol0[i]; o[1] = ell[i]; o[2] = lpn[i]; o[3] = la; }
+      if (a.rp.diag && wave == 0 && c == 0 && 4 * g + i < live) { double* o = a.rp.diag + 4 * (size_t)b; o[0] = vol0[i]; o[1] = ell[i]; o[2] = lpn[i]; o[3] = la; }
     }
   }
   __syncthreads();      // every wave has read the OLD log-densities before wave 0 publishes the accepted ones
@@ -2262,6 +2278,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
     const int col = 16 * (wave + NW * q) + c;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (4 * g + i >= live) continue;
       const size_t o = (size_t)(b0 + 4 * g + i) * D + col;
       if (f.proposed) f.proposed[o] = y[q][i];
       if (acc[i]) { f.pos[o] = y[q][i]; f.grad[o] = gnew[q][i]; }
@@ -2270,6 +2287,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
   if (wave == 0 && c == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (4 * g + i >= live) continue;
       const int b = b0 + 4 * g + i;
       if (acc[i]) f.logp[b] = lpn[i];
       if (f.acc_prob) f.acc_prob[b] = aprob[i];
@@ -2383,11 +2401,13 @@ static int launch_flow_tr(const OdeArgs& a0, const FlowArgs& f0, const NoiseArgs
     pad_rows(f0.pos, w.img[0], a.n, d, D, stream); pad_rows(f0.grad, w.img[1], a.n, d, D, stream);
     f.pos = w.img[0]; f.grad = w.img[1]; f.proposed = f0.proposed ? w.img[2] : nullptr;
   }
+  const int live = flow_live_rows(a.n);
+  f.mode = (f0.mode & 0xFF) | (live == 16 ? 0 : live << 8);
   if (d != D) {
     (void)hipFuncSetAttribute((const void*)flow_step_fast_kernel<D, RP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL((flow_step_fast_kernel<D, RP, true>), dim3(a.n / 16), dim3(NW * 64), sm, stream, a, f, nz, scratch);
+    hipLaunchKernelGGL((flow_step_fast_kernel<D, RP, true>), dim3(a.n / live), dim3(NW * 64), sm, stream, a, f, nz, scratch);
   } else {
-    hipLaunchKernelGGL((flow_step_fast_kernel<D, RP, false>), dim3(a.n / 16), dim3(NW * 64), sm, stream, a, f, nz, scratch);
+    hipLaunchKernelGGL((flow_step_fast_kernel<D, RP, false>), dim3(a.n / live), dim3(NW * 64), sm, stream, a, f, nz, scratch);
   }
   if (d != D) {
     unpad_rows(f.pos, f0.pos, a.n, d, D, stream); unpad_rows(f.grad, f0.grad, a.n, d, D, stream);

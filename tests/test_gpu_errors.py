@@ -17,8 +17,13 @@ def test_create_rejects_bad_configurations():
     from mfm_amd import _lib
     with pytest.raises(_lib.MfmError, match="multiple of 16"):
         _ctx(n_chain_local=30)
-    with pytest.raises(_lib.MfmError, match="multiples of 16"):
-        _ctx(hidden_x=(30, 32))
+    _ctx(hidden_x=(30, 32)).close()                                   # served since round 4: zero-padded widths, wide family
+    with pytest.raises(_lib.MfmError, match="wide kernel family only"):
+        _ctx(hidden_x=(30, 32), kernel_family=_lib.FAMILY_TILE)
+    with pytest.raises(_lib.MfmError, match="hidden widths must be positive"):
+        _ctx(hidden_x=(0, 32))
+    with pytest.raises(_lib.MfmError, match="hidden layers"):
+        _ctx(hidden_t=(32, 32, 32, 32))
     with pytest.raises(_lib.MfmError, match="outside n_chain_total"):
         _ctx(n_chain_total=32, chain_offset=16)
     with pytest.raises(_lib.MfmError, match="does not fit"):
@@ -66,10 +71,13 @@ def test_calls_in_the_wrong_state_or_with_bad_sizes_raise():
     ctx.close()
 
 
-def test_wide_family_declines_what_it_does_not_serve():
+def test_wide_family_takes_the_mixtures_and_declines_wide_ones():
     import torch
     from mfm_amd import _lib
     ctx = _ctx(kernel_family=_lib.FAMILY_WIDE, dim=2)
-    with pytest.raises(_lib.MfmError, match="PhiFour and LGCP"):
-        ctx.set_target(_lib.GMM, np.concatenate([[1], np.zeros(2), np.ones(2), [1.0]]))
+    ctx.set_target(_lib.GMM, np.concatenate([[1], np.zeros(2), np.ones(2), [1.0]]))      # served since round 4 (tests/test_gpu_depth.py)
+    ctx.close()
+    ctx = _ctx(kernel_family=_lib.FAMILY_WIDE, dim=16)
+    with pytest.raises(_lib.MfmError, match="dim <= 8"):
+        ctx.set_target(_lib.GMM, np.concatenate([[1], np.zeros(16), np.ones(16), [1.0]]))
     ctx.close()

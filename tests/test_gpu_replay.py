@@ -165,9 +165,24 @@ def _flow_replay_raw(ctx, model, params, args, dist, beta, x32, key, yardstick=F
 
 
 @pytest.mark.parametrize("d,hidden,F,fam", SHAPES)
-def test_flow_step_on_prescribed_steps_matches_oracle(d, hidden, F, fam):
+def test_flow_step_on_prescribed_steps_matches_oracle(monkeypatch, d, hidden, F, fam):
     """Well-conditioned field: inverse solve -> latent proposal -> forward solve -> target -> log acceptance ratio, per chain, on
     the oracle's step sequences.  d = 256 is the shape-specialised kernel (per-row solve phases, tail compaction)."""
+    monkeypatch.setenv("MFM_FLOW_LIVE", "16")          # the full 16-chain tile (32 chains would otherwise be spread over 16 workgroups: below)
+    _flow_step_case(d, hidden, F, fam)
+
+
+@pytest.mark.parametrize("live", [8, 4, 2, 0])
+@pytest.mark.parametrize("d", [256, 64])
+def test_flow_step_with_fewer_chains_per_workgroup_matches_oracle(monkeypatch, d, live):
+    """A launch with fewer tiles than CUs gives every workgroup 8 / 4 / 2 chains (ode.hip: flow_live_rows; the other rows of the tile are
+    done from the start, so the tile runs in its compact / two-pass / one-pass layout from the second attempt on): same step-for-step
+    parity, every layout entered at the START of a solve (initial-step phases included).  0 = the automatic choice (32 chains: 2)."""
+    monkeypatch.setenv("MFM_FLOW_LIVE", str(live)) if live else monkeypatch.delenv("MFM_FLOW_LIVE", raising=False)
+    _flow_step_case(d, 128, 128, None)
+
+
+def _flow_step_case(d, hidden, F, fam):
     from tests import gpu_util as gu
     B = 32
     args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=hidden, F=F)
@@ -196,11 +211,12 @@ def test_flow_step_on_prescribed_steps_matches_oracle(d, hidden, F, fam):
     ctx.close()
 
 
-@pytest.mark.parametrize("d,hidden,F,fam", [(256, 128, 128, None), (64, 32, 16, None), (256, 128, 128, "wide")])
-def test_independent_mh_flow_step_on_prescribed_steps_matches_oracle(d, hidden, F, fam):
+@pytest.mark.parametrize("d,hidden,F,fam,live", [(256, 128, 128, None, 16), (256, 128, 128, None, 8), (256, 128, 128, None, 2), (64, 32, 16, None, 16), (256, 128, 128, "wide", 16)])
+def test_independent_mh_flow_step_on_prescribed_steps_matches_oracle(monkeypatch, d, hidden, F, fam, live):
     """The independent-MH form (exe_flow_matching.py:246-260: proposal from the reference distribution, its density ratio in
-    log alpha) on prescribed steps: shape-specialised kernel, generic tile, wide family."""
+    log alpha) on prescribed steps: shape-specialised kernel (16 / 8 / 2 chains per workgroup), generic tile, wide family."""
     from tests import gpu_util as gu
+    monkeypatch.setenv("MFM_FLOW_LIVE", str(live))
     B = 32
     args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=hidden, F=F)
     params = _tamed(model, out_scale=2.0)
