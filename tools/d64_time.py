@@ -1,5 +1,7 @@
 """Development aid: the flow step at the reference's phi-four default shape (d = 64, 1024 chains, --hutch) on the shape-specialised
-kernel (zero-padded to its 128-wide tile) and on the generic tile (MFM_GENERIC_ODE=1), same network, same keys."""
+kernel (zero-padded to its 128-wide tile) and on the generic tile (MFM_GENERIC_ODE=1), same network, same keys.  The network is a random one
+with a STRONG field (every variant walks the same ~280 attempted steps per chain: a kernel-speed comparison at equal work, not a statement about
+a trained flow; the float64 oracle runs into its step limit on it).  D64_EXACT=1: exact trace; D64_B: chain count; MFM_FLOW_LIVE: chains per workgroup."""
 import os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,8 +12,8 @@ def one():
     from mfm_amd import _lib
     from oracle import prng
     from tests import gpu_util as gu
-    B, d = 1024, 64
-    args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=128, F=128)
+    B, d = int(os.environ.get("D64_B", 1024)), 64
+    args, dist, k, model, state = gu.phi4_setup(d=d, B=B, hidden=128, F=128, hutch=not os.environ.get("D64_EXACT"))
     params = gu.rand_params(model, seed=1, out_scale=0.05)
     ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
     pos0 = torch.from_numpy(dist.init_params.astype(np.float32)).cuda()
