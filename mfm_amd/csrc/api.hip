@@ -82,6 +82,7 @@ struct mfm_ctx {
   int* att_buf; size_t att_cap;   // per-sample attempt counts of the last solve when the caller passed no d_nsteps
   double* beta_out;
   wide::Ctx* wide;             // non-null: the wide kernel family serves the network kernels (wide.hip)
+  wide::Ctx* wide_ex = nullptr;   // fused family, exact trace, d >= 16: the SOLVES run on the wide family's solver (see create_impl)
   // context-owned RCCL communicator for the gradient all-reduce (mfm_comm_init; null: the caller reduces the gradient itself)
   ncclComm_t comm = nullptr; int comm_nranks = 0;
   hipStream_t comm_stream = nullptr; hipEvent_t ev_grads = nullptr, ev_comm = nullptr;
@@ -310,6 +311,16 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
     if (rc) return fail(rc, "workspace allocation of the wide kernel family failed");
     x->wide->exact = !c.hutch;           // exact-trace log-det (exe_flow_matching.py:216-217,236-237): wide.hip, exact_trace()
     x->wide->master = x->master;         // ... which reads two kernels in their canonical [in][out] layout
+  } else if (!c.hutch && c.dim >= 16 && !g_sw.tile_exact) {
+    // Exact trace (the reference's default: no --hutch) on the fused family: its generic tile pushes the d basis tangents of 16 chains
+    // through the network one 16-row tile at a time -- 7.4 ms per attempted step at d = 64, whatever the chain count.  The wide family's
+    // exact trace needs hx1 tangent rows per chain in a few large GEMMs over all chains (wide.hip: exact_trace): 1.2 ms per attempt at
+    // 1024 chains, 0.4 ms at 64.  So the SOLVES (flow steps, transforms) of such a context go to a wide workspace kept beside the tile
+    // kernels, which keep MALA, training and evaluation.  Both read the same packed weights.  MFM_TILE_EXACT=1 keeps the tile's own.
+    rc = wide::create(n, c.n_chain_local, &x->wide_ex);
+    if (rc) return fail(rc, "workspace allocation of the exact-trace solver failed");
+    x->wide_ex->exact = true;
+    x->wide_ex->master = x->master;
   }
   return MFM_OK;
 }
@@ -324,6 +335,7 @@ extern "C" int mfm_destroy(mfm_ctx* x) {
   (void)mfm_comm_destroy(x);
   ode_ws_free(x->ode);
   wide::destroy(x->wide);
+  wide::destroy(x->wide_ex);
   if (x->noise) {
     NoiseWs* w = x->noise;
     for (void* p : {(void*)w->mala_n, (void*)w->mala_u, (void*)w->fm_x0, (void*)w->fm_eps, (void*)w->fm_t, (void*)w->d_keys, (void*)w->counter}) if (p) (void)hipFree(p);
@@ -939,10 +951,10 @@ extern "C" int mfm_ode_transform(mfm_ctx* x, int direction, int per_chain, const
   a.in = d_in; a.out = d_out; a.ldj = d_ldj; a.n = n;
   a.nsteps = d_nsteps = att_buffer(x, d_nsteps, n);
   a.rp = x->replay; a.rp.n = n; memset(&x->replay, 0, sizeof x->replay);      // one-shot
-  if (x->wide) {
+  if (wide::Ctx* ws = x->wide ? x->wide : x->wide_ex) {
     launch_probe(per_chain ? 0 : 1, d_keys, a.key, 0, 0, 0, n, x->net.d, const_cast<float*>(a.z1), x->stream);
     wide::WReplay wr{a.rp.dt, a.rp.acc, a.rp.ratio, a.rp.dt_own, a.rp.cap, a.rp.n, 0, 0, nullptr};
-    const int rcw = wide::transform(x->wide, x->net, direction, a.rtol, a.atol, a.max_attempts, a.z1, d_in, n, d_out, d_ldj, d_nsteps, x->stream, wr);
+    const int rcw = wide::transform(ws, x->net, direction, a.rtol, a.atol, a.max_attempts, a.z1, d_in, n, d_out, d_ldj, d_nsteps, x->stream, wr);
     if (rcw) return fail(rcw, "wide ODE transform failed: %s", hipGetErrorString(hipGetLastError()));
     LAUNCHCHK();
     tally_solves(x, d_nsteps, n, 1);
@@ -990,7 +1002,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
   int rc = 0;
   {
     ProfScope ps_(x, PROF_FLOW);
-    if (x->wide) {
+    if (wide::Ctx* ws = x->wide ? x->wide : x->wide_ex) {
       launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 0, a.n, x->net.d, const_cast<float*>(a.zgen), x->stream);     // key_gen
       launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 3, a.n, x->net.d, const_cast<float*>(a.z1), x->stream);       // key_hutch2
       launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 2, a.n, x->net.d, const_cast<float*>(a.z2), x->stream);       // key_hutch1
@@ -999,7 +1011,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
       c.rtol = a.rtol; c.atol = a.atol; c.max_attempts = a.max_attempts; c.z_inv = a.z1; c.z_fwd = a.z2; c.zgen = a.zgen;
       c.pos = d_pos; c.logp = d_logp; c.grad = d_grad; c.acc_prob = d_acc; c.accepted = d_isacc; c.proposed = d_prop; c.nsteps = d_nsteps;
       c.rp = wide::WReplay{a.rp.dt, a.rp.acc, a.rp.ratio, a.rp.dt_own, a.rp.cap, a.rp.n, 0, 0, a.rp.diag};
-      const int rcw = wide::flow_step(x->wide, x->net, c, x->stream);
+      const int rcw = wide::flow_step(ws, x->net, c, x->stream);
       if (rcw) return fail(rcw, "wide flow step failed: %s", hipGetErrorString(hipGetLastError()));
     } else {
       rc = launch_flow_step(a, f, nz, x->stream);
