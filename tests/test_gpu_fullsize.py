@@ -104,6 +104,39 @@ def test_phi4_4096_chains_flow_round_trip_and_step_consistency(B, d):      # the
     ctx.close()
 
 
+def test_phi4_default_shape_flow_step_agrees_across_chains_per_workgroup(monkeypatch):
+    """The reference's phi-four shape (d = 64, 1024 chains): the launch gives every workgroup 4 chains (ode.hip: flow_live_rows).  The same
+    flow-MH step with 16, 8 and 4 chains per workgroup: two ADAPTIVE float32 solves of the same chain in layouts that round differently --
+    proposals within the solver tolerance of each other, the same decisions but for borderline chains, the same attempt statistics."""
+    import torch
+    from mfm_amd import _lib
+    from tests import gpu_util as gu
+    B, d = 1024, 64
+    args, dist, k, model, state = gu.phi4_setup(d=d, B=B)
+    params = _tamed(model, out_scale=0.5)
+    x32 = dist.init_params.astype(np.float32)
+    res = {}
+    for live in ("16", "8", None):
+        monkeypatch.setenv("MFM_FLOW_LIVE", live) if live else monkeypatch.delenv("MFM_FLOW_LIVE", raising=False)
+        ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+        pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+        ctx.mala_init(pos, 0.9, logp, grad)
+        acc = torch.empty(B, device="cuda"); isacc = torch.empty(B, dtype=torch.uint8, device="cuda"); prop = torch.empty(B, d, device="cuda")
+        ns = torch.empty(B, dtype=torch.int32, device="cuda")
+        ctx.flow_step(_lib.FLOW_RWMH, prng.PRNGKey(31), 0.9, pos, logp, grad, acc, isacc, prop, ns)
+        res[live] = (prop.cpu().numpy(), isacc.cpu().numpy().astype(bool), ns.cpu().numpy(), acc.cpu().numpy())
+        ctx.close()
+    p16, a16, n16, _ = res["16"]
+    for live in ("8", None):
+        p, a, n, _ = res[live]
+        dp = np.abs(p - p16).max(1)
+        print(f"chains per workgroup {live or 'auto'} vs 16: |dx'| median {np.median(dp):.2e} max {dp.max():.2e}; decisions equal {np.mean(a == a16):.4f}; attempts {n.mean():.1f} vs {n16.mean():.1f}")
+        assert np.median(dp) < 2e-4 and dp.max() < 2e-2, (np.median(dp), dp.max())
+        assert np.mean(a == a16) > 0.98
+        assert abs(n.mean() - n16.mean()) < 0.02 * n16.mean()
+    assert 0 < a16.sum() < B
+
+
 def test_gaussian_mixture_eval_batch_is_a_sum_of_its_chunks():
     """configs[1]: eval_step on eval_iter * num_chain = 100 * 4096 exact samples (exe_flow_matching.py:370-374)."""
     import torch
