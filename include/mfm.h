@@ -42,7 +42,7 @@ enum { MFM_ACT_RELU = 0, MFM_ACT_TANH = 1, MFM_ACT_ELU = 2, MFM_ACT_GELU = 3, MF
 typedef struct mfm_config {
   int32_t dim;                 /* args.dim */
   int32_t fourier_dim;         /* args.fourier_dim  (multi_modal.py:156) */
-  int32_t hidden_t[2];         /* args.hidden_t     (:179)  any positive width; multiples of 16 on the fused tile family */
+  int32_t hidden_t[2];         /* args.hidden_t     (:179)  any positive width (zero-padded to 16 inside the library) */
   int32_t hidden_x[2];         /* args.hidden_x     (:178) */
   int32_t hidden_xt[2];        /* args.hidden_xt    (:180) */
   int32_t n_chain_local;       /* chains resident on this GPU (multiple of 16) */

@@ -262,10 +262,10 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
   if (!(x->cfg.ref_std > 0.0)) return fail(MFM_EINVAL, "ref_std must be positive");
   bool use_wide = c.kernel_family == MFM_FAMILY_WIDE;
   const bool two_layer = n.nT == 2 && n.nX == 2 && n.nJ == 2;
-  if (!two_layer || ragged) {   // the fused tile kernels are written layer by layer for two hidden layers per branch, widths in whole MFMA tiles
+  (void)ragged;                 // (widths that are not multiples of 16 are zero-padded on either family: mlp.cuh, packed_row)
+  if (!two_layer) {             // the fused tile kernels are written layer by layer for two hidden layers per branch
     if (c.kernel_family == MFM_FAMILY_TILE)
-      return fail(MFM_EUNSUPPORTED, "hidden lists of %d / %d / %d layers (t / x / xt)%s run on the wide kernel family only", n.nT, n.nX, n.nJ,
-                  ragged ? " with widths that are not multiples of 16" : "");
+      return fail(MFM_EUNSUPPORTED, "hidden lists of %d / %d / %d layers (t / x / xt) run on the wide kernel family only", n.nT, n.nX, n.nJ);
     use_wide = true;
   } else {
     const FmLds L = fm_lds_layout(n, true);

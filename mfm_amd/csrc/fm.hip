@@ -5,6 +5,7 @@
 // Replaces exe_flow_matching.py:151-178 (cond_flow_fn / flow_fn + flow_matching_loss) and the XLA backward of
 // jax.value_and_grad(loss_fn, argnums=2) at :364-365.  K3 is fused into the prologue (no HBM round trip for t, x0,
 // eps, cond, target); the loss is the SUM over chains and dims (:178).
+#include <type_traits>
 #include "mlp.cuh"
 #include "prng.cuh"
 
@@ -880,17 +881,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   float* slab = a.slabs + (size_t)sp * n.n_params;
   const float big = 3.0e38f / (float)a.split;      // |partial| <= big for every slice: the sum over the slices cannot overflow
   bool suspicious = false;
-  auto put = [&](f32x4 acc, int kt, int nt) {
+  // the joint layer reads [sx | st] with both halves padded to 16: packed rows [ks_true, ks_pad) are padding, row r >= ks_pad is
+  // canonical row r - ks_pad + ks_true (mlp.cuh: packed_row); every other layer -- and every network whose hidden widths are multiples
+  // of 16 -- has no gap and takes the branch-free store
+  const int ks_true = J.layer == 5 ? n.L[3].N : 0, ks_pad = J.layer == 5 ? n.L[3].Np : 0;
+  auto put = [&](f32x4 acc, int kt, int nt, auto gap) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int k = kt * 16 + 4 * g + i, nn = nt * 16 + c;
+      int k = kt * 16 + 4 * g + i;
+      const int nn = nt * 16 + c;
+      if constexpr (decltype(gap)::value) {
+        if (k >= ks_true) {
+          if (k < ks_pad) continue;
+          k -= ks_pad - ks_true;
+        }
+      }
       if (k < ld.K && nn < ld.N) { slab[ld.m_w + k * ld.N + nn] = acc[i]; suspicious |= !(fabsf(acc[i]) <= big); }
     }
   };
-  if (k0 && n0) put(acc00, kq, nq);
-  if (k0 && n1) put(acc01, kq, nq + 1);
-  if (k1 && n0) put(acc10, kq + 1, nq);
-  if (k1 && n1) put(acc11, kq + 1, nq + 1);
+  if (ks_pad == ks_true) {      // (wave-uniform)
+    const std::false_type ng;
+    if (k0 && n0) put(acc00, kq, nq, ng);
+    if (k0 && n1) put(acc01, kq, nq + 1, ng);
+    if (k1 && n0) put(acc10, kq + 1, nq, ng);
+    if (k1 && n1) put(acc11, kq + 1, nq + 1, ng);
+  } else {
+    const std::true_type wg;
+    if (k0 && n0) put(acc00, kq, nq, wg);
+    if (k0 && n1) put(acc01, kq, nq + 1, wg);
+    if (k1 && n0) put(acc10, kq + 1, nq, wg);
+    if (k1 && n1) put(acc11, kq + 1, nq + 1, wg);
+  }
   if (kq == 0) {        // bias gradient: sum over chains of dZ, for the n-tiles of this quadrant
     float s0 = bs0[0] + bs0[1] + bs0[2] + bs0[3], s1 = bs1[0] + bs1[1] + bs1[2] + bs1[3];
     s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);

@@ -103,6 +103,14 @@ __host__ __device__ __forceinline__ int packed_row(const NetDev& n, int layer, i
   return k < lx.N ? k : k - lx.N + lx.Np;
 }
 
+// a hidden width that is not a multiple of 16 (zero-padded: K / N of the layers differ from Kp / Np beyond the d- and 2F-wide edges)
+__host__ __device__ __forceinline__ bool net_ragged(const NetDev& n) {
+  const int gate = n.nT + n.nX, out = gate + n.nJ + 1;
+  for (int l = 0; l < out; ++l)
+    if (l != gate && n.L[l].N != n.L[l].Np) return true;
+  return false;
+}
+
 // ---- the tile GEMM -------------------------------------------------------------------------------------------
 // acc[m] (+)= A[m-tile rows][K] * W[K][tile nt], for the n-tiles nt = wave + NW * q owned by this wave (NW waves per workgroup).
 // A: LDS, row-major, MT*16 rows, leading dimension lda (multiple of 4 floats).  Wp: packed weights of the layer.

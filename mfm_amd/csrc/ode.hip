@@ -52,7 +52,7 @@ static int ode_ws_alloc(const NetDev& n, const mfm_config& c, OdeWs& w) {
   const size_t t_flow = (size_t)c.n_chain_local / flow_live_rows(c.n_chain_local);      // the flow step runs one workgroup per 16 (8 / 4 / 2) chains
   if (w.fast_wgs < t_flow) w.fast_wgs = t_flow;
   memset(&w.pad, 0, sizeof w.pad);
-  if (c.hutch && n.nT == 2 && n.nX == 2 && n.nJ == 2 && n.T.kind == MFM_TARGET_PHI4 && n.act == MFM_ACT_RELU && n.F == 128 && n.ht1 == 128 && n.ht2 == 128 && n.hx1 == 128 &&
+  if (c.hutch && n.nT == 2 && n.nX == 2 && n.nJ == 2 && !net_ragged(n) && n.T.kind == MFM_TARGET_PHI4 && n.act == MFM_ACT_RELU && n.F == 128 && n.ht1 == 128 && n.ht2 == 128 && n.hx1 == 128 &&
       n.hx2 == 128 && n.hj1 == 128 && n.hj2 == 128 && n.d >= 16 && n.d < 256 && n.d != 128 && n.d % 16 == 0) {
     const int D = n.d < 128 ? 128 : 256;
     const size_t wtot = (size_t)2 * 128 * 128 + 5 * 128 * 128 + 3 * (size_t)D * 128;      // FS<D>::WTOT

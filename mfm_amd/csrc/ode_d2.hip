@@ -40,7 +40,7 @@ __host__ __device__ inline Lds layout(const NetDev& n) {
 }
 
 static bool shape_ok(const NetDev& n, int hutch) {
-  if (n.d != 2 || hutch || n.T.kind != MFM_TARGET_GMM) return false;
+  if (n.d != 2 || hutch || n.T.kind != MFM_TARGET_GMM || net_ragged(n)) return false;
   if (n.F % 16 || n.F2p != 2 * n.F) return false;
   if (n.hx1 / 16 > 2 * NW) return false;
   return (size_t)layout(n).total * sizeof(float) <= 160 * 1024;

@@ -2324,7 +2324,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_fast_kernel(OdeArgs a, Flow
 static int tile_width(const NetDev& n) { return n.d <= 128 ? 128 : 256; }
 static bool shape_ok(const NetDev& n, int hutch) {
   if (!hutch || n.T.kind != MFM_TARGET_PHI4 || n.act != MFM_ACT_RELU) return false;
-  if (n.nT != 2 || n.nX != 2 || n.nJ != 2) return false;
+  if (n.nT != 2 || n.nX != 2 || n.nJ != 2 || net_ragged(n)) return false;
   if (n.F != F || n.ht1 != H || n.ht2 != H || n.hx1 != H || n.hx2 != H || n.hj1 != H || n.hj2 != H) return false;
   return n.d >= 16 && n.d <= 256 && n.d % 16 == 0;
 }

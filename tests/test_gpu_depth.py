@@ -14,7 +14,8 @@ ONE = ([32], [32], [32])
 THREE = ([32, 48, 32], [48, 32, 16], [64, 32, 48])
 MIXED = ([48], [32, 16, 32], [32, 64])          # one x layer: its output IS sx; three t layers; two joint layers
 MIXED2 = ([32, 48], [16], [32, 16, 32])
-RAGGED = ([20, 50], [30, 24], [100, 36])        # widths that are not multiples of 16 (multi_modal.py:178-180 takes any int): zero-padded
+RAGGED = ([20, 50], [30, 24], [100, 36])        # widths that are not multiples of 16 (multi_modal.py:178-180 takes any int): zero-padded; two layers
+                                                # per branch, so this one runs on the FUSED tile family (the deeper ragged case below: wide)
 RAGGED3 = ([24, 40, 20], [10], [50])
 DEPTHS = {"1-1-1": ONE, "3-3-3": THREE, "x1-t3-j2": MIXED, "x2-t1-j3": MIXED2, "ragged": RAGGED, "ragged-x3-t1-j1": RAGGED3}
 
@@ -41,6 +42,25 @@ def _tamed(model, out_scale, gate, seed=9):
     g = model.zero_layers()[0]                         # the gate layer: t.., x.., GATE, joint.., out
     p[g]["kernel"] *= gate; p[g]["bias"] *= gate
     return p
+
+
+def test_ragged_two_layer_network_runs_on_the_fused_family_and_matches_the_wide_one():
+    import torch
+    from mfm_amd import _lib
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.phi4_setup(d=64, B=32, hidden=RAGGED, F=16)
+    params = gu.rand_params(model, seed=5)
+    x32 = dist.init_params.astype(np.float32)
+    res = []
+    for fam in (_lib.FAMILY_TILE, _lib.FAMILY_WIDE):
+        ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, family=fam)
+        assert ctx.cfg.kernel_family == fam
+        loss = torch.zeros(1, dtype=torch.float64, device="cuda"); grads = torch.zeros(ctx.n_params, device="cuda")
+        ctx.fm_loss_grad(prng.PRNGKey(7), _dev(x32), loss, grads)
+        res.append((loss.item(), grads.cpu().numpy()))
+        ctx.close()
+    assert abs(res[0][0] - res[1][0]) < 1e-6 * abs(res[0][0])
+    assert np.abs(res[0][1] - res[1][1]).max() < 2e-5 * np.abs(res[0][1]).max()
 
 
 def test_two_layer_request_on_the_tile_family_and_bad_depths_are_named():

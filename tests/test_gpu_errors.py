@@ -17,9 +17,11 @@ def test_create_rejects_bad_configurations():
     from mfm_amd import _lib
     with pytest.raises(_lib.MfmError, match="multiple of 16"):
         _ctx(n_chain_local=30)
-    _ctx(hidden_x=(30, 32)).close()                                   # served since round 4: zero-padded widths, wide family
+    _ctx(hidden_x=(30, 32)).close()                                   # served since round 4: zero-padded widths, either family
+    _ctx(hidden_x=(30, 32), kernel_family=_lib.FAMILY_TILE).close()
+    _ctx(hidden_x=(30, 32), kernel_family=_lib.FAMILY_WIDE).close()
     with pytest.raises(_lib.MfmError, match="wide kernel family only"):
-        _ctx(hidden_x=(30, 32), kernel_family=_lib.FAMILY_TILE)
+        _ctx(hidden_x=(32, 32, 32), kernel_family=_lib.FAMILY_TILE)
     with pytest.raises(_lib.MfmError, match="hidden widths must be positive"):
         _ctx(hidden_x=(0, 32))
     with pytest.raises(_lib.MfmError, match="hidden layers"):
