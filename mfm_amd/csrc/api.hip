@@ -220,7 +220,6 @@ extern "C" int mfm_create(const mfm_config* cfg, mfm_ctx** out) {
 
 static int create_impl(const mfm_config& c, mfm_ctx* x) {
   if (c.dim <= 0 || c.fourier_dim <= 0) return fail(MFM_EINVAL, "dim / fourier_dim must be positive");
-  bool ragged = false;          // a hidden width that is not a multiple of 16: zero-padded, wide family
   {
     int hs[3][MLP_MAX_DEPTH];
     const int nd[3] = {branch_widths(c.depth_t, c.hidden_t, c.hidden_t3, hs[0]), branch_widths(c.depth_x, c.hidden_x, c.hidden_x3, hs[1]),
@@ -228,8 +227,7 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
     for (int b = 0; b < 3; ++b) {
       if (nd[b] < 0) return fail(MFM_EUNSUPPORTED, "a branch has 1 to %d hidden layers (depth_t / depth_x / depth_xt = %d / %d / %d)", MLP_MAX_DEPTH, c.depth_t, c.depth_x, c.depth_xt);
       for (int i = 0; i < nd[b]; ++i) {
-        if (hs[b][i] <= 0) return fail(MFM_EINVAL, "hidden widths must be positive (got %d)", hs[b][i]);
-        ragged |= hs[b][i] % 16 != 0;
+        if (hs[b][i] <= 0) return fail(MFM_EINVAL, "hidden widths must be positive (got %d)", hs[b][i]);      // (not multiples of 16: zero-padded, mlp.cuh)
       }
     }
   }
@@ -262,7 +260,6 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
   if (!(x->cfg.ref_std > 0.0)) return fail(MFM_EINVAL, "ref_std must be positive");
   bool use_wide = c.kernel_family == MFM_FAMILY_WIDE;
   const bool two_layer = n.nT == 2 && n.nX == 2 && n.nJ == 2;
-  (void)ragged;                 // (widths that are not multiples of 16 are zero-padded on either family: mlp.cuh, packed_row)
   if (!two_layer) {             // the fused tile kernels are written layer by layer for two hidden layers per branch
     if (c.kernel_family == MFM_FAMILY_TILE)
       return fail(MFM_EUNSUPPORTED, "hidden lists of %d / %d / %d layers (t / x / xt) run on the wide kernel family only", n.nT, n.nX, n.nJ);
