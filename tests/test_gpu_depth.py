@@ -170,6 +170,39 @@ def test_transform_on_prescribed_steps_matches_oracle(depth, direction, hutch):
     ctx.close()
 
 
+@pytest.mark.parametrize("act", ["gelu", "tanh", "swish"])
+@pytest.mark.parametrize("depth", ["3-3-3", "x1-t3-j2", "ragged"])
+def test_exact_trace_with_smooth_activations_on_prescribed_steps(depth, act):
+    """The exact trace's masks act'(.) come from the stored outputs (tanh) or from the stored pre-activations (gelu, swish: one stash per
+    hidden layer of whatever depth); act'(0) != 0 for all three, so the padded units of the ragged case must be cut by zero weights (GEMM
+    hops) and by the seed kernel's row guard.  `ragged` runs on the fused family with its solves on the wide solver, the others on the wide family."""
+    import torch
+    from tests import gpu_util as gu
+    from tests.test_gpu_replay import _replay_arrays
+    B, d = 32, 64
+    args, dist, k, model, state = _setup("lgcp", d, B, DEPTHS[depth], 16, hutch=False, non_linearity=act)
+    params = _tamed(model, 0.5, 0.05)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params)
+    x64 = dist.init_params.astype(np.float32).astype(np.float64)
+    keys = prng.split(prng.PRNGKey(21), B)
+    o = (False, args.rtol, args.atol, args.mxstep)
+    st = {}
+    ode.transform_and_logdet(model, params, keys, x64, *o, stats=st)
+    dt, acc = _replay_arrays([st])
+    y_o, l_o = ode.transform_and_logdet(model, params, keys, x64, *o, stats={}, replay=dict(dt=dt[0].astype(np.float64), acc=acc[0]))
+    ratio = torch.zeros(dt[0].shape, device="cuda"); own = torch.zeros(dt[0].shape, device="cuda")
+    ctx.debug_replay(_dev(dt[0]), _dev(acc[0]), ratio, own)
+    out = torch.empty(B, d, device="cuda"); ldj = torch.empty(B, device="cuda"); ns = torch.empty(B, dtype=torch.int32, device="cuda")
+    ctx.ode_transform(1, _dev(x64.astype(np.float32)), out, ldj, keys=_dev(keys.astype(np.uint32).view(np.int32)), nsteps=ns)
+    y, l, n = out.cpu().numpy(), ldj.cpu().numpy(), ns.cpu().numpy()
+    np.testing.assert_array_equal(n, st["n_attempted"])
+    ey, el = np.abs(y - y_o).max(), np.abs(l - l_o).max()
+    print(f"exact trace {act} depth {depth}: attempts {n.mean():.1f}, |l| {np.abs(l_o).max():.2f}, |dy| {ey:.2e}, |dl| {el:.2e}")
+    assert n.mean() > 3 and np.abs(l_o).max() > 0.2
+    assert ey < 3e-5 * max(1.0, np.abs(y_o).max()) and el < 1e-4 * max(1.0, np.abs(l_o).max()), (ey, el)
+    ctx.close()
+
+
 @pytest.mark.parametrize("depth,hutch", [("1-1-1", False), ("3-3-3", True), ("x1-t3-j2", True), ("x2-t1-j3", False), ("ragged", False), ("ragged-x3-t1-j1", True)])
 def test_flow_step_on_prescribed_steps_matches_oracle(depth, hutch):
     from tests import gpu_util as gu
