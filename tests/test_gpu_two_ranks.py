@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 
 def _args(num_chain):
     from oracle import loop
+    deep = os.environ.get("MFM_TEST_HIDDEN") == "deep"      # three layers on the x branch, one on the t branch, ragged widths: the wide family
+    hid = dict(hidden_x=[32, 40, 24], hidden_t=[20], hidden_xt=[48, 32]) if deep else dict(hidden_x=[32, 32], hidden_t=[32, 32], hidden_xt=[32, 32])
     return loop.default_args(example="phi-four", dim=64, num_chain=num_chain, learning_iter=7, mcmc_per_flow_steps=3.0,
-                             hutchs=True, fourier_dim=16, hidden_x=[32, 32], hidden_t=[32, 32], hidden_xt=[32, 32],
-                             seed=1024, eval_iter=1, step_size=1e-4)
+                             hutchs=True, fourier_dim=16, seed=1024, eval_iter=1, step_size=1e-4, **hid)
 
 
 def _worker(rank, world, port, out):
@@ -70,6 +71,28 @@ def test_two_ranks_reproduce_single_process(tmp_path):
     # seven Adam updates (bounded by 2e-3 above): O(1) samples move by up to a few 1e-2 (observed 1.3e-2 .. 3.1e-2 over builds)
     assert np.abs(z[0]["flow"] - fin1["flow_samples"]).max() < 5e-2
     np.testing.assert_allclose(z[0]["res"][:3], res[:3], rtol=5e-2, atol=1e-3)          # logpdf, KSD U / V of the flow samples
+
+
+def test_two_ranks_with_a_deep_ragged_network_reproduce_single_process(tmp_path, monkeypatch):
+    """The same through the wide family (hidden lists 3 / 1 / 2 with widths that are not multiples of 16): an eight-layer gradient vector
+    summed over two ranks, deferred AdamW, replicas identical, losses against the single-process run."""
+    import torch.multiprocessing as mp
+    from mfm_amd import distributions as D, exe_flow_matching as E
+    monkeypatch.setenv("MFM_TEST_HIDDEN", "deep")
+    out = str(tmp_path / "r%d.npz")
+    port = 29500 + (os.getpid() + 7) % 2000
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    res, res_, ex = E.run(D.PhiFour(64), _args(64), None, log_every=1000, return_extras=True)
+    m1, p1, opt1 = ex["metrics"], ex["engine"].ctx.get_params(), ex["engine"].ctx.opt_state()
+    assert ex["engine"].ctx.n_params == sum(fi * fo + fo for fi, fo in E.layer_shapes(64, 16, [32, 40, 24], [20], [48, 32]))
+    ex["engine"].close()
+    z = [np.load(out % r) for r in range(2)]
+    np.testing.assert_array_equal(z[0]["metrics"], z[1]["metrics"])
+    np.testing.assert_array_equal(z[0]["params"], z[1]["params"])
+    np.testing.assert_allclose(z[0]["metrics"][:3, 0], m1[:3, 0], rtol=1e-6)
+    np.testing.assert_allclose(z[0]["metrics"][:, 0], m1[:, 0], rtol=5e-3)
+    assert tuple(z[0]["opt"]) == (opt1["step"], opt1["count"])
+    assert np.abs(z[0]["params"] - p1).max() < 2e-3 * max(1.0, np.abs(p1).max())
 
 
 def _rccl_worker(rank, world, port, out, in_lib):
