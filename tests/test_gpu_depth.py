@@ -325,3 +325,24 @@ def test_four_mode_loop_with_three_hidden_layers_matches_oracle():
     np.testing.assert_allclose(ex["betas"], tr["beta"], rtol=2e-3)
     assert np.isfinite(res).all()
     ex["engine"].close()
+
+
+DEEP = ([32, 40, 24], [20], [48, 32])
+
+
+@pytest.mark.parametrize("opts", [dict(num_importance_samples=-1), dict(num_importance_samples=3), dict(ref_dist="widegauss", num_importance_samples=-1),
+                                  dict(cond_flow=False), dict(non_linearity="tanh")],
+                         ids=["imh", "cis", "widegauss-imh", "no-cond-flow", "tanh"])
+def test_phi4_loop_options_with_a_deep_ragged_network(opts):
+    """The other flow kernels and options of the loop (exe_flow_matching.py:246-260 independent MH, :280-296 conditional importance
+    sampling, the wide reference distribution, the unconditional flow-matching batch, another activation) with hidden lists 3 / 1 / 2 of
+    widths that are not multiples of 16: wide family, against the oracle's loop."""
+    from tests.test_gpu_loop import _run_both
+    out, res, ex = _run_both("phi-four", 64, 64, 8, 3, width=DEEP, step_size=1e-4, **opts)
+    tr, m = out["trace"], ex["metrics"]
+    np.testing.assert_allclose(m[:3, 0], tr["loss"][:3], rtol=2e-5)          # before the first flow step: same chains, same noise
+    assert np.isfinite(m[:, 0]).all() and np.isfinite(np.array(tr["loss"])).all()
+    np.testing.assert_allclose(m[:, 0], tr["loss"], rtol=5e-2)               # after it: borderline decisions / near-tie categorical draws may differ
+    np.testing.assert_allclose(ex["betas"], tr["beta"], rtol=2e-3)
+    assert np.isfinite(res).all()
+    ex["engine"].close()
