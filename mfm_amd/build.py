@@ -13,7 +13,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mfm.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mfm.h"), os.path.abspath(__file__)]      # (this file: the flags)
     return any(os.path.getmtime(p) > t for p in deps)
 
 
@@ -22,8 +22,13 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # -amdgpu-sched-strategy=max-ilp: the machine scheduler orders for instruction-level parallelism instead of for occupancy.  Every
+    # hot kernel here runs at a FIXED occupancy (8 waves per CU with up to 256 registers, set by its LDS tile), so there is nothing for
+    # the default strategy's register-pressure heuristics to win; measured on the same chain states (tools/flow_ab.py): flow step
+    # 48.68 -> 46.04 ms, bench 7.56 -> 7.90 M chain-steps/s (0.710 -> 0.748 of the MFMA peak); the other workloads within +-0.7 %
+    # (tools/dbg/ab_workloads.sh).  Same arithmetic: attempt counts and results are unchanged.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB] + SOURCES
+           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, cwd=CSRC, check=True)
