@@ -124,7 +124,8 @@ int mfm_loglik(mfm_ctx* ctx, const float* d_pos, double* d_out);
 /* loss and parameter gradient on the local chains; d_grads [num_params] (canonical layout) and d_loss [1] are caller
  * owned so a multi-GPU host can all-reduce them (SUM) before mfm_adamw_step. */
 int mfm_fm_loss_grad(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const float* d_pos, double* d_loss, float* d_grads);
-/* loss only on n samples (eval_step, :370-374); n multiple of 16, draws indexed out of n_total starting at offset */
+/* loss only on n samples (eval_step, :370-374); any n > 0 (a last partial 16-row tile is staged inside the library), draws
+ * indexed out of n_total starting at offset */
 int mfm_fm_loss(mfm_ctx* ctx, uint32_t key0, uint32_t key1, const float* d_samples, int n, int n_total, int offset,
                 double* d_loss);
 

@@ -2,7 +2,7 @@
 // jaxopt.Bisection(lower = prev_beta, upper = 1, maxiter = 30, tol = 1e-5, check_bracket = False) restated
 // (SURVEY.md section 8c): returns the LAST midpoint evaluated.  One workgroup; <= 32 passes over the n log-likelihoods
 // (float64, L2-resident).
-#include "common.cuh"
+#include "common.hip.h"
 
 #define BETA_THREADS 1024
 

@@ -15,6 +15,7 @@
 #include "lgcp.hip"
 #include "fm.hip"
 #include "optim.hip"
+#include "wgrad_sk.hip"
 #include "noise.hip"
 #include "ode.hip"
 #include "anneal.hip"
@@ -70,7 +71,12 @@ struct mfm_ctx {
   float *master, *mu, *nu, *Wp, *WpT, *bias, *fourier;
   float *acts, *dzs, *slabs, *dacts;
   double* loss_part; int loss_cap;
+  float* wsk_partials = nullptr; int* wsk_tickets = nullptr;      // stream-K weight gradients (wgrad_sk.hip): partial blocks, arrival counters
+  int wsk_G = 0, wsk_q = 0, wsk_r = 0;                              // its grid and units per workgroup (0: the slab kernels serve this context)
+  int sus_par = 0;                                                  // parity of the training kernel's "suspicious values" word (flag[5 + parity])
+  float* eval_pad = nullptr;   // [16][dim]: the last, partial 16-row tile of a mfm_fm_loss call whose n is not a multiple of 16
   WgradJob* jobs; int n_jobs, split;
+  std::vector<WgradJob> h_jobs;          // host copy (wgrad_sk.hip takes the table in its launch arguments)
   OptState* opt; int* flag;      // opt: the CURRENT optimizer scalars (opt_alt: the buffer the one-launch reduction + optimizer writes next)
   OptState* opt_alt;
   const float* checked_grads = nullptr;   // gradient whose finite check already sits in flag[0] (single-rank mfm_fm_loss_grad)
@@ -87,9 +93,15 @@ struct mfm_ctx {
   ncclComm_t comm = nullptr; int comm_nranks = 0;
   hipStream_t comm_stream = nullptr; hipEvent_t ev_grads = nullptr, ev_comm = nullptr;
   const float* comm_pending = nullptr;   // gradient buffer whose all-reduce is in flight on comm_stream
+  Switches sw;                           // the A/B switches as read at mfm_create: installed by every entry point (use_ctx)
   FmMala fuse_mala = {};                 // on != 0 during a mfm_train_iter whose MALA step rides in the training kernel
   int opt_resident_wgs = 0;              // workgroups of reduce_adamw_kernel this device holds at once (occupancy query at create)
 };
+
+// The development switches (common.hip.h) are read once per mfm_create and belong to THAT context: every entry point installs its
+// context's snapshot before it sizes or launches anything, so a second context created under another environment cannot change what an
+// earlier one launches (its workspaces were sized from its own snapshot: e.g. the flow step's chains per workgroup, MFM_FLOW_LIVE).
+static inline void use_ctx(const mfm_ctx* x) { if (x) g_sw = x->sw; }
 
 struct ProfScope {
   mfm_ctx* x; bool active;
@@ -120,7 +132,7 @@ ProfScope::~ProfScope() {
   p->used += 2;
 }
 
-extern "C" int mfm_profile(mfm_ctx* x, int enable) {
+extern "C" int mfm_profile(mfm_ctx* x, int enable) { use_ctx(x);
   if (!x) return fail(MFM_EINVAL, "null ctx");
   if (!x->prof) x->prof = new Prof();
   Prof* p = x->prof;
@@ -134,7 +146,7 @@ extern "C" int mfm_profile(mfm_ctx* x, int enable) {
   return MFM_OK;
 }
 
-extern "C" int mfm_profile_read(mfm_ctx* x, double ms[8], int64_t counts[8]) {
+extern "C" int mfm_profile_read(mfm_ctx* x, double ms[8], int64_t counts[8]) { use_ctx(x);
   if (!x || !ms || !counts) return fail(MFM_EINVAL, "null argument");
   for (int i = 0; i < 8; ++i) { ms[i] = 0.0; counts[i] = 0; }
   if (!x->prof) return MFM_OK;
@@ -181,7 +193,7 @@ static void build_net(const mfm_config& c, NetDev& n) {
   int wo = 0, bo = 0, mo = 0;
   for (int l = 0; l < nl; ++l) {
     LayerDesc& L = n.L[l];
-    L.K = K[l]; L.N = N[l]; L.Kp = l == joint0 ? n.hx2 + n.ht2 : ceil16(K[l]); L.Np = ceil16(N[l]);      // [sx | st]: both halves padded (mlp.cuh: packed_row)
+    L.K = K[l]; L.N = N[l]; L.Kp = l == joint0 ? n.hx2 + n.ht2 : ceil16(K[l]); L.Np = ceil16(N[l]);      // [sx | st]: both halves padded (mlp.hip.h: packed_row)
     L.w_off = wo; wo += L.Kp * L.Np;
     L.b_off = bo; bo += L.Np;
     L.m_w = mo; mo += K[l] * N[l];
@@ -227,7 +239,7 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
     for (int b = 0; b < 3; ++b) {
       if (nd[b] < 0) return fail(MFM_EUNSUPPORTED, "a branch has 1 to %d hidden layers (depth_t / depth_x / depth_xt = %d / %d / %d)", MLP_MAX_DEPTH, c.depth_t, c.depth_x, c.depth_xt);
       for (int i = 0; i < nd[b]; ++i) {
-        if (hs[b][i] <= 0) return fail(MFM_EINVAL, "hidden widths must be positive (got %d)", hs[b][i]);      // (not multiples of 16: zero-padded, mlp.cuh)
+        if (hs[b][i] <= 0) return fail(MFM_EINVAL, "hidden widths must be positive (got %d)", hs[b][i]);      // (not multiples of 16: zero-padded, mlp.hip.h)
       }
     }
   }
@@ -240,7 +252,7 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
                 c.chain_offset + n_valid, c.n_chain_total);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MFM_EHIP, "no HIP device available");
-  switches_read();                     // development / A-B switches: fixed from here until the next mfm_create (common.cuh)
+  switches_read(); x->sw = g_sw;                     // development / A-B switches: fixed from here until the next mfm_create (common.hip.h)
   {
     // reduce_adamw_kernel's grid-wide exchange (taken when a gradient partial is huge or non-finite) spins until every workgroup
     // of its grid has arrived: all of them must be RESIDENT at once.  Ask the runtime what this device (a full MI355X, a CPX
@@ -283,7 +295,7 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
   for (int l = 0; l < 8; ++l)
     for (int nt = 0; nt < n.L[l].Np / 16; nt += 4)
       for (int kt = 0; kt < n.L[l].Kp / 16; kt += 4) jobs.push_back(WgradJob{l, kt, nt});
-  x->n_jobs = (int)jobs.size();
+  x->n_jobs = (int)jobs.size(); x->h_jobs = jobs;
 #define ALLOC(p, cnt) HIPCHK(hipMalloc((void**)&(p), (size_t)(cnt) * sizeof(*(p))))
   ALLOC(x->master, n.n_params); ALLOC(x->mu, n.n_params); ALLOC(x->nu, n.n_params);
   ALLOC(x->Wp, n.n_packed); ALLOC(x->WpT, n.n_packed); ALLOC(x->bias, n.n_bias); ALLOC(x->fourier, n.F);
@@ -293,6 +305,12 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
     ALLOC(x->slabs, (size_t)x->split * n.n_params);
   }
   ALLOC(x->loss_part, x->loss_cap);
+  ALLOC(x->eval_pad, (size_t)16 * c.dim);
+  if (!use_wide && x->n_jobs <= WSK_MAXJOBS && !getenv("MFM_WGRAD_SLABS")) {      // (MFM_WGRAD_SLABS=1: the round-1..4 slab kernels, for A/B)
+    wsk_plan(x->n_jobs, nbb, x->wsk_G, x->wsk_q, x->wsk_r);
+    ALLOC(x->wsk_partials, (size_t)2 * x->wsk_G * WSK_PSZ); ALLOC(x->wsk_tickets, x->n_jobs);
+    HIPCHK(hipMemset(x->wsk_tickets, 0, (size_t)x->n_jobs * sizeof(int)));
+  }
   ALLOC(x->jobs, x->n_jobs); ALLOC(x->opt, 1); ALLOC(x->opt_alt, 1); ALLOC(x->flag, 8); ALLOC(x->beta_out, 4);
   ALLOC(x->d_att, 1); HIPCHK(hipMemset(x->d_att, 0, sizeof(unsigned long long)));
   HIPCHK(hipMemcpy(x->jobs, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice));
@@ -322,10 +340,10 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
   return MFM_OK;
 }
 
-extern "C" int mfm_destroy(mfm_ctx* x) {
+extern "C" int mfm_destroy(mfm_ctx* x) { use_ctx(x);
   if (!x) return MFM_OK;
   hipDeviceSynchronize();
-  void* ps[] = {x->master, x->mu, x->nu, x->Wp, x->WpT, x->bias, x->fourier, x->acts, x->dzs, x->dacts, x->slabs, x->loss_part,
+  void* ps[] = {x->master, x->mu, x->nu, x->Wp, x->WpT, x->bias, x->fourier, x->acts, x->dzs, x->dacts, x->slabs, x->loss_part, x->eval_pad, x->wsk_partials, x->wsk_tickets,
                 x->jobs, x->opt, x->opt_alt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->kdiag, x->beta_out,
                 x->d_att, x->att_buf};
   for (void* p : ps) if (p) hipFree(p);
@@ -343,11 +361,11 @@ extern "C" int mfm_destroy(mfm_ctx* x) {
   return MFM_OK;
 }
 
-extern "C" int mfm_set_stream(mfm_ctx* x, void* s) { if (!x) return fail(MFM_EINVAL, "null ctx"); x->stream = (hipStream_t)s; return MFM_OK; }
-extern "C" int mfm_sync(mfm_ctx* x) { if (!x) return fail(MFM_EINVAL, "null ctx"); HIPCHK(hipStreamSynchronize(x->stream)); return MFM_OK; }
-extern "C" int mfm_num_params(const mfm_ctx* x) { return x ? x->net.n_params : MFM_EINVAL; }
+extern "C" int mfm_set_stream(mfm_ctx* x, void* s) { use_ctx(x); if (!x) return fail(MFM_EINVAL, "null ctx"); x->stream = (hipStream_t)s; return MFM_OK; }
+extern "C" int mfm_sync(mfm_ctx* x) { use_ctx(x); if (!x) return fail(MFM_EINVAL, "null ctx"); HIPCHK(hipStreamSynchronize(x->stream)); return MFM_OK; }
+extern "C" int mfm_num_params(const mfm_ctx* x) { use_ctx(x); return x ? x->net.n_params : MFM_EINVAL; }
 
-extern "C" int mfm_set_target(mfm_ctx* x, int kind, const double* p, size_t np) {
+extern "C" int mfm_set_target(mfm_ctx* x, int kind, const double* p, size_t np) { use_ctx(x);
   if (!x || !p) return fail(MFM_EINVAL, "null argument");
   TargetDev& T = x->net.T;
   const int d = x->cfg.dim;
@@ -414,13 +432,13 @@ extern "C" int mfm_set_target(mfm_ctx* x, int kind, const double* p, size_t np) 
   return MFM_OK;
 }
 
-extern "C" int mfm_set_fourier(mfm_ctx* x, const float* h) {
+extern "C" int mfm_set_fourier(mfm_ctx* x, const float* h) { use_ctx(x);
   if (!x || !h) return fail(MFM_EINVAL, "null argument");
   HIPCHK(hipMemcpy(x->fourier, h, x->net.F * 4, hipMemcpyHostToDevice));
   x->has_fourier = true;
   return MFM_OK;
 }
-extern "C" int mfm_set_params(mfm_ctx* x, const float* h) {
+extern "C" int mfm_set_params(mfm_ctx* x, const float* h) { use_ctx(x);
   if (!x || !h) return fail(MFM_EINVAL, "null argument");
   HIPCHK(hipMemcpyAsync(x->master, h, (size_t)x->net.n_params * 4, hipMemcpyHostToDevice, x->stream));
   launch_pack(x->net, x->master, x->Wp, x->WpT, x->bias, x->stream);
@@ -428,13 +446,13 @@ extern "C" int mfm_set_params(mfm_ctx* x, const float* h) {
   HIPCHK(hipStreamSynchronize(x->stream));
   return MFM_OK;
 }
-extern "C" int mfm_get_params(mfm_ctx* x, float* h) {
+extern "C" int mfm_get_params(mfm_ctx* x, float* h) { use_ctx(x);
   if (!x || !h) return fail(MFM_EINVAL, "null argument");
   HIPCHK(hipStreamSynchronize(x->stream));
   HIPCHK(hipMemcpy(h, x->master, (size_t)x->net.n_params * 4, hipMemcpyDeviceToHost));
   return MFM_OK;
 }
-extern "C" int mfm_reset_optimizer(mfm_ctx* x) {
+extern "C" int mfm_reset_optimizer(mfm_ctx* x) { use_ctx(x);
   if (!x) return fail(MFM_EINVAL, "null ctx");
   HIPCHK(hipMemsetAsync(x->mu, 0, (size_t)x->net.n_params * 4, x->stream));
   HIPCHK(hipMemsetAsync(x->nu, 0, (size_t)x->net.n_params * 4, x->stream));
@@ -471,7 +489,7 @@ static int lgcp_mala_dispatch(mfm_ctx* x, const LgcpArgs& l) {
   return wide_mala_lgcp(x, l);
 }
 
-extern "C" int mfm_mala_init(mfm_ctx* x, const float* d_pos, double beta, double* d_logp, float* d_grad) {
+extern "C" int mfm_mala_init(mfm_ctx* x, const float* d_pos, double beta, double* d_logp, float* d_grad) { use_ctx(x);
   NEED_TARGET();
   if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
   if (x->net.T.kind == MFM_TARGET_LGCP) {
@@ -524,16 +542,16 @@ static int mala_step_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const uint32_t
 }
 
 extern "C" int mfm_mala_step(mfm_ctx* x, uint32_t k0, uint32_t k1, double beta, double step, int textbook, float* d_pos,
-                             double* d_logp, float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, float* d_pw) {
+                             double* d_logp, float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, float* d_pw) { use_ctx(x);
   return mala_step_common(x, k0, k1, nullptr, beta, step, textbook, d_pos, d_logp, d_grad, d_acc, d_isacc, d_prop, d_pw);
 }
 extern "C" int mfm_mala_step_keys(mfm_ctx* x, const uint32_t* d_keys, double beta, double step, int textbook, float* d_pos,
-                                  double* d_logp, float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, float* d_pw) {
+                                  double* d_logp, float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, float* d_pw) { use_ctx(x);
   if (!d_keys) return fail(MFM_EINVAL, "null key array");
   return mala_step_common(x, 0, 0, d_keys, beta, step, textbook, d_pos, d_logp, d_grad, d_acc, d_isacc, d_prop, d_pw);
 }
 
-extern "C" int mfm_loglik(mfm_ctx* x, const float* d_pos, double* d_out) {
+extern "C" int mfm_loglik(mfm_ctx* x, const float* d_pos, double* d_out) { use_ctx(x);
   NEED_TARGET();
   if (!d_pos || !d_out) return fail(MFM_EINVAL, "null device pointer");
   MalaArgs a = mala_args(x, 1.0);
@@ -555,8 +573,9 @@ static int noise_take(mfm_ctx* x, Key2 key, bool step) {
   return -1;
 }
 
+// eval_valid > 0 (forward only): rows >= eval_valid of the launch are padding (no loss); accumulate: add to *d_loss
 static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_samples, int n, int n_total, int offset, bool train,
-                     double* d_loss, float* d_grads = nullptr) {
+                     double* d_loss, float* d_grads = nullptr, int eval_valid = 0, bool accumulate = false) {
   if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
   if (n <= 0 || n % 16) return fail(MFM_EUNSUPPORTED, "sample count must be a positive multiple of 16 (got %d)", n);
   if (!x->wide && n / 16 > x->loss_cap) return fail(MFM_ETOOLARGE, "n=%d exceeds max_eval_samples given at mfm_create", n);
@@ -572,6 +591,7 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
   a.n_total = n_total; a.chain_offset = offset; a.B = n; a.sigma = x->cfg.sigma; a.cond_flow = x->cfg.cond_flow;
   a.ref_std = x->cfg.ref_std;
   a.n_valid = train && x->cfg.n_chain_valid > 0 ? x->cfg.n_chain_valid : n;      // (padding rows of the chain shard: no loss, no gradient)
+  if (!train && eval_valid > 0) a.n_valid = eval_valid;
   a.pos = d_samples; a.acts = x->acts; a.dzs = x->dzs; a.dacts = x->dacts; a.loss_part = x->loss_part;
   if (x->wide) {      // R rows per pass; the loss is accumulated over the passes
     wide::Ctx* w = x->wide;
@@ -588,14 +608,14 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
       if (rcw) return fail(rcw, "wide fm kernels cannot be launched for this configuration");
       LAUNCHCHK();
       ProfScope ps2_(x, PROF_REDUCE);
-      launch_reduce_loss(w->loss_part, (c.rows + 3) / 4, d_loss, r0 > 0, x->stream);
+      launch_reduce_loss(w->loss_part, (c.rows + 3) / 4, d_loss, r0 > 0 || accumulate, x->stream);
       LAUNCHCHK();
       if (inline_check) x->checked_grads = d_grads;
     }
     return MFM_OK;
   }
   if (train && x->fuse_mala.on) a.mala = x->fuse_mala;      // mfm_train_iter: the iteration's MALA step in the same launch
-  if (train) a.flags_clear = x->flag;
+  if (train) { a.flags_clear = x->flag; a.sus_set = x->flag + 5 + x->sus_par; a.sus_clear = x->flag + 5 + (x->sus_par ^ 1); }
   if (train && x->cfg.cond_flow) {
     const int slot = noise_take(x, key, true);
     if (slot >= 0) {
@@ -610,7 +630,7 @@ static int fm_common(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_sample
   LAUNCHCHK();
   if (train) return MFM_OK;            // the training path totals the loss partials in its slab-reduction kernel
   ProfScope ps2_(x, PROF_REDUCE);
-  launch_reduce_loss(x->loss_part, fm_eval_parts(x->net, n), d_loss, 0, x->stream);
+  launch_reduce_loss(x->loss_part, fm_eval_parts(x->net, n), d_loss, accumulate ? 1 : 0, x->stream);
   LAUNCHCHK();
   return MFM_OK;
 }
@@ -634,6 +654,7 @@ static bool opt_fusable(mfm_ctx* x) {
   // margin for other queues' kernels and for a CU mask narrower than the device (headline: 837 of 2048 on a full MI355X; a
   // 32-CU partition holds 256 and falls back to reduce_slabs + adamw)
   const int grid = (x->net.n_params + 255) / 256;
+  if (x->wsk_G) return !g_sw.no_fused_opt && !x->wide && !x->comm && x->cfg.n_chain_total == x->cfg.n_chain_local;      // (wgrad_sk.hip: no workgroup waits on another)
   return !g_sw.no_fused_opt && !x->wide && !x->comm && x->cfg.n_chain_total == x->cfg.n_chain_local && 2 * grid <= x->opt_resident_wgs;
 }
 
@@ -643,6 +664,35 @@ static int fm_loss_grad_impl(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* 
   x->checked_grads = nullptr;
   int rc = fm_common(x, k0, k1, d_pos, x->cfg.n_chain_local, x->cfg.n_chain_total, x->cfg.chain_offset, true, d_loss, d_grads);
   if (rc || x->wide) return rc;
+  const int sus_par = x->sus_par; x->sus_par ^= 1;      // (the training kernel just wrote flag[5 + sus_par] and cleared the other word)
+  if (x->wsk_G) {
+    // stream-K weight gradients; the last arriver of every block totals it and, with the optimizer, updates it (wgrad_sk.hip)
+    WskArgs k; memset(&k, 0, sizeof k);
+    k.net = x->net; k.ws = x->ws; k.acts = x->acts; k.dzs = x->dzs; k.nbb = x->cfg.n_chain_local / 16; k.n_jobs = x->n_jobs;
+    k.G = x->wsk_G; k.upw_q = x->wsk_q; k.upw_r = x->wsk_r; k.xcd_remap = g_sw.wsk_xcd;
+    k.partials = x->wsk_partials; k.tickets = x->wsk_tickets; k.out = d_grads;
+    k.loss_part = x->loss_part; k.n_part = x->cfg.n_chain_local / 16; k.loss_out = d_loss;
+    for (int j = 0; j < x->n_jobs; ++j) k.jobs[j] = x->h_jobs[j];
+    const bool single1 = x->cfg.n_chain_total == x->cfg.n_chain_local;
+    if (with_optimizer) {
+      const mfm_config& c = x->cfg;
+      k.fuse = 1;
+      k.opt.master = x->master; k.opt.mu = x->mu; k.opt.nu = x->nu; k.opt.Wp = x->Wp; k.opt.WpT = x->WpT; k.opt.bias = x->bias;
+      k.opt.st = x->opt; k.opt.st_next = x->opt_alt; k.opt.flag = x->flag; k.opt.suspicious = x->flag + 5 + sus_par;
+      k.opt.lr0 = c.learning_rate; k.opt.learning_iter = c.learning_iter; k.opt.warmup = c.warmup_steps;
+      k.opt.b1 = c.adam_b1; k.opt.b2 = c.adam_b2; k.opt.eps = (float)c.adam_eps; k.opt.wd = (float)c.weight_decay; k.opt.clip = (float)c.update_clip;
+      k.opt.max_err = 10; k.opt.force_exchange = g_sw.force_exchange ? 1 : 0;
+    } else {
+      k.bad = single1 ? x->flag : nullptr;      // flag[0] was cleared by the training kernel (FmArgs::flags_clear)
+    }
+    { ProfScope ps_(x, PROF_WGRAD); launch_wgrad_sk(k, x->stream); }
+    LAUNCHCHK();
+    if (with_optimizer) {
+      OptState* t = x->opt; x->opt = x->opt_alt; x->opt_alt = t;
+      x->ctr[CTR_OPT_STEPS] += 1;
+    } else x->checked_grads = single1 ? d_grads : nullptr;
+    return MFM_OK;
+  }
   WgradArgs w; memset(&w, 0, sizeof w);
   w.net = x->net; w.ws = x->ws; w.acts = x->acts; w.dzs = x->dzs; w.jobs = x->jobs; w.n_jobs = x->n_jobs;
   w.nbb = x->cfg.n_chain_local / 16; w.split = x->split; w.slabs = x->slabs;
@@ -670,14 +720,36 @@ static int fm_loss_grad_impl(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* 
   x->checked_grads = single ? d_grads : nullptr;
   return MFM_OK;
 }
-extern "C" int mfm_fm_loss_grad(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_pos, double* d_loss, float* d_grads) {
+extern "C" int mfm_fm_loss_grad(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_pos, double* d_loss, float* d_grads) { use_ctx(x);
   return fm_loss_grad_impl(x, k0, k1, d_pos, d_loss, d_grads, false);
 }
 
-extern "C" int mfm_fm_loss(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_samples, int n, int n_total, int offset, double* d_loss) {
+// rows [0, rem) of `src` followed by copies of row rem - 1: the 16-row image of a partial tile (finite padding, never counted)
+__global__ void pad_tile_kernel(const float* src, int rem, int d, float* dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 16 * d; i += gridDim.x * blockDim.x) {
+    const int r = i / d, j = i - r * d;
+    dst[i] = src[(size_t)(r < rem ? r : rem - 1) * d + j];
+  }
+}
+
+extern "C" int mfm_fm_loss(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* d_samples, int n, int n_total, int offset, double* d_loss) { use_ctx(x);
   NEED_TARGET();
+  if (n <= 0) return fail(MFM_EINVAL, "sample count must be positive (got %d)", n);
   if (!d_samples || !d_loss) return fail(MFM_EINVAL, "null device pointer");
-  return fm_common(x, k0, k1, d_samples, n, n_total, offset, false, d_loss);
+  // Any n: the kernels work on 16-row tiles, so the last n % 16 samples go through a 16-row staging tile of the context whose other
+  // rows are padding with residual 0 (FmArgs::n_valid).  Every draw is indexed by the sample's GLOBAL index out of n_total, so the
+  // two launches see the draws one launch over n rows would (eval_step on num_chain * eval_iter samples for ANY --num_chain,
+  // exe_flow_matching.py:370-374, and for any split of them over ranks).
+  const int n_main = n & ~15, rem = n - n_main;
+  if (n_main) {
+    const int rc = fm_common(x, k0, k1, d_samples, n_main, n_total, offset, false, d_loss);
+    if (rc || !rem) return rc;
+  }
+  hipLaunchKernelGGL(pad_tile_kernel, dim3(16), dim3(256), 0, x->stream, d_samples + (size_t)n_main * x->cfg.dim, rem, x->cfg.dim, x->eval_pad);
+  LAUNCHCHK();
+  const int rc = fm_common(x, k0, k1, x->eval_pad, 16, n_total, offset + n_main, false, d_loss, nullptr, rem, n_main > 0);
+  x->ctr[CTR_FM_EVAL] -= 16 - rem;      // (fm_common counted the staging tile's 16 rows)
+  return rc;
 }
 
 // ---- RCCL, resolved at run time ------------------------------------------------------------------------------------------
@@ -725,7 +797,7 @@ extern "C" int mfm_comm_unique_id(uint8_t out[MFM_COMM_ID_BYTES]) {
   return MFM_OK;
 }
 
-extern "C" int mfm_comm_destroy(mfm_ctx* x) {
+extern "C" int mfm_comm_destroy(mfm_ctx* x) { use_ctx(x);
   if (!x) return fail(MFM_EINVAL, "null ctx");
   // keyed on what exists, not on the communicator: a mfm_comm_init that failed half-way leaves a stream / events behind
   if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
@@ -737,7 +809,7 @@ extern "C" int mfm_comm_destroy(mfm_ctx* x) {
   return MFM_OK;
 }
 
-extern "C" int mfm_comm_init(mfm_ctx* x, int nranks, int rank, const uint8_t id_bytes[MFM_COMM_ID_BYTES]) {
+extern "C" int mfm_comm_init(mfm_ctx* x, int nranks, int rank, const uint8_t id_bytes[MFM_COMM_ID_BYTES]) { use_ctx(x);
   if (!x || !id_bytes) return fail(MFM_EINVAL, "null argument");
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(MFM_EINVAL, "bad rank %d of %d", rank, nranks);
   if (x->comm) return fail(MFM_EINVAL, "the context already owns a communicator (mfm_comm_destroy first)");
@@ -762,7 +834,7 @@ extern "C" int mfm_comm_init(mfm_ctx* x, int nranks, int rank, const uint8_t id_
 
 // Ranks of the context's communicator AS RCCL REPORTS THEM (ncclCommCount), 0 without a communicator: what a scaling record
 // cites to show that the all-reduce spanned N ranks.
-extern "C" int mfm_comm_count(mfm_ctx* x, int32_t* out) {
+extern "C" int mfm_comm_count(mfm_ctx* x, int32_t* out) { use_ctx(x);
   if (!x || !out) return fail(MFM_EINVAL, "null argument");
   *out = 0;
   if (!x->comm) return MFM_OK;
@@ -777,7 +849,7 @@ extern "C" int mfm_comm_count(mfm_ctx* x, int32_t* out) {
 // stream, ordered after everything queued on the context's stream so far; returns at once.  Work the caller queues next that
 // touches neither the gradient nor the parameters (the MALA step of the following iteration) overlaps it; the next
 // mfm_adamw_step on the same buffer waits for it.
-extern "C" int mfm_grad_allreduce_begin(mfm_ctx* x, float* d_grads) {
+extern "C" int mfm_grad_allreduce_begin(mfm_ctx* x, float* d_grads) { use_ctx(x);
   if (!x || !d_grads) return fail(MFM_EINVAL, "null argument");
   if (!x->comm) return fail(MFM_EINVAL, "no communicator (mfm_comm_init)");
   if (x->comm_pending) return fail(MFM_EINVAL, "an all-reduce is already in flight: apply it with mfm_adamw_step first");
@@ -790,7 +862,7 @@ extern "C" int mfm_grad_allreduce_begin(mfm_ctx* x, float* d_grads) {
   return MFM_OK;
 }
 
-extern "C" int mfm_adamw_step(mfm_ctx* x, const float* d_grads) {
+extern "C" int mfm_adamw_step(mfm_ctx* x, const float* d_grads) { use_ctx(x);
   if (!x || !d_grads) return fail(MFM_EINVAL, "null argument");
   AdamArgs a = adam_args(x, d_grads, 1);
   a.inline_decide = (x->checked_grads == d_grads) ? 1 : 0;
@@ -820,7 +892,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
 // exe_flow_matching.py:432-439 as one call: generator (:300-314) + train_step (:362-368); see include/mfm.h
 extern "C" int mfm_train_iter(mfm_ctx* x, int64_t count, int K, int flow_mode, uint32_t gk0, uint32_t gk1, uint32_t tk0, uint32_t tk1,
                               double beta, double step_size, float* d_pos, double* d_logp, float* d_grad, float* d_acc,
-                              int32_t* d_nsteps, double* d_loss, float* d_grads, int apply_update) {
+                              int32_t* d_nsteps, double* d_loss, float* d_grads, int apply_update) { use_ctx(x);
   if (!x) return fail(MFM_EINVAL, "null context");
   if (K < 1) return fail(MFM_EINVAL, "mfm_train_iter serves mcmc_per_flow_steps >= 1; compose the other schedules from the separate calls");
   if (count < 0) return fail(MFM_EINVAL, "count must be non-negative");
@@ -859,7 +931,7 @@ extern "C" int mfm_train_iter(mfm_ctx* x, int64_t count, int K, int flow_mode, u
   return mfm_adamw_step(x, d_grads);
 }
 
-extern "C" int mfm_opt_state(mfm_ctx* x, int32_t out[4], float* lr) {
+extern "C" int mfm_opt_state(mfm_ctx* x, int32_t out[4], float* lr) { use_ctx(x);
   if (!x || !out) return fail(MFM_EINVAL, "null argument");
   OptState s;
   HIPCHK(hipStreamSynchronize(x->stream));
@@ -894,7 +966,7 @@ static void tally_solves(mfm_ctx* x, const int* nsteps, int n, int solves_per_sa
   if (nsteps) hipLaunchKernelGGL(tally_attempts_kernel, dim3(1), dim3(256), 0, x->stream, nsteps, n, x->d_att);
 }
 
-extern "C" int mfm_get_counters(mfm_ctx* x, int64_t h_out[8]) {
+extern "C" int mfm_get_counters(mfm_ctx* x, int64_t h_out[8]) { use_ctx(x);
   if (!x || !h_out) return fail(MFM_EINVAL, "null argument");
   unsigned long long att = 0;
   HIPCHK(hipStreamSynchronize(x->stream));
@@ -904,14 +976,14 @@ extern "C" int mfm_get_counters(mfm_ctx* x, int64_t h_out[8]) {
   h_out[CTR_FIELD_EVALS] = 2 * x->ctr[CTR_SOLVES] + 6 * (int64_t)att;      // odeint: f(y0), the initial-step probe, six stages per attempt
   return MFM_OK;
 }
-extern "C" int mfm_reset_counters(mfm_ctx* x) {
+extern "C" int mfm_reset_counters(mfm_ctx* x) { use_ctx(x);
   if (!x) return fail(MFM_EINVAL, "null ctx");
   for (int i = 0; i < 8; ++i) x->ctr[i] = 0;
   HIPCHK(hipMemsetAsync(x->d_att, 0, sizeof(unsigned long long), x->stream));
   return MFM_OK;
 }
 
-extern "C" int mfm_debug_replay(mfm_ctx* x, int cap, const float* d_dt, const uint8_t* d_acc, float* d_ratio, float* d_dt_own, double* d_diag) {
+extern "C" int mfm_debug_replay(mfm_ctx* x, int cap, const float* d_dt, const uint8_t* d_acc, float* d_ratio, float* d_dt_own, double* d_diag) { use_ctx(x);
   if (!x) return fail(MFM_EINVAL, "null ctx");
   if (!d_dt) { memset(&x->replay, 0, sizeof x->replay); return MFM_OK; }          // disarm
   if (!d_acc || !d_ratio || !d_dt_own || cap < 2) return fail(MFM_EINVAL, "mfm_debug_replay needs all four arrays and cap >= 2");
@@ -919,7 +991,7 @@ extern "C" int mfm_debug_replay(mfm_ctx* x, int cap, const float* d_dt, const ui
   return MFM_OK;
 }
 
-extern "C" int mfm_vf_apply(mfm_ctx* x, const float* d_x, const float* d_t, const float* d_tan, int n, float* d_v, float* d_jvp) {
+extern "C" int mfm_vf_apply(mfm_ctx* x, const float* d_x, const float* d_t, const float* d_tan, int n, float* d_v, float* d_jvp) { use_ctx(x);
   NEED_TARGET();
   if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
   if (!d_x || !d_t || !d_v || ((d_tan == nullptr) != (d_jvp == nullptr))) return fail(MFM_EINVAL, "bad pointer arguments");
@@ -936,7 +1008,7 @@ extern "C" int mfm_vf_apply(mfm_ctx* x, const float* d_x, const float* d_t, cons
 }
 
 extern "C" int mfm_ode_transform(mfm_ctx* x, int direction, int per_chain, const uint32_t* d_keys, uint32_t k0, uint32_t k1,
-                                 const float* d_in, int n, float* d_out, float* d_ldj, int32_t* d_nsteps) {
+                                 const float* d_in, int n, float* d_out, float* d_ldj, int32_t* d_nsteps) { use_ctx(x);
   NEED_TARGET();
   if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
   if (!d_in || !d_out || !d_ldj || (per_chain && !d_keys)) return fail(MFM_EINVAL, "null device pointer");
@@ -965,7 +1037,7 @@ extern "C" int mfm_ode_transform(mfm_ctx* x, int direction, int per_chain, const
 }
 
 extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, double beta, float* d_pos, double* d_logp,
-                             float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, int32_t* d_nsteps) {
+                             float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, int32_t* d_nsteps) { use_ctx(x);
   NEED_TARGET();
   if (!x->has_fourier) return fail(MFM_EINVAL, "mfm_set_fourier has not been called");
   if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
@@ -1020,7 +1092,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
   return MFM_OK;
 }
 
-extern "C" int mfm_beta_update(mfm_ctx* x, double prev_beta, const double* d_ll, int n, double alpha, double* h_out) {
+extern "C" int mfm_beta_update(mfm_ctx* x, double prev_beta, const double* d_ll, int n, double alpha, double* h_out) { use_ctx(x);
   if (!x || !d_ll || !h_out) return fail(MFM_EINVAL, "null argument");
   if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
   launch_beta(prev_beta, d_ll, n, alpha, x->beta_out, x->stream);
@@ -1031,7 +1103,7 @@ extern "C" int mfm_beta_update(mfm_ctx* x, double prev_beta, const double* d_ll,
 }
 
 // ---- reference-distribution rows and the CIS selection step ---------------------------------------------------------
-extern "C" int mfm_normal_rows(mfm_ctx* x, const uint32_t* d_keys, int n, float* d_out) {
+extern "C" int mfm_normal_rows(mfm_ctx* x, const uint32_t* d_keys, int n, float* d_out) { use_ctx(x);
   if (!x || !d_keys || !d_out) return fail(MFM_EINVAL, "null argument");
   if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
   launch_probe(0, d_keys, Key2{0, 0}, 0, 0, 0, n, x->cfg.dim, d_out, x->stream);
@@ -1041,7 +1113,7 @@ extern "C" int mfm_normal_rows(mfm_ctx* x, const uint32_t* d_keys, int n, float*
 
 extern "C" int mfm_cis_select(mfm_ctx* x, uint32_t k0, uint32_t k1, int n_is, const float* d_u0, const float* d_vol0, const float* d_refs,
                               const float* d_xs, const float* d_vols, const double* d_lps, float* d_pos, double* d_logp, float* d_acc,
-                              uint8_t* d_isacc, float* d_prop, float* d_weight) {
+                              uint8_t* d_isacc, float* d_prop, float* d_weight) { use_ctx(x);
   if (!x || !d_u0 || !d_vol0 || !d_refs || !d_xs || !d_vols || !d_lps || !d_pos || !d_logp) return fail(MFM_EINVAL, "null argument");
   if (n_is <= 0) return fail(MFM_EINVAL, "num_importance_samples must be positive");
   CisArgs a; memset(&a, 0, sizeof a);
@@ -1069,7 +1141,7 @@ static int pair_call(mfm_ctx* x, int mode, const float* A, const float* GA, cons
   return MFM_OK;
 }
 
-extern "C" int mfm_stein_disc(mfm_ctx* x, const float* d_x, const float* d_grad, int n, double beta, double h_out[2]) {
+extern "C" int mfm_stein_disc(mfm_ctx* x, const float* d_x, const float* d_grad, int n, double beta, double h_out[2]) { use_ctx(x);
   if (!x || !d_x || !d_grad || !h_out) return fail(MFM_EINVAL, "null argument");
   if (n < 2) return fail(MFM_EINVAL, "stein_disc needs at least 2 samples");
   double h[2];
@@ -1080,7 +1152,7 @@ extern "C" int mfm_stein_disc(mfm_ctx* x, const float* d_x, const float* d_grad,
   return MFM_OK;
 }
 
-extern "C" int mfm_max_mean_disc(mfm_ctx* x, const float* d_x, const float* d_y, int m, double* h_out) {
+extern "C" int mfm_max_mean_disc(mfm_ctx* x, const float* d_x, const float* d_y, int m, double* h_out) { use_ctx(x);
   if (!x || !d_x || !d_y || !h_out) return fail(MFM_EINVAL, "null argument");
   if (m < 2) return fail(MFM_EINVAL, "max_mean_disc needs at least 2 samples");
   double xx[2], yy[2], xy[2];
@@ -1093,7 +1165,7 @@ extern "C" int mfm_max_mean_disc(mfm_ctx* x, const float* d_x, const float* d_y,
 }
 
 // ---- noise prefetch (noise.hip) -------------------------------------------------------------------------------------------
-extern "C" int mfm_noise_prefetch(mfm_ctx* x, int n_slots, const uint32_t* h_keys_gn, const uint32_t* h_keys_step) {
+extern "C" int mfm_noise_prefetch(mfm_ctx* x, int n_slots, const uint32_t* h_keys_gn, const uint32_t* h_keys_step) { use_ctx(x);
   NEED_TARGET();
   if (!h_keys_gn || !h_keys_step || n_slots <= 0) return fail(MFM_EINVAL, "bad arguments");
   if (x->wide || !x->cfg.cond_flow || !fast::shape_ok(x->net, x->cfg.hutch))
@@ -1123,14 +1195,14 @@ extern "C" int mfm_noise_prefetch(mfm_ctx* x, int n_slots, const uint32_t* h_key
   w->n_armed = n_slots; w->n_valid = 0;
   return MFM_OK;
 }
-extern "C" int mfm_noise_drop(mfm_ctx* x) {
+extern "C" int mfm_noise_drop(mfm_ctx* x) { use_ctx(x);
   if (!x) return fail(MFM_EINVAL, "null ctx");
   if (x->noise) { x->noise->n_valid = 0; x->noise->n_armed = 0; }
   return MFM_OK;
 }
 
 // ---- N4: adaptive tempered SMC pieces (bblackjax/smc; exe_others.py:79-111) -------------------------------------------
-extern "C" int mfm_smc_delta(mfm_ctx* x, const double* d_ll, int n, double target_ess, double max_delta, double* h_delta) {
+extern "C" int mfm_smc_delta(mfm_ctx* x, const double* d_ll, int n, double target_ess, double max_delta, double* h_delta) { use_ctx(x);
   if (!x || !d_ll || !h_delta) return fail(MFM_EINVAL, "null argument");
   if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
   hipLaunchKernelGGL(smc_delta_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, d_ll, n, target_ess, max_delta, x->beta_out);
@@ -1139,7 +1211,7 @@ extern "C" int mfm_smc_delta(mfm_ctx* x, const double* d_ll, int n, double targe
   HIPCHK(hipStreamSynchronize(x->stream));
   return MFM_OK;
 }
-extern "C" int mfm_smc_weights(mfm_ctx* x, const double* d_ll, int n, double delta, double* d_weights, double* h_lognorm) {
+extern "C" int mfm_smc_weights(mfm_ctx* x, const double* d_ll, int n, double delta, double* d_weights, double* h_lognorm) { use_ctx(x);
   if (!x || !d_ll || !d_weights) return fail(MFM_EINVAL, "null argument");
   if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
   hipLaunchKernelGGL(smc_weights_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, d_ll, n, delta, d_weights, x->beta_out + 1);
@@ -1150,14 +1222,14 @@ extern "C" int mfm_smc_weights(mfm_ctx* x, const double* d_ll, int n, double del
   }
   return MFM_OK;
 }
-extern "C" int mfm_smc_resample(mfm_ctx* x, uint32_t k0, uint32_t k1, const double* d_weights, int n, double* d_scratch, int32_t* d_idx) {
+extern "C" int mfm_smc_resample(mfm_ctx* x, uint32_t k0, uint32_t k1, const double* d_weights, int n, double* d_scratch, int32_t* d_idx) { use_ctx(x);
   if (!x || !d_weights || !d_scratch || !d_idx) return fail(MFM_EINVAL, "null argument");
   if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
   hipLaunchKernelGGL(smc_resample_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, Key2{k0, k1}, d_weights, n, d_scratch, d_idx);
   LAUNCHCHK();
   return MFM_OK;
 }
-extern "C" int mfm_smc_resample_scheme(mfm_ctx* x, int scheme, uint32_t k0, uint32_t k1, const double* d_weights, int n, double* d_scratch, int32_t* d_idx) {
+extern "C" int mfm_smc_resample_scheme(mfm_ctx* x, int scheme, uint32_t k0, uint32_t k1, const double* d_weights, int n, double* d_scratch, int32_t* d_idx) { use_ctx(x);
   if (scheme == MFM_RESAMPLE_SYSTEMATIC) return mfm_smc_resample(x, k0, k1, d_weights, n, d_scratch, d_idx);
   if (!x || !d_weights || !d_scratch || !d_idx) return fail(MFM_EINVAL, "null argument");
   if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
@@ -1166,21 +1238,21 @@ extern "C" int mfm_smc_resample_scheme(mfm_ctx* x, int scheme, uint32_t k0, uint
   LAUNCHCHK();
   return MFM_OK;
 }
-extern "C" int mfm_choice_logw(mfm_ctx* x, uint32_t k0, uint32_t k1, const double* d_logw, int n, int m, double* d_scratch, int32_t* d_idx) {
+extern "C" int mfm_choice_logw(mfm_ctx* x, uint32_t k0, uint32_t k1, const double* d_logw, int n, int m, double* d_scratch, int32_t* d_idx) { use_ctx(x);
   if (!x || !d_logw || !d_scratch || !d_idx) return fail(MFM_EINVAL, "null argument");
   if (n <= 0 || m <= 0) return fail(MFM_EINVAL, "n and m must be positive");
   hipLaunchKernelGGL(choice_logw_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, Key2{k0, k1}, d_logw, n, m, d_scratch, d_idx);
   LAUNCHCHK();
   return MFM_OK;
 }
-extern "C" int mfm_acc_stats(mfm_ctx* x, const float* d_x, int n, double* d_out) {
+extern "C" int mfm_acc_stats(mfm_ctx* x, const float* d_x, int n, double* d_out) { use_ctx(x);
   if (!x || !d_x || !d_out) return fail(MFM_EINVAL, "null argument");
   if (n <= 0) return fail(MFM_EINVAL, "n must be positive");
   hipLaunchKernelGGL(acc_stats_kernel, dim3(1), dim3(SMC_THREADS), 0, x->stream, d_x, n, d_out);
   LAUNCHCHK();
   return MFM_OK;
 }
-extern "C" int mfm_gather_rows(mfm_ctx* x, const float* d_src, const int32_t* d_idx, int n, int dim, float* d_dst) {
+extern "C" int mfm_gather_rows(mfm_ctx* x, const float* d_src, const int32_t* d_idx, int n, int dim, float* d_dst) { use_ctx(x);
   if (!x || !d_src || !d_idx || !d_dst) return fail(MFM_EINVAL, "null argument");
   if (n <= 0 || dim <= 0) return fail(MFM_EINVAL, "n and dim must be positive");
   if (d_src == d_dst) return fail(MFM_EINVAL, "gather_rows is not in-place");
@@ -1195,11 +1267,16 @@ extern "C" int mfm_debug_fm_buffer(unsigned long long* d_buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_fm_dbg), &d_buf, sizeof d_buf) == hipSuccess ? 0 : MFM_EHIP;
 }
 #endif
+#ifdef MFM_WSK_STAMPS
+extern "C" int mfm_debug_wsk_buffer(unsigned long long* d_buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wsk_dbg), &d_buf, sizeof d_buf) == hipSuccess ? 0 : MFM_EHIP;
+}
+#endif
 #ifdef MFM_STAMPS
 extern "C" int mfm_debug_flow_buffer(unsigned long long* d_buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_flow_dbg), &d_buf, sizeof d_buf) == hipSuccess ? 0 : MFM_EHIP;
 }
-extern "C" int mfm_debug_eval_stamps(mfm_ctx* x, const float* d_x, const float* d_t, const float* d_tan, int n, int reps, unsigned long long* d_stamps) {
+extern "C" int mfm_debug_eval_stamps(mfm_ctx* x, const float* d_x, const float* d_t, const float* d_tan, int n, int reps, unsigned long long* d_stamps) { use_ctx(x);
   int rc = launch_eval_stamps(x->net, d_x, d_t, d_tan, n, reps, d_stamps, x->stream);
   if (rc) return fail(rc, "eval_stamps cannot be launched");
   LAUNCHCHK();

@@ -10,7 +10,7 @@
 // One wavefront per chain, float64 weights (they span hundreds of orders of magnitude before normalisation), weights
 // are normalised by their sum exactly as the reference does (no max subtraction: overflow -> NaN -> the reference's
 // behaviour is reproduced, index 0 is chosen by searchsorted on an all-NaN table).
-#include "prng.cuh"
+#include "prng.hip.h"
 
 struct CisArgs {
   Key2 key; uint32_t n_total, chain_offset;

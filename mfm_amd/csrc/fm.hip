@@ -6,8 +6,8 @@
 // jax.value_and_grad(loss_fn, argnums=2) at :364-365.  K3 is fused into the prologue (no HBM round trip for t, x0,
 // eps, cond, target); the loss is the SUM over chains and dims (:178).
 #include <type_traits>
-#include "mlp.cuh"
-#include "prng.cuh"
+#include "mlp.hip.h"
+#include "prng.hip.h"
 
 #ifdef MFM_FM_STAMPS
 __device__ unsigned long long* g_fm_dbg = nullptr;      // [WG][32] section time stamps (development build only)
@@ -52,7 +52,10 @@ struct FmArgs {
   FmMala mala;           // fm_fwd_bwd_kernel<.., MALA = true> only
   int* flags_clear;      // non-null (TRAIN): flag words [0], [3], [4] of the optimizer's scratch, cleared here for the weight-gradient kernel
                          // and the one-launch reduction + optimizer that follow (optim.hip: reduce_adamw_kernel)
+  int* sus_set;          // non-null (TRAIN): raised when a value stored for the weight-gradient kernel is not <= FM_SAFE in magnitude (NaN included):
+  int* sus_clear;        // clear, no sum of <= 2^20 of their products overflows (wgrad_sk.hip).  sus_clear: the OTHER iteration parity's word, reset here
 };
+constexpr float FM_SAFE = 1.0e15f;
 
 struct FmLds {           // float offsets into dynamic LDS
   int ff, ldff, x, ldx, t1, ldt1, cat, ldcat, x1, ldx1, j1, ldj1, j2, ldj2, g, ldg;
@@ -139,7 +142,14 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   float* bDV = lds + L.dv;  float* bD1 = lds + L.d1; float* bD2 = lds + L.d2; float* bDC = lds + L.dcat;
   float* gcs = lds + L.gcs; double* red = reinterpret_cast<double*>(lds + L.red); float* bGC = lds + L.gc;
 
-  if (TRAIN && a.flags_clear && blockIdx.x == 0 && threadIdx.x == 0) { a.flags_clear[0] = 0; a.flags_clear[3] = 0; a.flags_clear[4] = 0; }
+  if (TRAIN && a.flags_clear && blockIdx.x == 0 && threadIdx.x == 0) { a.flags_clear[0] = 0; a.flags_clear[3] = 0; a.flags_clear[4] = 0; if (a.sus_clear) *a.sus_clear = 0; }
+  // running sum of squares of everything this lane stores for the weight-gradient kernel: NaN and infinity propagate, an overflow of the
+  // sum itself only errs on the safe side; one comparison at the end of the kernel (FmArgs::sus_set)
+  float sq_acc = 0.f;
+  auto store_chk = [&](float* base, int tile_row, f32x4 v) {
+    store_packed(base, tile_row, nbb, bb, lane, v);
+    sq_acc = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[3], v[3], sq_acc))));
+  };
   WChain wch; wch.have = false;
   if constexpr (STATIC) {      // the first tile's first fragment group: requested before everything else, it arrives under the prologue
     const __amdgpu_buffer_rsrc_t w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(n.Wp + n.L[0].w_off) + (size_t)wave * (n.L[0].Kp / 16) * 256, 0,
@@ -231,7 +241,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
           bX[(4 * g + i) * L.ldx + 4 + col] = cv[i];
         }
       }
-      if (TRAIN && nt * 16 < n.dp) store_packed(a.acts, a.ws.a_cond + nt, nbb, bb, lane, cv);
+      if (TRAIN && nt * 16 < n.dp) store_chk(a.acts, a.ws.a_cond + nt, cv);
     }
   } else
 #pragma unroll
@@ -263,7 +273,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
         bX[row * L.ldx + 4 + col] = cv[i];
       }
     }
-    if (TRAIN && nt * 16 < n.dp) store_packed(a.acts, a.ws.a_cond + nt, nbb, bb, lane, cv);
+    if (TRAIN && nt * 16 < n.dp) store_chk(a.acts, a.ws.a_cond + nt, cv);
   }
   FM_STAMP(1);
   // Fourier features of t (:70-71): cos block then sin block
@@ -284,8 +294,8 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
         bFF[(4 * g + i) * L.ldff + n.F + col] = sv;
       }
       if (TRAIN) {
-        store_packed(a.acts, a.ws.a_ffat + nt, nbb, bb, lane, cs);
-        store_packed(a.acts, a.ws.a_ffat + FT + nt, nbb, bb, lane, sn);
+        store_chk(a.acts, a.ws.a_ffat + nt, cs);
+        store_chk(a.acts, a.ws.a_ffat + FT + nt, sn);
       }
     }
   } else {
@@ -306,11 +316,11 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) bFF[(4 * g + i) * L.ldff + col] = fv[i];
-      if (TRAIN) store_packed(a.acts, a.ws.a_ffat + nt, nbb, bb, lane, fv);
+      if (TRAIN) store_chk(a.acts, a.ws.a_ffat + nt, fv);
     }
   }
   __syncthreads();
-  if (n.T.kind == MFM_TARGET_GMM && (n.T.n_modes <= 16 ? threadIdx.x < 256 : threadIdx.x < 16)) {      // one mode per lane (targets.cuh)
+  if (n.T.kind == MFM_TARGET_GMM && (n.T.n_modes <= 16 ? threadIdx.x < 256 : threadIdx.x < 16)) {      // one mode per lane (targets.hip.h)
     double lp; float gg[8];
     const int row = n.T.n_modes <= 16 ? (int)(threadIdx.x >> 4) : (int)threadIdx.x;
     if (n.T.n_modes <= 16) gmm_eval_lanes16<8>(n.T, bX + row * L.ldx + 4, threadIdx.x & 15, &lp, gg);
@@ -329,7 +339,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
         v[i] = act_f(acc[i] + bias, n.act);
         out[(4 * g + i) * ldo + coff + nt * 16 + c] = v[i];
       }
-      if (TRAIN) store_packed(a.acts, a_tile + nt, nbb, bb, lane, v);
+      if (TRAIN) store_chk(a.acts, a_tile + nt, v);
       if (TRAIN && n.act >= MFM_ACT_GELU) {          // the derivative the backward epilogue of this tile will need (same lane, same slots)
         f32x4 dv;
 #pragma unroll
@@ -338,7 +348,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
       }
     };
   };
-  // the network's 14 layer GEMMs: on the headline shape with the weight stream chained from tile to tile (mlp.cuh: layer_gemm_chain)
+  // the network's 14 layer GEMMs: on the headline shape with the weight stream chained from tile to tile (mlp.hip.h: layer_gemm_chain)
   auto LG = [&](const float* A, int lda, const float* W, const float* bias, int KB, int NT, auto epi, const float* Wnext, int KBnext) {
     if constexpr (STATIC)
       layer_gemm_chain<1, MLP_WAVES_FM>(A, lda, W, bias, KB, NT, wave, lane, epi, wch, WNext{Wnext ? Wnext + (size_t)wave * KBnext * 256 : nullptr, KBnext});
@@ -402,8 +412,8 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                        if (TRAIN) { bDV[row * L.lddv + col] = dv[i]; bG[row * L.ldg + col] = dg[i]; }
                      }
                      if (TRAIN) {
-                       store_packed(a.dzs, a.ws.z_out + nt, nbb, bb, lane, dv);
-                       store_packed(a.dzs, a.ws.z_gate + nt, nbb, bb, lane, dg);
+                       store_chk(a.dzs, a.ws.z_out + nt, dv);
+                       store_chk(a.dzs, a.ws.z_gate + nt, dg);
                      }
                    }, TRAIN ? n.WpT + n.L[7].w_off : nullptr, n.L[7].Np / 16);
   {
@@ -437,7 +447,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                        z[i] = dmask(bJ2[row * L.ldj2 + col], acc[i], dd, i);
                        bD1[row * L.ldd1 + col] = z[i];
                      }
-                     store_packed(a.dzs, a.ws.z_j2 + nt, nbb, bb, lane, z);
+                     store_chk(a.dzs, a.ws.z_j2 + nt, z);
                    }, n.WpT + n.L[6].w_off, n.L[6].Np / 16);
   __syncthreads();
   // d j1
@@ -451,7 +461,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                        z[i] = dmask(bJ1[row * L.ldj1 + col], acc[i], dd, i);
                        bD2[row * L.ldd2 + col] = z[i];
                      }
-                     store_packed(a.dzs, a.ws.z_j1 + nt, nbb, bb, lane, z);
+                     store_chk(a.dzs, a.ws.z_j1 + nt, z);
                    }, n.WpT + n.L[5].w_off, n.L[5].Np / 16);
   __syncthreads();
   // d [sx | st] through j1; the sx half is finished here (-> dz of x2), the st half waits for the gate path
@@ -467,7 +477,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                        z[i] = is_sx ? dmask(bCat[row * L.ldcat + col], acc[i], dd, i) : acc[i];
                        bDC[row * L.ldcat + col] = z[i];
                      }
-                     if (is_sx) store_packed(a.dzs, a.ws.z_x2 + nt, nbb, bb, lane, z);
+                     if (is_sx) store_chk(a.dzs, a.ws.z_x2 + nt, z);
                    }, n.WpT + n.L[4].w_off, n.L[4].Np / 16);
   __syncthreads();
   // d st += dgate . W_gate^T ; then relu mask -> dz of t2
@@ -482,7 +492,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                        z[i] = dmask(bCat[row * L.ldcat + col], ds, dd, i);
                        bDC[row * L.ldcat + col] = z[i];
                      }
-                     store_packed(a.dzs, a.ws.z_t2 + nt, nbb, bb, lane, z);
+                     store_chk(a.dzs, a.ws.z_t2 + nt, z);
                    }, n.WpT + n.L[3].w_off, n.L[3].Np / 16);
   __syncthreads();
   // d x1 (only needed by wgrad) and d t1
@@ -492,7 +502,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                      const f32x4 dd = dload(a.ws.a_x1, nt);
 #pragma unroll
                      for (int i = 0; i < 4; ++i) z[i] = dmask(bX1[(4 * g + i) * L.ldx1 + nt * 16 + c], acc[i], dd, i);
-                     store_packed(a.dzs, a.ws.z_x1 + nt, nbb, bb, lane, z);
+                     store_chk(a.dzs, a.ws.z_x1 + nt, z);
                    }, n.WpT + n.L[1].w_off, n.L[1].Np / 16);
   LG(bDC + n.hx2, L.ldcat, n.WpT + n.L[1].w_off, nullptr, n.L[1].Np / 16, n.L[1].Kp / 16,
                    [&](int q, int nt, int m, f32x4 acc, float) {
@@ -500,8 +510,9 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                      const f32x4 dd = dload(a.ws.a_t1, nt);
 #pragma unroll
                      for (int i = 0; i < 4; ++i) z[i] = dmask(bT1[(4 * g + i) * L.ldt1 + nt * 16 + c], acc[i], dd, i);
-                     store_packed(a.dzs, a.ws.z_t1 + nt, nbb, bb, lane, z);
+                     store_chk(a.dzs, a.ws.z_t1 + nt, z);
                    }, nullptr, 0);
+  if (a.sus_set && __ballot(!(sq_acc <= FM_SAFE * FM_SAFE)) != 0ull && lane == 0) atomicOr(a.sus_set, 1);
   FM_STAMP(5);
 }
 
@@ -676,7 +687,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64), (MT == 2 ? 4 : 2)) void fm_eva
     };
   };
   auto L_ = [&](int l) -> const LayerDesc& { return n.L[l]; };
-  // the five full-width layers with the weight stream chained from tile to tile (mlp.cuh: layer_gemm_chain) where every K is a
+  // the five full-width layers with the weight stream chained from tile to tile (mlp.hip.h: layer_gemm_chain) where every K is a
   // multiple of 128 (an even number of fragment groups per tile) and each wave owns exactly one column tile per layer
   const bool chain_ok = CHAIN;
   WChain wch; wch.have = false;
@@ -882,7 +893,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const float big = 3.0e38f / (float)a.split;      // |partial| <= big for every slice: the sum over the slices cannot overflow
   bool suspicious = false;
   // the joint layer reads [sx | st] with both halves padded to 16: packed rows [ks_true, ks_pad) are padding, row r >= ks_pad is
-  // canonical row r - ks_pad + ks_true (mlp.cuh: packed_row); every other layer -- and every network whose hidden widths are multiples
+  // canonical row r - ks_pad + ks_true (mlp.hip.h: packed_row); every other layer -- and every network whose hidden widths are multiples
   // of 16 -- has no gap and takes the branch-free store
   const int ks_true = J.layer == 5 ? n.L[3].N : 0, ks_pad = J.layer == 5 ? n.L[3].Np : 0;
   auto put = [&](f32x4 acc, int kt, int nt, auto gap) {

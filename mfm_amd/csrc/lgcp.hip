@@ -1,13 +1,13 @@
 // K1/K2 for the log-Gaussian Cox process target (distributions.py:231-314, cox_process_utils.py:98-165): the one target
 // whose gradient needs a dense contraction, K^-1 (x - mu).  One workgroup per tile of 16 chains; the proposal tile
-// sits in LDS and is multiplied by the packed K^-1 with the same MFMA tile GEMM the MLP kernels use (mlp.cuh), so
+// sits in LDS and is multiplied by the packed K^-1 with the same MFMA tile GEMM the MLP kernels use (mlp.hip.h), so
 // K^-1 is streamed once per 16 chains; everything else (noise, energies, accept) is fused around it.
 //   loglik(x)   = sum_i (x_i c_i - a exp(x_i))                      a = 1/d              (cox_process_utils.py:113-115)
 //   logprior(x) = -1/2 (x - mu)^T K^-1 (x - mu) + log_norm                              (distributions.py:299-303)
 //   grad        = beta (c - a exp(x)) - K^-1 (x - mu)
 // mode 0: mala_init (value and gradient at the given positions); 1: one MALA step (mala.py:86-118, as written).
-#include "mlp.cuh"
-#include "prng.cuh"
+#include "mlp.hip.h"
+#include "prng.hip.h"
 
 #define LGCP_NW 8
 

@@ -10,8 +10,8 @@
 // stride the row (coalesced 256 B per wave instruction), the proposal row is staged in LDS with one zero pad on
 // each side for the stencil, energies are reduced in float64 with wavefront shuffles.  Noise is drawn in-kernel
 // (threefry + float64 erfinv), so the only HBM traffic is the algorithmic 4*(5d+5) bytes per chain.
-#include "prng.cuh"
-#include "targets.cuh"
+#include "prng.hip.h"
+#include "targets.hip.h"
 
 #define MALA_WAVES 4
 #define MALA_MAXD_SMALL 8
@@ -53,7 +53,7 @@ __device__ __forceinline__ double row_value_grad(const TargetDev& T, double beta
       if (j < d) { acc += (double)xs[j] * (double)T.counts[j] - (double)T.poisson_a * (double)expf(xs[j]); gout[it] = 0.f; }
     }
     return beta * wave_sum(acc);
-  } else if (T.n_modes <= 16) {  // GMM, one mode per lane: every 16-lane group of the wave evaluates the row (targets.cuh)
+  } else if (T.n_modes <= 16) {  // GMM, one mode per lane: every 16-lane group of the wave evaluates the row (targets.hip.h)
     double lp = 0.0;
     float g[MALA_MAXD_SMALL];
     gmm_eval_lanes16<MALA_MAXD_SMALL>(T, xs, lane & 15, &lp, g);

@@ -12,7 +12,7 @@
 //
 // Bound: VALU (5 flop-instructions per pair and coordinate for the Stein terms); HBM / L2 traffic is negligible
 // (N d floats re-read N / 64 times from L2).
-#include "common.cuh"
+#include "common.hip.h"
 
 #define PAIR_T 64          // tile edge (pairs)
 #define PAIR_KC 32         // coordinates per LDS chunk

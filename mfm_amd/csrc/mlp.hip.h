@@ -21,8 +21,8 @@
 // row = 4 g + reg) IS the packed activation fragment, so epilogues store it with one float4 per lane and the
 // weight-gradient GEMM (reduction over chains) loads both of its operands as float4 with no transposes.
 #pragma once
-#include "common.cuh"
-#include "targets.cuh"
+#include "common.hip.h"
+#include "targets.hip.h"
 
 #define MLP_NLAYER 8              // layers of the network with TWO hidden layers per branch: what the fused tile kernels are written for
 #define MLP_MAX_DEPTH 3           // hidden layers per branch the wide family takes (exe_flow_matching.py:74-85 loops over lists of any length)

@@ -8,8 +8,8 @@
 // with and without the prefetch.  Slot j holds the draws of the MALA step keyed gn[j] (mala.py:93, util.py:80-82,
 // proposal.py:179) and of the flow-matching batch keyed st[j] (exe_flow_matching.py:153-155,166).
 #pragma once
-#include "common.cuh"
-#include "prng.cuh"
+#include "common.hip.h"
+#include "prng.hip.h"
 
 struct NoiseArgs {
   const uint32_t* gn; const uint32_t* st;     // [n_slots][2] device copies of the keys

@@ -17,8 +17,8 @@
 // The intermediate output times of the "4-mode" example (n_ts = 5) do not change the step sequence (steps are not
 // clamped to output times); they only reset odeint's attempted-step counter, so mxstep is applied per segment as
 // mxstep * (n_ts - 1) attempted steps in total.
-#include "mlp.cuh"
-#include "prng.cuh"
+#include "mlp.hip.h"
+#include "prng.hip.h"
 
 // Gaussian draws the solver kernels consume (Hutchinson probes of both solves, latent random-walk noise) are
 // produced by a small separate kernel into this workspace: the float64 erfinv code would otherwise sit inside the
@@ -277,7 +277,7 @@ struct OdeTile {
       }
     }
     if (N.T.kind == MFM_TARGET_GMM && (N.T.n_modes <= 16 ? threadIdx.x < 256 : threadIdx.x < 16)) {
-      // small-d target: grad / hvp per row -- one mode per lane, 16 lanes per row (targets.cuh); > 16 modes: one thread per row
+      // small-d target: grad / hvp per row -- one mode per lane, 16 lanes per row (targets.hip.h); > 16 modes: one thread per row
       double lp; float gg[8], hv[8];
       const int row = N.T.n_modes <= 16 ? (int)(threadIdx.x >> 4) : (int)threadIdx.x;
       const float* xr = bX() + row * L.ldx + 4;

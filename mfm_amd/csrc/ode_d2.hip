@@ -224,7 +224,7 @@ static bool shape_ok_r(const NetDev& n, int hutch) {
 }
 
 // grad log pi and the DIAGONAL of its Jacobian for a d = 2 mixture, one mode per lane (k = lane & 15): the two calls of
-// gmm_eval_lanes16 with v = e_1, e_2 (targets.cuh) folded into one pass -- (H e_j)_j = sum_k r_k (a_kj^2 - 1/s_kj^2) - g_j^2.
+// gmm_eval_lanes16 with v = e_1, e_2 (targets.hip.h) folded into one pass -- (H e_j)_j = sum_k r_k (a_kj^2 - 1/s_kj^2) - g_j^2.
 __device__ __forceinline__ void gmm_grad_hdiag2(const TargetDev& T, float x0, float x1, int k, float (&gg)[2], float (&hd)[2]) {
   const bool live = k < T.n_modes;
   float comp = -INFINITY, a[2] = {0.f, 0.f}, iv[2] = {0.f, 0.f};

@@ -7,7 +7,7 @@
 // updates; a non-finite gradient zeroes the update and leaves the inner state untouched, up to 10 in a row.
 //
 // The finite check and the step counters live on the device (OptState) so an iteration needs no host sync.
-#include "mlp.cuh"
+#include "mlp.hip.h"
 
 struct OptState {        // device-resident scalars
   int step;              // TrainState.step (every call)
@@ -15,6 +15,8 @@ struct OptState {        // device-resident scalars
   int notfinite_count;   // consecutive non-finite gradients
   int last_applied;      // 1 if the last call changed the parameters
   float last_lr;         // learning_rate_fn(state.step) as logged at :367 (pre-increment step)
+  int bc_for;            // wgrad_sk.hip: bc1 / bc2 below are Adam's bias corrections 1 - b^bc_for (0: not computed; they depend on nothing else,
+  float bc1, bc2;        // so a writer that leaves them alone leaves them valid or visibly stale)
 };
 
 struct AdamArgs {
@@ -95,7 +97,7 @@ __device__ __forceinline__ void adamw_element(const AdamArgs& a, int p, bool app
 
 // One parameter's AdamW + clip update (optax 0.1.9: scale_by_adam, add_decayed_weights on kernels, scale by -lr, clip).  Every
 // multiply-add is an explicit fused operation: the three update kernels (scalar, 4 x 4 blocks, reduction + update) inline this
-// one function and must round alike -- left to the compiler's contraction they need not (targets.cuh: phi4_grad, round 3).
+// one function and must round alike -- left to the compiler's contraction they need not (targets.hip.h: phi4_grad, round 3).
 __device__ __forceinline__ float adam_update(float w, float g, float& m, float& v, float b1, float b2, float bc1, float bc2, float eps, float wd,
                                              bool decay, float lr, float clip) {
   m = __builtin_fmaf(b1, m, (1.f - b1) * g);
@@ -333,7 +335,7 @@ void launch_adamw(const AdamArgs& a, hipStream_t stream) {
     bl.first[l] = bl.n_blocks; bl.n_blocks += (a.net.L[l].K / 4) * (a.net.L[l].N / 4); bl.n_bias_items += a.net.L[l].N;
   }
   bl.first[MLP_MAXL] = bl.n_blocks;
-  vec &= packed_row(a.net, a.net.nT + a.net.nX + 1, a.net.L[a.net.nT + a.net.nX + 1].K - 1) == a.net.L[a.net.nT + a.net.nX + 1].K - 1;      // no row remap (mlp.cuh)
+  vec &= packed_row(a.net, a.net.nT + a.net.nX + 1, a.net.L[a.net.nT + a.net.nX + 1].K - 1) == a.net.L[a.net.nT + a.net.nX + 1].K - 1;      // no row remap (mlp.hip.h)
   if (vec) {
     const int items = bl.n_blocks + bl.n_bias_items, nbv = (items + 255) / 256;
     hipLaunchKernelGGL(adamw_vec_kernel, dim3(nbv < cap ? nbv : cap), block, 0, stream, a, bl);

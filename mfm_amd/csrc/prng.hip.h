@@ -5,7 +5,7 @@
 // conventions; a draw is a pure function of (key, sample index, draw size), so it does not depend on
 // how chains are sharded over workgroups or GPUs.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 struct Key2 { uint32_t k0, k1; };
 

@@ -6,8 +6,8 @@
 //   smc_weights_kernel  base.py:125-128 (normalised weights, log normalising constant) with weigh_fn = delta * loglik (tempered.py:118-119)
 //   smc_resample_kernel resampling.py:50-52,124-135 (systematic: ONE uniform, cumsum, searchsorted(left), clip)
 //   gather_rows_kernel  base.py:120 (particles[resampling_idx])
-#include "common.cuh"
-#include "prng.cuh"
+#include "common.hip.h"
+#include "prng.hip.h"
 
 #define SMC_THREADS 1024
 

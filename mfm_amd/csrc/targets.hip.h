@@ -6,7 +6,7 @@
 // Row convention: a chain's position lives in an LDS row `xs` with one zero pad on EACH side
 // (xs[-1] = xs[d] = 0), so the PhiFour stencil needs no branches.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 enum { MFM_TARGET_PHI4 = 0, MFM_TARGET_GMM = 1, MFM_TARGET_LGCP = 2 };
 

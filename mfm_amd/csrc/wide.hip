@@ -1,4 +1,4 @@
-// The WIDE kernel family: networks / dimensions that do not fit the fused 16-chain LDS tile (mlp.cuh) -- the
+// The WIDE kernel family: networks / dimensions that do not fit the fused 16-chain LDS tile (mlp.hip.h) -- the
 // "pines" configuration of the reference (multi_modal.py:89-96: hidden widths 1024, d = 1024 / 1600; SURVEY.md
 // section 8d config C4).  Same arithmetic and the same C ABI as the fused family; what changes is the data movement:
 //
@@ -21,8 +21,8 @@
 // Replaces the same reference code as fm.hip / ode.hip: exe_flow_matching.py:56-90 (VectorFieldNet), :151-178 (loss),
 // :206-242 (CNF transforms), :246-278 (flow-MH steps), jax.value_and_grad at :364-365.
 #include <type_traits>
-#include "mlp.cuh"
-#include "prng.cuh"
+#include "mlp.hip.h"
+#include "prng.hip.h"
 
 namespace wide {
 
@@ -30,7 +30,7 @@ namespace wide {
 // GEMM:  Y[r][n] = epi( sum_k X[r][k] W[k][n] ),  optionally also the tangent rows YT = epi'( XT W ).
 // ---------------------------------------------------------------------------------------------------------------------
 struct Gemm {
-  const float* W; int KB, NT;            // packed weights [NT][KB][64 lanes] float4 (mlp.cuh "Wp" layout), K blocks, N tiles
+  const float* W; int KB, NT;            // packed weights [NT][KB][64 lanes] float4 (mlp.hip.h "Wp" layout), K blocks, N tiles
   const float* bias;                     // [16 NT] or null
   const float* X; int ldx;               // value rows (row-major, ld multiple of 4)
   const float* XT; int KBT;              // tangent rows (same ld) and the K blocks they span (<= KB); null: no tangent GEMM
@@ -415,7 +415,7 @@ static void launch_gemm(const Gemm& a, hipStream_t s) {
 // Weight gradients: dW[k][n] = sum_r A[r][k] dZ[r][n], db[n] = sum_r dZ[r][n]; one wave per 64 x 64 block of dW.
 // ---------------------------------------------------------------------------------------------------------------------
 struct WgLayer { const float* A; int lda; const float* Z; int ldz; int K, N, Kp, Np, m_w, m_b;
-                 int ks_true, ks_pad; };      // input columns [ks_true, ks_pad) are padding, column c >= ks_pad is canonical row c - ks_pad + ks_true (the first joint layer, mlp.cuh: packed_row)
+                 int ks_true, ks_pad; };      // input columns [ks_true, ks_pad) are padding, column c >= ks_pad is canonical row c - ks_pad + ks_true (the first joint layer, mlp.hip.h: packed_row)
 struct WgJob { int layer, kt, nt; };
 struct WgArgs { WgLayer L[MLP_MAXL]; const WgJob* jobs; int n_jobs; int rows; float* grads;
                 int* bad;      // non-null: raise *bad when a gradient element is not finite (the optimizer's apply_if_finite check)
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void target_kernel(TgtArgs a) {
 }
 
 // The Gaussian mixtures (distributions.py:42-77; d <= 8, the reference forces 2): one thread per chain row walks the modes
-// (targets.cuh: gmm_eval).  Tangent mode: H z by the closed form; diag mode: H_jj from one unit tangent per coordinate.
+// (targets.hip.h: gmm_eval).  Tangent mode: H z by the closed form; diag mode: H_jj from one unit tangent per coordinate.
 __global__ __launch_bounds__(256) void target_gmm_kernel(TgtArgs a) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= a.rows) return;

@@ -2,7 +2,7 @@
 
 Only what the host needs: deriving / splitting keys, one-off draws at set-up time (chain initialisation, Fourier
 frequencies, network initialisation, exact mixture samples).  Per-iteration noise is drawn inside the HIP kernels
-(mfm_amd/csrc/prng.cuh) with the same conventions, so a key means the same stream on both sides.
+(mfm_amd/csrc/prng.hip.h) with the same conventions, so a key means the same stream on both sides.
 Reference call sites: exe_flow_matching.py:333,350,353,371-372,433; distributions.py:70-76,163-164.
 """
 import numpy as np

@@ -69,7 +69,7 @@ def run(dist, args, target_gn=None, params_override=None, beta_override=None, ti
     else:
         states = flow.init_fn(dist.init_params, dist, beta)                              # :431
     key_sample = k["sample"]
-    trace = dict(loss=[], learning_rate=[], acc_mean=[], acc_std=[], target_loss=[], beta=[], n_att=[])
+    trace = dict(loss=[], learning_rate=[], acc_mean=[], acc_std=[], target_loss=[], beta=[], n_att=[], n_moved=[])
     t0 = time.perf_counter()
     for count in range(1, args.learning_iter + 1):                                       # :432
         key_sample, key_gn, key_step = prng.split(key_sample, 3)                         # :433
@@ -78,8 +78,10 @@ def run(dist, args, target_gn=None, params_override=None, beta_override=None, ti
             states = flow.MALAState(target_gn(prng.split(key_gn, n_chain)), None, None)
             infos = flow.MALAInfo(np.full(n_chain, np.nan), None, None, None)
         else:
+            before = states.position
             states, infos = flow.train_data_generator(key_gn, states, count, model, state.params, dist,
                                                       args, beta, stats=stats)           # :438
+            trace["n_moved"].append(int((states.position != before).any(1).sum()))        # (test bookkeeping: chains whose proposal was accepted)
         loss, grads = fm.loss_and_grad(model, state.params, key_step, states.position, args.sigma,
                                        args.cond_flow, ref_std=ref_std)                  # :364-365
         lr = lr_fn(state.step)                                                           # :367

@@ -13,7 +13,7 @@ Reference call sites served: ``exe_flow_matching.py:141-143,153-155,166,212,
 ``distributions.py:70-76,93-97,163-164,313-314``.
 
 The HIP kernels implement exactly these index conventions
-(mfm_amd/csrc/prng.cuh), so a GPU chain and an oracle chain given the same key
+(mfm_amd/csrc/prng.hip.h), so a GPU chain and an oracle chain given the same key
 draw the same numbers (up to float64 erfinv rounding and the final cast to
 float32).
 """

@@ -197,6 +197,50 @@ def test_headline_shape_one_cycle_matches_frozen_oracle_run():
     ex["engine"].close()
 
 
+def test_headline_lattice_with_accepted_flow_proposals_matches_frozen_oracle_run():
+    """The ACCEPTED-state path of the flow-MH step (exe_flow_matching.py:271-278) at the headline lattice, d = 256 with --hutch, on the
+    shape-specialised solver: in the one-cycle run above every proposal is rejected on both sides, so the state a flow step ACCEPTS never
+    reaches a compared quantity there.  Here (`--learning_rate 1e-4 --mcmc_per_flow_steps 3`, 256 chains, 24 iterations of the annealing:
+    tools/make_e2e_golden.py) the oracle accepts 75, 20, 11, 11, 5 and 5 of the 256 proposals of its six flow steps, which integrate
+    non-trivial fields (7 .. 12 attempted steps per inverse solve, 19 .. 60 per forward solve).  An accepted proposal moves its chain by
+    |dx| ~ 2.4, a MALA step by ~ 0.2: the chains' FINAL positions are compared one by one."""
+    g = _gold("phi4_256_accept")
+    o = g[1]
+    flow_it = np.arange(3, 24, 4)
+    assert o["n_moved"][flow_it].sum() >= 100 and (o["n_moved"][flow_it] >= 5).all()          # the fixture does cover the accept path
+    args, res, res_, ex = _run("phi4_256_accept")
+    m = ex["metrics"]
+    K1 = 3
+    pre = dict(loss=_rel(m[:K1, 0], o["loss"][:K1]).max(), beta=_rel(ex["betas"][:K1], o["beta"][:K1]).max(),
+               acc_mean=np.abs(m[:K1, 1] - o["acc_mean"][:K1]).max())
+    print("phi-four d=256 accept-path e2e, iterations 1..3:", {k: f"{v:.1e}" for k, v in pre.items()})
+    assert pre["loss"] < 2e-6 and pre["beta"] < 1e-6 and pre["acc_mean"] < 2e-5, pre
+    np.testing.assert_allclose(ex["lrs"], o["learning_rate"], rtol=1e-12)
+    # the first flow step sees the same chains on both sides: its mean UNCLIPPED ratio (:271-274; exp of log alpha up to ~ 6) in the log
+    la_g, la_o = np.log(m[3, 1]), np.log(o["acc_mean"][3])
+    # per chain: all but the chains whose accept decision was borderline (u within float32 rounding of alpha, or the two adaptive
+    # controllers ending a step apart) went through the same 18 MALA steps and the same accepted / rejected flow proposals
+    pos = ex["states"].position.cpu().numpy().astype(np.float64)
+    ref = o["chain_pos"].astype(np.float64)
+    dmax = np.abs(pos - ref).max(1)
+    same = dmax < 0.05
+    rl = _rel(m[:, 0], o["loss"])
+    sp = _spread(g, "loss")
+    print(f"   first flow step: log mean ratio gpu {la_g:.3f} oracle {la_o:.3f}; final chains: {same.sum()} of 256 within 0.05 of the oracle's (max |d| among them "
+          f"{dmax[same].max():.1e}), the others {np.sort(dmax[~same]).round(2)}; loss rel median {np.median(rl):.1e} max {rl.max():.1e} "
+          f"(seed spread / loss {np.median(sp / o['loss']):.1e})")
+    assert abs(la_g - la_o) < 0.2
+    assert same.sum() >= 240 and dmax[same].max() < 2e-2
+    # a chain that differs changes the loss (a sum over 256 chains) by ~ 1 / 256 of itself and through the gradient every later iteration
+    assert np.median(rl) < 2e-3 and rl.max() < 2e-2
+    dm, ds = np.abs(pos.mean(0) - o["chain_mean"]).max(), np.abs((pos ** 2).mean(0) - o["chain_second"]).max()
+    print(f"   final chains: |d mean| {dm:.1e} (seed spread {_spread(g, 'chain_mean').max():.1e}), |d second| {ds:.1e} (seed spread {_spread(g, 'chain_second').max():.1e}); "
+          f"logpdf gpu {res[0]:.1f} oracle {float(o['logpdf']):.1f} (seed spread {float(_spread(g, 'logpdf')):.1f})")
+    assert dm < 0.25 * _spread(g, "chain_mean").max() and ds < 0.25 * _spread(g, "chain_second").max()
+    assert abs(res[0] - float(o["logpdf"])) < 0.25 * float(_spread(g, "logpdf"))
+    ex["engine"].close()
+
+
 @pytest.mark.parametrize("case", ["gmm16", "pines"])
 def test_loop_of_the_other_baseline_configurations_matches_frozen_oracle_runs(case):
     """The training loop of BASELINE configs[1] (16-mode mixture, 4096 chains, K = 100, exact trace, `eval_step` on 409,600 exact

@@ -56,8 +56,10 @@ def test_calls_in_the_wrong_state_or_with_bad_sizes_raise():
     with pytest.raises(_lib.MfmError, match="mfm_set_fourier"):
         ctx.fm_loss_grad((0, 1), pos, loss, g)
     ctx.set_fourier(np.ones(16, dtype=np.float32))
-    with pytest.raises(_lib.MfmError, match="multiple of 16"):
-        ctx.fm_loss((0, 1), pos[:24], loss)
+    ctx.fm_loss((0, 1), pos[:24], loss)                       # any n > 0 (a last partial tile is staged inside the library) ...
+    assert np.isfinite(loss.item())
+    with pytest.raises(_lib.MfmError, match="must be positive"):
+        ctx.fm_loss((0, 1), pos[:0], loss)                    # ... but not none
     with pytest.raises(_lib.MfmError, match="max_eval_samples"):
         ctx.fm_loss((0, 1), torch.zeros(64, 64, device="cuda"), loss)
     out = torch.zeros(32, 64, device="cuda"); ldj = torch.zeros(32, device="cuda")

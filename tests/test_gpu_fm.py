@@ -47,6 +47,31 @@ def test_fm_loss_and_grad_match_oracle(setup, d, B, hidden, F):
     ctx.close()
 
 
+@pytest.mark.parametrize("family", ["tile", "wide"])
+@pytest.mark.parametrize("n", [8, 56, 150])
+def test_eval_loss_on_a_sample_count_that_is_not_a_multiple_of_16(family, n):
+    """mfm_fm_loss (eval_step, exe_flow_matching.py:370-374) takes any n: the last n % 16 samples go through a staged 16-row
+    tile with residual 0 on its padding rows; draws are indexed by the global sample index, so a shard [start, start + n) of
+    n_total equals the oracle on the same shard."""
+    import torch
+    from mfm_amd import _lib
+    from tests import gpu_util as gu
+    args, dist, k, model, state = gu.gmm4_setup(B=160, hidden=32, F=16)
+    params = gu.rand_params(model, seed=5)
+    ctx = gu.make_ctx(dist, args, fourier=model.f, params=params, max_eval=160, family=_lib.FAMILY_WIDE if family == "wide" else None)
+    xs = dist.sample_model_rows(prng.split(prng.PRNGKey(3), 160)).astype(np.float32)
+    key = prng.PRNGKey(12)
+    for start, n_total in ((0, n), (7, 160)):
+        if start + n > n_total:
+            continue
+        lo, _ = fm.loss_and_grad(model, params, key, xs[start:start + n].astype(np.float64), args.sigma, n_total=n_total, start=start, need_grad=False)
+        l = torch.zeros(1, dtype=torch.float64, device="cuda")
+        ctx.fm_loss(key, _dev(xs[start:start + n]), l, n_total=n_total, offset=start)
+        assert abs(l.item() - lo) <= 2e-5 * abs(lo), (start, n, l.item(), lo)
+    assert ctx.counters()["fm_eval_samples"] == n * (1 + (7 + n <= 160))
+    ctx.close()
+
+
 def test_fm_zero_init_loss_is_target_norm():
     import torch
     from tests import gpu_util as gu

@@ -131,6 +131,25 @@ def test_four_mode_loop_matches_oracle(hutch):
     ex["engine"].close()
 
 
+def test_four_mode_loop_with_an_eval_set_that_is_not_a_multiple_of_16():
+    """--num_chain 50 on a mixture example: eval_step (exe_flow_matching.py:370-374, :444-446) runs on num_chain * eval_iter = 150
+    exact samples every iteration -- 9 full 16-row tiles and a partial one, which mfm_fm_loss stages inside the library (it used
+    to decline any n % 16 != 0, so every such run aborted at its first iteration with the default eval_iter)."""
+    from mfm_amd import distributions as D, exe_flow_matching as E
+    from oracle import loop, targets
+    from tests import gpu_util as gu
+    common = dict(example="4-mode", dim=2, num_chain=50, learning_iter=5, mcmc_per_flow_steps=3.0, hutchs=False, fourier_dim=16, seed=1024,
+                  eval_iter=3, step_size=0.2, **gu.hidden_lists(32))
+    modes, covs, w = 8.0 * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1.0]]), np.ones((4, 2)), np.ones(4) / 4
+    dg, do = D.GaussianMixture(modes, covs, w), targets.GaussianMixture(modes, covs, w)
+    out = loop.run(do, _args(**common), target_gn=do.sample_model_rows)
+    res, res_, ex = E.run(dg, _args(**common), dg.sample_model, log_every=1000, return_extras=True)
+    tr, m = out["trace"], ex["metrics"]
+    np.testing.assert_allclose(m[:3, 0], tr["loss"][:3], rtol=1e-5)
+    np.testing.assert_allclose(m[:, 3], tr["target_loss"], rtol=1e-3)
+    ex["engine"].close()
+
+
 def test_pines_loop_matches_oracle():
     """Log-Gaussian Cox process on a 16 x 16 grid (dim > 128, so the +-1 clip of grad log pi is active as in the
     reference's 40 x 40 example, whose hidden width of 1024 does not fit the 16-chain LDS tile): annealing with a prior

@@ -355,11 +355,11 @@ def test_wide_exact_trace_flow_step_on_prescribed_steps():
 
 def test_wide_exact_trace_at_the_pines_width_on_prescribed_steps():
     """32 x 32 grid, hidden 1024 (the pines network of BASELINE configs[4] / multi_modal.py:96) with the exact trace: sixteen chains on
-    the GPU, the oracle's d = 1024 tangent columns on four of them (the other twelve replay those four inputs and step sequences, so
-    every row of the 16-row GEMM tiles is checked and equal inputs must give equal outputs)."""
+    the GPU, the oracle's d = 1024 tangent columns on two of them (75 s of oracle time; the other fourteen replay those two inputs and step
+    sequences, so every row of the 16-row GEMM tiles is checked and equal inputs must give equal outputs)."""
     import torch
     from tests.test_gpu_replay import _replay_arrays
-    B, Bo, d = 16, 4, 1024
+    B, Bo, d = 16, 2, 1024
     from tests import gpu_util as gu
     args, dist, k, model, state = _setup("lgcp", d, B, 1024, 128, hutch=False)
     params = gu.rand_params(model, seed=9, out_scale=2.0)          # 12-15 attempted steps, |log-det| ~ 1, points move by ~5
@@ -418,13 +418,13 @@ def test_wide_fm_loss_and_grad_at_the_reference_pines_default():
 def test_wide_flow_step_at_the_reference_pines_default_on_prescribed_steps():
     """One Hutchinson flow-MH step (exe_flow_matching.py:264-278) at d = 1600 / 128 chains / hidden 1024 on the oracle's step sequences:
     attempt counts exact, proposal, both log-dets, log alpha term by term, decisions.  The kernels integrate all 128 chains; the float64
-    oracle (minutes for 128 chains at this width) checks the first 8, the others replay one of those 8 step sequences, which ends by
+    oracle (minutes for 128 chains at this width) checks the first 4, the others replay one of those 4 step sequences, which ends by
     itself (as in tests/test_gpu_rank_slices.py)."""
     import torch
     from mfm_amd import _lib
     from tests import gpu_util as gu
     from tests.test_gpu_replay import _replay_arrays
-    B, Bo, d = 128, 8, 1600
+    B, Bo, d = 128, 4, 1600
     args, dist, k, model, state = gu.lgcp_setup(n=40, B=B, hidden=1024, F=128)
     params = gu.rand_params(model, seed=9, out_scale=2.0)
     params[4]["kernel"] *= 0.05; params[4]["bias"] *= 0.05

@@ -23,6 +23,23 @@ def test_library_exports_every_symbol_declared_in_header():
     assert _lib.load().mfm_version() == 1
 
 
+def test_build_retries_without_the_scheduler_flag_when_hipcc_rejects_it(tmp_path, monkeypatch, capfd):
+    """mfm_amd/build.py: `-mllvm -amdgpu-sched-strategy=max-ilp` is an internal LLVM option; a toolchain that no longer knows it
+    must still produce the library (default strategy), and say so."""
+    from mfm_amd import build
+    (tmp_path / "tiny.hip").write_text('extern "C" int tiny_answer(void) { return 42; }\n')
+    monkeypatch.setattr(build, "CSRC", str(tmp_path))
+    monkeypatch.setattr(build, "SOURCES", ["tiny.hip"])
+    monkeypatch.setattr(build, "LIB", str(tmp_path / "libtiny.so"))
+    monkeypatch.setattr(build, "SCHED_FLAGS", ["-mllvm", "-amdgpu-sched-strategy-of-a-future-rocm=max-ilp"])
+    assert build.build(force=True) == str(tmp_path / "libtiny.so")
+    assert ctypes.CDLL(build.LIB).tiny_answer() == 42
+    assert "default scheduling strategy" in capfd.readouterr().err
+    monkeypatch.setattr(build, "SOURCES", ["missing.hip"])          # any other failure still raises
+    with pytest.raises(Exception):
+        build.build(force=True)
+
+
 def test_ctypes_config_mirrors_the_header_struct_field_for_field():
     """mfm_config crosses the C ABI by value layout: the ctypes mirror must list the header's members in order, with the same types."""
     from mfm_amd import _lib

@@ -33,6 +33,14 @@ CASES = {
     # BASELINE configs[2], the headline: phi-four d = 256, 4096 chains, K = 100, --hutch -- one full MALA / flow cycle + 2 iterations
     "phi4_256": dict(example="phi-four", dim=256, num_chain=4096, learning_iter=103, mcmc_per_flow_steps=100.0, step_size=1e-4,
                      eval_iter=1, hutchs=True),
+    # The headline SHAPE with flow proposals that are ACCEPTED: at lr 1e-3 the Hutchinson log-det of the d = 256 field makes every
+    # flow-MH proposal of phi4_256 a rejection (log alpha ~ -700 .. -9000 after one cycle, on both sides), so that case never
+    # exercises the accepted-state path.  With --learning_rate 1e-4 (a flag of the reference, multi_modal.py:199) the field grows
+    # slowly enough: over the first 24 iterations of the annealing (beta 1e-4 .. 1.3e-3) the six flow steps (K = 3) integrate
+    # non-trivial fields (8 .. 10 attempted steps per inverse solve, 17 .. 45 per forward solve) and a sizeable share of their
+    # proposals is accepted (mean unclipped ratio 0.02 .. 4).  256 chains, --hutch.
+    "phi4_256_accept": dict(example="phi-four", dim=256, num_chain=256, learning_iter=24, mcmc_per_flow_steps=3.0, step_size=1e-4,
+                            eval_iter=1, hutchs=True, learning_rate=1e-4),
     # BASELINE configs[1]: the 16-mode mixture, 4096 chains, K = 100, exact trace, eval_step on 409,600 exact samples every iteration
     # (the LOOP only: its final sampling is 409,600 exact-trace solves, hours of oracle time)
     "gmm16": dict(example="gaussian-mixture", dim=2, num_chain=4096, learning_iter=103, mcmc_per_flow_steps=100.0, step_size=0.2,
@@ -42,6 +50,8 @@ CASES = {
                   eval_iter=1, hutchs=True, hidden_x=[1024, 1024], hidden_t=[1024, 1024], hidden_xt=[1024, 1024]),
 }
 NO_FINAL = ("gmm16",)
+# cases that keep EVERY chain's final position of every seed (per-chain comparison of the accepted flow proposals)
+FULL_POS = ("phi4_256_accept",)
 
 
 def make_dist(case):
@@ -76,11 +86,11 @@ def run_one(job):
     out = loop.run(dist, args, target_gn=target_gn, timer=timer)
     tr = out["trace"]
     res = dict(seed=seed, loss=np.array(tr["loss"]), learning_rate=np.array(tr["learning_rate"]), beta=np.array(tr["beta"]),
-               acc_mean=np.array(tr["acc_mean"]), acc_std=np.array(tr["acc_std"]), n_att=np.array(tr["n_att"]),
+               acc_mean=np.array(tr["acc_mean"]), acc_std=np.array(tr["acc_std"]), n_att=np.array(tr["n_att"]), n_moved=np.array(tr["n_moved"]),
                target_loss=np.array(tr["target_loss"]) if tr["target_loss"] else np.zeros(0))
     pos = out["states"].position
     res.update(chain_mean=pos.mean(0), chain_second=(pos[:, :, None] * pos[:, None, :]).mean(0) if pos.shape[1] <= 8 else (pos ** 2).mean(0),
-               chain_logdensity_mean=out["states"].logdensity.mean(), chain_pos=pos.astype(np.float32) if pos.shape[1] == 2 else pos[:64, :64].astype(np.float32))
+               chain_logdensity_mean=out["states"].logdensity.mean(), chain_pos=pos.astype(np.float32) if pos.shape[1] == 2 or case in FULL_POS else pos[:64, :64].astype(np.float32))
     print(f"[{case} seed {seed}] loop done in {time.time() - t0:.0f} s; final sampling", flush=True)
     if case in NO_FINAL:
         res["oracle_seconds"] = time.time() - t0
