@@ -71,8 +71,9 @@ struct mfm_ctx {
   float *master, *mu, *nu, *Wp, *WpT, *bias, *fourier;
   float *acts, *dzs, *slabs, *dacts;
   double* loss_part; int loss_cap;
-  float* wsk_partials = nullptr; int* wsk_tickets = nullptr;      // stream-K weight gradients (wgrad_sk.hip): partial blocks, arrival counters
-  int wsk_G = 0, wsk_q = 0, wsk_r = 0;                              // its grid and units per workgroup (0: the slab kernels serve this context)
+  float* wsk_partials = nullptr; int* wsk_tickets = nullptr;      // stream-K weight gradients (wgrad_sk.hip): partial blocks, arrival counters [2][n_jobs]
+  WskConst* wsk_const = nullptr; WskWg* wsk_wg = nullptr;           // its tables, in device memory
+  int wsk_G = 0, wsk_par = 0;                                       // its grid (0: the slab kernels serve this context), parity of the arrival counters
   int sus_par = 0;                                                  // parity of the training kernel's "suspicious values" word (flag[5 + parity])
   float* eval_pad = nullptr;   // [16][dim]: the last, partial 16-row tile of a mfm_fm_loss call whose n is not a multiple of 16
   WgradJob* jobs; int n_jobs, split;
@@ -307,9 +308,50 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
   ALLOC(x->loss_part, x->loss_cap);
   ALLOC(x->eval_pad, (size_t)16 * c.dim);
   if (!use_wide && x->n_jobs <= WSK_MAXJOBS && !getenv("MFM_WGRAD_SLABS")) {      // (MFM_WGRAD_SLABS=1: the round-1..4 slab kernels, for A/B)
-    wsk_plan(x->n_jobs, nbb, x->wsk_G, x->wsk_q, x->wsk_r);
-    ALLOC(x->wsk_partials, (size_t)2 * x->wsk_G * WSK_PSZ); ALLOC(x->wsk_tickets, x->n_jobs);
-    HIPCHK(hipMemset(x->wsk_tickets, 0, (size_t)x->n_jobs * sizeof(int)));
+    // stream-K weight gradients + optimizer in one launch (wgrad_sk.hip).  Its workgroups WAIT for the other contributors of their
+    // block, so every workgroup of the grid must be resident at once: the grid never exceeds what the runtime says this device (a
+    // full MI355X, a partition ...) holds of this kernel; a device that cannot hold one workgroup per block keeps the slab kernels.
+    int dev = 0, per_cu = 0, cus = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_sk_kernel, 256, 0));
+    WskConst h; memset(&h, 0, sizeof h);
+    int G = 0;
+    if (per_cu * cus >= x->n_jobs) wsk_plan(x->n_jobs, nbb, per_cu * cus, G, h.upw_q, h.upw_r);
+    if (G >= x->n_jobs && h.upw_q >= 1) {
+      h.net = n; h.nbb = nbb; h.n_jobs = x->n_jobs; h.G = G;
+      ALLOC(x->wsk_partials, (size_t)2 * G * WSK_PSZ); ALLOC(x->wsk_tickets, 2 * x->n_jobs); ALLOC(x->wsk_const, 1);
+      HIPCHK(hipMemset(x->wsk_tickets, 0, (size_t)2 * x->n_jobs * sizeof(int)));
+      h.acts = x->acts; h.dzs = x->dzs; h.partials = x->wsk_partials;
+      h.master = x->master; h.mu = x->mu; h.nu = x->nu; h.Wp = x->Wp; h.WpT = x->WpT; h.bias = x->bias;
+      h.lr0 = c.learning_rate; h.learning_iter = c.learning_iter; h.warmup = c.warmup_steps;
+      h.b1 = c.adam_b1; h.b2 = c.adam_b2; h.eps = (float)c.adam_eps; h.wd = (float)c.weight_decay; h.clip = (float)c.update_clip; h.max_err = 10;
+      for (int j = 0; j < x->n_jobs; ++j) {
+        const WgradJob& J = jobs[j];
+        WskJob& o = h.jobs[j];
+        o.layer = J.layer; o.kt0 = J.kt0; o.nt0 = J.nt0;
+        const int KT = n.L[J.layer].Kp / 16, NT = n.L[J.layer].Np / 16;
+        for (int wv = 0; wv < 4; ++wv) {
+          o.a_row[wv] = wgrad_a_tile(n, x->ws, J.layer, J.kt0 + wv < KT ? J.kt0 + wv : J.kt0);
+          o.z_row[wv] = wgrad_z_tile(x->ws, J.layer, J.nt0 + wv < NT ? J.nt0 + wv : J.nt0);
+        }
+        h.n_slices += wsk_wg_of(h.upw_q, h.upw_r, (j + 1) * nbb - 1) - wsk_wg_of(h.upw_q, h.upw_r, j * nbb) + 1;
+      }
+      HIPCHK(hipMemcpy(x->wsk_const, &h, sizeof h, hipMemcpyHostToDevice));
+      std::vector<WskWg> wg(G);
+      for (int wq = 0; wq < G; ++wq) {
+        WskWg& d = wg[wq];
+        const int u0 = wsk_start(h.upw_q, h.upw_r, wq);
+        d.cnt = h.upw_q + (wq < h.upw_r ? 1 : 0); d.j0 = u0 / nbb; d.bb0 = u0 - d.j0 * nbb; d.n0 = d.cnt < nbb - d.bb0 ? d.cnt : nbb - d.bb0;
+        for (int sg = 0; sg < 2; ++sg) {
+          const WskJob& J = h.jobs[d.j0 + sg < x->n_jobs ? d.j0 + sg : d.j0];
+          for (int wv = 0; wv < 4; ++wv) { d.a_row[sg][wv] = J.a_row[wv]; d.z_row[sg][wv] = J.z_row[wv]; }
+        }
+      }
+      ALLOC(x->wsk_wg, G);
+      HIPCHK(hipMemcpy(x->wsk_wg, wg.data(), sizeof(WskWg) * G, hipMemcpyHostToDevice));
+      x->wsk_G = G;
+    }
   }
   ALLOC(x->jobs, x->n_jobs); ALLOC(x->opt, 1); ALLOC(x->opt_alt, 1); ALLOC(x->flag, 8); ALLOC(x->beta_out, 4);
   ALLOC(x->d_att, 1); HIPCHK(hipMemset(x->d_att, 0, sizeof(unsigned long long)));
@@ -343,7 +385,7 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
 extern "C" int mfm_destroy(mfm_ctx* x) { use_ctx(x);
   if (!x) return MFM_OK;
   hipDeviceSynchronize();
-  void* ps[] = {x->master, x->mu, x->nu, x->Wp, x->WpT, x->bias, x->fourier, x->acts, x->dzs, x->dacts, x->slabs, x->loss_part, x->eval_pad, x->wsk_partials, x->wsk_tickets,
+  void* ps[] = {x->master, x->mu, x->nu, x->Wp, x->WpT, x->bias, x->fourier, x->acts, x->dzs, x->dacts, x->slabs, x->loss_part, x->eval_pad, x->wsk_partials, x->wsk_tickets, x->wsk_const, x->wsk_wg,
                 x->jobs, x->opt, x->opt_alt, x->flag, x->gmm_mode, x->gmm_std, x->gmm_logw, x->counts, x->Kinv, x->kbias, x->kdiag, x->beta_out,
                 x->d_att, x->att_buf};
   for (void* p : ps) if (p) hipFree(p);
@@ -668,24 +710,20 @@ static int fm_loss_grad_impl(mfm_ctx* x, uint32_t k0, uint32_t k1, const float* 
   if (x->wsk_G) {
     // stream-K weight gradients; the last arriver of every block totals it and, with the optimizer, updates it (wgrad_sk.hip)
     WskArgs k; memset(&k, 0, sizeof k);
-    k.net = x->net; k.ws = x->ws; k.acts = x->acts; k.dzs = x->dzs; k.nbb = x->cfg.n_chain_local / 16; k.n_jobs = x->n_jobs;
-    k.G = x->wsk_G; k.upw_q = x->wsk_q; k.upw_r = x->wsk_r; k.xcd_remap = g_sw.wsk_xcd;
-    k.partials = x->wsk_partials; k.tickets = x->wsk_tickets; k.out = d_grads;
+    k.C = x->wsk_const; k.wg = x->wsk_wg; k.acts = x->acts; k.dzs = x->dzs; k.nbb = x->cfg.n_chain_local / 16; k.G = x->wsk_G;
+    k.xcd_remap = g_sw.wsk_xcd ? 1 : 0;
+    k.tickets = x->wsk_tickets + x->wsk_par * x->n_jobs; k.tickets_clear = x->wsk_tickets + (x->wsk_par ^ 1) * x->n_jobs; x->wsk_par ^= 1;
+    k.out = d_grads;
     k.loss_part = x->loss_part; k.n_part = x->cfg.n_chain_local / 16; k.loss_out = d_loss;
-    for (int j = 0; j < x->n_jobs; ++j) k.jobs[j] = x->h_jobs[j];
     const bool single1 = x->cfg.n_chain_total == x->cfg.n_chain_local;
     if (with_optimizer) {
-      const mfm_config& c = x->cfg;
       k.fuse = 1;
-      k.opt.master = x->master; k.opt.mu = x->mu; k.opt.nu = x->nu; k.opt.Wp = x->Wp; k.opt.WpT = x->WpT; k.opt.bias = x->bias;
-      k.opt.st = x->opt; k.opt.st_next = x->opt_alt; k.opt.flag = x->flag; k.opt.suspicious = x->flag + 5 + sus_par;
-      k.opt.lr0 = c.learning_rate; k.opt.learning_iter = c.learning_iter; k.opt.warmup = c.warmup_steps;
-      k.opt.b1 = c.adam_b1; k.opt.b2 = c.adam_b2; k.opt.eps = (float)c.adam_eps; k.opt.wd = (float)c.weight_decay; k.opt.clip = (float)c.update_clip;
-      k.opt.max_err = 10; k.opt.force_exchange = g_sw.force_exchange ? 1 : 0;
+      k.st = x->opt; k.st_next = x->opt_alt; k.flag = x->flag; k.suspicious = x->flag + 5 + sus_par;
+      k.force_exchange = g_sw.force_exchange ? 1 : 0;
     } else {
       k.bad = single1 ? x->flag : nullptr;      // flag[0] was cleared by the training kernel (FmArgs::flags_clear)
     }
-    { ProfScope ps_(x, PROF_WGRAD); launch_wgrad_sk(k, x->stream); }
+    { ProfScope ps_(x, PROF_WGRAD); launch_wgrad_sk(k, x->wsk_G, x->stream); }
     LAUNCHCHK();
     if (with_optimizer) {
       OptState* t = x->opt; x->opt = x->opt_alt; x->opt_alt = t;

@@ -21,7 +21,7 @@ struct Switches {
   bool wide_nolds = false, wide_no_small_tiles = false, wide_wm1 = false, wide_ring8 = false, wide_wgrad_nosplit = false;
   bool wide_nocompact = false, wide_no_tbatch = false;
   bool tile_exact = false;  // exact-trace solves of the fused family on its own generic tile instead of the wide family's solver (api.hip: wide_ex)
-  bool wsk_xcd = false;     // wgrad_sk.hip: consecutive unit ranges on one XCD (A/B)
+  bool wsk_xcd = false;     // wgrad_sk.hip: consecutive unit ranges on one XCD instead of workgroup w = blockIdx.x (A/B, with MFM_WSK_G)
   int flow_live = 0;        // chains per workgroup of the shape-specialised flow step: 0 automatic, 16 / 8 / 4 / 2 forced (ode_fast.hip: flow_live_rows)
 };
 static Switches g_sw;

@@ -796,7 +796,7 @@ struct WgradArgs {
                            // is non-finite or so large that the sum over the slices could overflow; cleared by the training kernel
 };
 
-__device__ __forceinline__ int wgrad_a_tile(const NetDev& n, const WsLayout& w, int layer, int kt) {
+__host__ __device__ __forceinline__ int wgrad_a_tile(const NetDev& n, const WsLayout& w, int layer, int kt) {
   switch (layer) {
     case 0: return w.a_ffat + kt;
     case 1: return w.a_t1 + kt;
@@ -808,7 +808,7 @@ __device__ __forceinline__ int wgrad_a_tile(const NetDev& n, const WsLayout& w, 
     default: return w.a_j2 + kt;
   }
 }
-__device__ __forceinline__ int wgrad_z_tile(const WsLayout& w, int layer, int nt) {
+__host__ __device__ __forceinline__ int wgrad_z_tile(const WsLayout& w, int layer, int nt) {
   switch (layer) {
     case 0: return w.z_t1 + nt;
     case 1: return w.z_t2 + nt;

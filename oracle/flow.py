@@ -28,12 +28,18 @@ def _accept(keys_acc, a, prev, prop):
     return state, info
 
 
+def fixed_mode(args):
+    """``(method, nsteps)`` of the build-side fixed-step mode (``--ode_method rk4|euler --ode_steps N``), or None: the reference's Dopri5."""
+    n = int(getattr(args, "ode_steps", 0) or 0)
+    return (getattr(args, "ode_method", "rk4"), n) if n > 0 else None
+
+
 def rwmh_step(keys, prev, value_and_grad, model, params, args, stats=None, replay=None, round32=False):
     """``exe_flow_matching.py:264-278``.  ``replay = dict(inv=..., fwd=...)``: prescribed step sequences of the two
     solves (parity instrumentation, see ``ode.odeint``)."""
     B, d = prev.position.shape
     kk = prng.split_rows(keys, 4)                      # :265 key_gen, key_acc, key_hutch1, key_hutch2
-    o = dict(hutch=args.hutchs, rtol=args.rtol, atol=args.atol, mxstep=args.mxstep, n_ts=args.n_ts)
+    o = dict(hutch=args.hutchs, rtol=args.rtol, atol=args.atol, mxstep=args.mxstep, n_ts=args.n_ts, fixed=fixed_mode(args))
     st_inv = {} if stats is not None else None
     st_fwd = {} if stats is not None else None
     rp = replay or {}
@@ -56,7 +62,7 @@ def imh_step(keys, prev, value_and_grad, model, params, args, stats=None, replay
     B, d = prev.position.shape
     ref = IndepGaussian(d, var=REF_VARS[getattr(args, "ref_dist", "stdgauss")])
     kk = prng.split_rows(keys, 4)                      # :247
-    o = dict(hutch=args.hutchs, rtol=args.rtol, atol=args.atol, mxstep=args.mxstep, n_ts=args.n_ts)
+    o = dict(hutch=args.hutchs, rtol=args.rtol, atol=args.atol, mxstep=args.mxstep, n_ts=args.n_ts, fixed=fixed_mode(args))
     st_inv = {} if stats is not None else None
     st_fwd = {} if stats is not None else None
     rp = replay or {}
@@ -81,7 +87,7 @@ def cis_step(keys, prev, value_and_grad, model, params, args, stats=None):
     n_is = int(args.num_importance_samples)
     ref = IndepGaussian(d, var=REF_VARS[getattr(args, "ref_dist", "stdgauss")])
     kk = prng.split_rows(keys, 4)                      # :281 key_sample, key_hutch_prev, key_hutch, key_choice
-    o = dict(hutch=args.hutchs, rtol=args.rtol, atol=args.atol, mxstep=args.mxstep, n_ts=args.n_ts)
+    o = dict(hutch=args.hutchs, rtol=args.rtol, atol=args.atol, mxstep=args.mxstep, n_ts=args.n_ts, fixed=fixed_mode(args))
     u0, vol0 = ode.inverse_and_logdet(model, params, kk[:, 1], prev.position, **o)                 # :282
     with np.errstate(over="ignore", invalid="ignore"):
         w_prev = np.exp(prev.logdensity - ref.logprob(u0) - vol0)                                  # :283

@@ -118,7 +118,7 @@ def final_sampling(model, params, dist, args, key_gen, stats=None):
     u = ref.sample_model_rows(prng.split(key_gen, n))                                    # :453 (:389)
     key_hutch, key_choice = prng.split(key_gen)                                          # :454
     x, vols = ode.transform_and_logdet(model, params, key_hutch, u, args.hutchs, args.rtol, args.atol, args.mxstep,
-                                       n_ts=args.n_ts, stats=stats)                      # :455 (one shared probe key)
+                                       n_ts=args.n_ts, stats=stats, fixed=flow.fixed_mode(args))   # :455 (one shared probe key)
     lp = dist.logprob(x)                                                                 # :456
     logw = lp - ref.logprob(u) - vols                                                    # :457
     w = np.exp(logw - logw.max())                                                        # :458

@@ -190,6 +190,49 @@ def _compress_rounds(dt_seq, acc_seq, ratio_seq, dt_own, act_seq, n_att):
     return out
 
 
+def odeint_fixed(fun, y0, ts, method, nsteps, stats=None):
+    """Fixed-step explicit integrator over ``[ts[0], ts[-1]]``: ``nsteps`` equal steps of classical RK4 (``method="rk4"``) or
+    forward Euler (``"euler"``).  BUILD-SIDE MODE, NOT IN THE REFERENCE: the reference integrates with the adaptive Dopri5 above
+    (``exe_flow_matching.py:345-349``); BASELINE.json's north star names an "RK4/Euler ODE integrator", the mode in which every
+    chain takes the same number of steps.  Returns ``[len(ts), B, n]`` like ``odeint`` (intermediate output times must fall on
+    step boundaries)."""
+    B = y0.shape[0]
+    t0, t1 = float(ts[0]), float(ts[-1])
+    h = (t1 - t0) / nsteps
+    marks = {int(round((float(tt) - t0) / h)): j for j, tt in enumerate(ts)}
+    for j, tt in enumerate(ts):
+        assert abs(t0 + h * int(round((float(tt) - t0) / h)) - float(tt)) < 1e-12, "output times must be step boundaries"
+    outs = [None] * len(ts)
+    y = y0.copy()
+    outs[0] = y0
+    for n in range(nsteps):
+        t = np.full(B, t0 + n * h)
+        if method == "euler":
+            y = y + h * fun(y, t)
+        elif method == "rk4":
+            k1 = fun(y, t)
+            k2 = fun(y + 0.5 * h * k1, t + 0.5 * h)
+            k3 = fun(y + 0.5 * h * k2, t + 0.5 * h)
+            k4 = fun(y + h * k3, t + h)
+            y = y + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        else:
+            raise ValueError(method)
+        if n + 1 in marks:
+            outs[marks[n + 1]] = y
+    if stats is not None:
+        stats["n_attempted"] = np.full(B, nsteps, dtype=np.int64)
+        stats["n_evals"] = nsteps * (4 if method == "rk4" else 1)
+    return np.stack(outs)
+
+
+def _integrate(fun, y0, ts, rtol, atol, mxstep, stats, replay, fixed):
+    """``fixed = (method, nsteps)`` selects the fixed-step mode; None: the reference's adaptive Dopri5."""
+    if fixed:
+        assert replay is None
+        return odeint_fixed(fun, y0, ts, fixed[0], int(fixed[1]), stats)
+    return odeint(fun, y0, ts, rtol, atol, mxstep, stats, replay)
+
+
 def _augmented(model, params, z, hutch, sign, round32=False):
     """RHS of the augmented ODE.  sign=+1: ``:208-218`` (forward); sign=-1: ``:225-239`` (inverse).
 
@@ -217,24 +260,24 @@ def _augmented(model, params, z, hutch, sign, round32=False):
 
 
 def transform_and_logdet(model, params, keys, ref_sample, hutch, rtol, atol, mxstep, n_ts=2,
-                         stats=None, z=None, replay=None, round32=False):
+                         stats=None, z=None, replay=None, round32=False, fixed=None):
     """``exe_flow_matching.py:206-221``; ``keys`` [B, 2] (one Hutchinson key per chain) or one key."""
     B, d = ref_sample.shape
     if hutch and z is None:
         keys = np.asarray(keys)
         z = prng.normal_rows(keys, d) if keys.ndim == 2 else np.broadcast_to(prng.normal(keys, (d,)), (B, d))
     y0 = np.concatenate([ref_sample, np.zeros((B, 1))], axis=1)             # :220
-    ys = odeint(_augmented(model, params, z, hutch, +1, round32), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats, replay)
+    ys = _integrate(_augmented(model, params, z, hutch, +1, round32), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats, replay, fixed)
     return ys[-1][:, :d], ys[-1][:, d]                                      # :221
 
 
 def inverse_and_logdet(model, params, keys, target_sample, hutch, rtol, atol, mxstep, n_ts=2,
-                       stats=None, z=None, replay=None, round32=False):
+                       stats=None, z=None, replay=None, round32=False, fixed=None):
     """``exe_flow_matching.py:223-242``."""
     B, d = target_sample.shape
     if hutch and z is None:
         keys = np.asarray(keys)
         z = prng.normal_rows(keys, d) if keys.ndim == 2 else np.broadcast_to(prng.normal(keys, (d,)), (B, d))
     y0 = np.concatenate([target_sample, np.zeros((B, 1))], axis=1)          # :241
-    ys = odeint(_augmented(model, params, z, hutch, -1, round32), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats, replay)
+    ys = _integrate(_augmented(model, params, z, hutch, -1, round32), y0, np.linspace(0.0, 1.0, n_ts), rtol, atol, mxstep, stats, replay, fixed)
     return ys[-1][:, :d], ys[-1][:, d]                                      # :242

@@ -89,6 +89,56 @@ def test_odeint_fifth_order():
     assert errs[0] / errs[1] > 25 and errs[1] / errs[2] > 25
 
 
+def test_fixed_step_integrators_orders_closed_forms_and_scipy():
+    """oracle.ode.odeint_fixed (the build-side RK4 / Euler mode BASELINE.json's north star names; the reference itself integrates
+    with the adaptive Dopri5): closed-form linear and time-dependent flows, the classical orders 4 and 1, scipy's RK45 at a
+    tight tolerance, and agreement with the oracle's own Dopri5 on the CNF transform of a random network."""
+    import scipy.linalg as sla
+    from scipy.integrate import solve_ivp
+    rng = np.random.default_rng(3)
+    n, B = 4, 5
+    A = rng.standard_normal((n, n)) * 0.7
+    y0 = rng.standard_normal((B, n))
+    lin = lambda y, t: y @ A.T
+    exact = y0 @ sla.expm(A).T
+    e_rk4 = [np.abs(ode.odeint_fixed(lin, y0, np.array([0.0, 1.0]), "rk4", N)[-1] - exact).max() for N in (8, 16, 32)]
+    e_eul = [np.abs(ode.odeint_fixed(lin, y0, np.array([0.0, 1.0]), "euler", N)[-1] - exact).max() for N in (64, 128, 256)]
+    assert 13 < e_rk4[0] / e_rk4[1] < 19 and 13 < e_rk4[1] / e_rk4[2] < 19 and e_rk4[2] < 1e-6          # order 4
+    assert 1.8 < e_eul[0] / e_eul[1] < 2.2 and 1.8 < e_eul[1] / e_eul[2] < 2.2                            # order 1
+    # per-chain times and a time-dependent field; intermediate output times on step boundaries (n_ts = 5 of the 4-mode example)
+    ys = ode.odeint_fixed(lambda y, t: y * np.cos(t)[:, None], y0, np.linspace(0, 1, 5), "rk4", 64)
+    for j, tt in enumerate(np.linspace(0, 1, 5)):
+        np.testing.assert_allclose(ys[j], y0 * np.exp(np.sin(tt)), rtol=1e-8)
+    for bidx in range(B):
+        sol = solve_ivp(lambda t, y: A @ y, (0, 1), y0[bidx], method="RK45", rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(ode.odeint_fixed(lin, y0, np.array([0.0, 1.0]), "rk4", 64)[-1][bidx], sol.y[:, -1], rtol=1e-7, atol=1e-8)
+    st = {}
+    ode.odeint_fixed(lin, y0, np.array([0.0, 1.0]), "rk4", 10, st)
+    assert (st["n_attempted"] == 10).all() and st["n_evals"] == 40
+    # the CNF transform with its Hutchinson log-det: fixed RK4 converges to what the adaptive solver gives at a tight tolerance
+    from oracle import loop
+    args = loop.default_args(example="phi-four", dim=16, num_chain=6, hutchs=True, fourier_dim=8, hidden_x=[16, 16], hidden_t=[16, 16], hidden_xt=[16, 16])
+    dist = targets.PhiFour(16)
+    k, model, state, lr_fn, _, _ = loop.setup(dist, args)
+    prm = [dict(kernel=rng.standard_normal(p["kernel"].shape) / np.sqrt(p["kernel"].shape[0]), bias=rng.standard_normal(p["bias"].shape) * 0.05) for p in state.params]
+    prm[4]["kernel"] *= 1e-2; prm[4]["bias"] *= 1e-2                     # the gate of grad log pi (cubic in x): a tame field
+    keys = prng.split(prng.PRNGKey(4), 6)
+    u = rng.standard_normal((6, 16))
+    xa, la = ode.transform_and_logdet(model, prm, keys, u, True, 1e-10, 1e-10, 10000)
+    ex, el = {}, {}
+    for N in (16, 256):
+        xf, lf = ode.transform_and_logdet(model, prm, keys, u, True, 0, 0, 0, fixed=("rk4", N))
+        ex[N], el[N] = np.abs(xf - xa).max(), np.abs(lf - la).max()
+    # a strong field (points move by ~6, log-det ~6, thousands of adaptive steps at 1e-10) with ReLU kinks: the log-det integrand is
+    # only piecewise smooth, so its error falls like h rather than h^4 (measured: x 3.8e-3 -> 8e-5, log-det 4e-2 -> 2e-3)
+    assert ex[256] < 1e-3 and el[256] < 5e-3 and ex[256] < ex[16] / 5 and el[256] < el[16] / 5
+    xe1, le1 = ode.transform_and_logdet(model, prm, keys, u, True, 0, 0, 0, fixed=("euler", 128))
+    xe2, le2 = ode.transform_and_logdet(model, prm, keys, u, True, 0, 0, 0, fixed=("euler", 256))
+    assert 1.5 < np.abs(xe1 - xa).max() / np.abs(xe2 - xa).max() < 2.5                                   # order 1
+    ub, lb = ode.inverse_and_logdet(model, prm, keys, xf, True, 0, 0, 0, fixed=("rk4", 256))
+    np.testing.assert_allclose(ub, u, atol=1e-3)                          # inverse(transform(u)) = u
+
+
 def test_mala_as_written_matches_literal_transcription():
     d, B, eps = 8, 6, 0.05
     dist = targets.PhiFour(d)
