@@ -76,7 +76,18 @@ typedef struct mfm_config {
      layer): MFM_FAMILY_TILE then fails with MFM_EUNSUPPORTED. */
   int32_t depth_t, depth_x, depth_xt;
   int32_t hidden_t3, hidden_x3, hidden_xt3;
+  /* BUILD-SIDE MODE, not in the reference (whose integrator is the adaptive Dopri5 of jax.experimental.ode.odeint,
+     exe_flow_matching.py:345-349 -- ode_method = MFM_ODE_DOPRI5, the default): the CNF solves on ode_steps EQUAL steps of classical
+     RK4 (MFM_ODE_RK4) or forward Euler (MFM_ODE_EULER), the "RK4/Euler ODE integrator" BASELINE.json's north star names -- no step-size
+     controller, every chain takes the same steps.  Built for the shape-specialised solver (default widths, PhiFour, relu, hutch = 1,
+     random-walk flow step and the transforms); other configurations fail with MFM_EUNSUPPORTED at the first solve.  rtol / atol /
+     mxstep are ignored in this mode; n_ts > 2 needs ode_steps % (n_ts - 1) == 0. */
+  int32_t ode_method, ode_steps;
 } mfm_config;
+
+#define MFM_ODE_DOPRI5 0
+#define MFM_ODE_RK4 1
+#define MFM_ODE_EULER 2
 
 const char* mfm_last_error(void);
 int mfm_version(void);

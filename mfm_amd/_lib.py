@@ -34,10 +34,12 @@ class Config(C.Structure):
         ("kernel_family", C.c_int32), ("activation", C.c_int32), ("ref_std", C.c_double), ("n_chain_valid", C.c_int32),
         ("depth_t", C.c_int32), ("depth_x", C.c_int32), ("depth_xt", C.c_int32),
         ("hidden_t3", C.c_int32), ("hidden_x3", C.c_int32), ("hidden_xt3", C.c_int32),
+        ("ode_method", C.c_int32), ("ode_steps", C.c_int32),
     ]
 
 
 MAX_DEPTH = 3          # include/mfm.h: MFM_MAX_DEPTH
+ODE_METHODS = {"dopri5": 0, "rk4": 1, "euler": 2}      # include/mfm.h: MFM_ODE_*
 
 
 _P = C.c_void_p

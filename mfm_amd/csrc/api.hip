@@ -286,6 +286,8 @@ static int create_impl(const mfm_config& c, mfm_ctx* x) {
     if (!fits) use_wide = true;
   }
   if (c.kernel_family < 0 || c.kernel_family > MFM_FAMILY_WIDE) return fail(MFM_EINVAL, "unknown kernel_family %d", c.kernel_family);
+  if (c.ode_method < MFM_ODE_DOPRI5 || c.ode_method > MFM_ODE_EULER) return fail(MFM_EINVAL, "unknown ode_method %d", c.ode_method);
+  if (c.ode_method != MFM_ODE_DOPRI5 && (c.ode_steps < 1 || (c.n_ts > 2 && c.ode_steps % (c.n_ts - 1)))) return fail(MFM_EINVAL, "ode_steps=%d: a positive number of steps (a multiple of n_ts - 1) is needed with a fixed-step ode_method", c.ode_steps);
   const int nbb = c.n_chain_local / 16;
   x->split = nbb < 8 ? nbb : 8;
   if (const char* e = getenv("MFM_WGRAD_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= nbb) x->split = v; }      // development: A/B
@@ -1058,6 +1060,7 @@ extern "C" int mfm_ode_transform(mfm_ctx* x, int direction, int per_chain, const
   a.in = d_in; a.out = d_out; a.ldj = d_ldj; a.n = n;
   a.nsteps = d_nsteps = att_buffer(x, d_nsteps, n);
   a.rp = x->replay; a.rp.n = n; memset(&x->replay, 0, sizeof x->replay);      // one-shot
+  if ((x->wide || x->wide_ex) && a.fixed_steps > 0) return fail(MFM_EUNSUPPORTED, "fixed-step mode (ode_method / ode_steps): built for the shape-specialised solver");
   if (wide::Ctx* ws = x->wide ? x->wide : x->wide_ex) {
     launch_probe(per_chain ? 0 : 1, d_keys, a.key, 0, 0, 0, n, x->net.d, const_cast<float*>(a.z1), x->stream);
     wide::WReplay wr{a.rp.dt, a.rp.acc, a.rp.ratio, a.rp.dt_own, a.rp.cap, a.rp.n, 0, 0, nullptr};
@@ -1068,6 +1071,7 @@ extern "C" int mfm_ode_transform(mfm_ctx* x, int direction, int per_chain, const
     return MFM_OK;
   }
   int rc = launch_ode_transform(a, x->stream);
+  if (rc == -4) return fail(MFM_EUNSUPPORTED, "fixed-step mode (ode_method / ode_steps): built for the shape-specialised solver -- default widths, PhiFour, relu, hutch");
   if (rc) return fail(rc, "ODE kernel cannot be launched for this configuration");
   LAUNCHCHK();
   tally_solves(x, d_nsteps, n, 1);
@@ -1093,7 +1097,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
   if (x->noise) {
     NoiseWs* w = x->noise;
     w->n_valid = 0;
-    const bool fast_path = !x->wide && fast::shape_ok(x->net, x->cfg.hutch) && !g_sw.generic_ode;
+    const bool fast_path = !x->wide && fast::shape_ok(x->net, x->cfg.hutch) && !g_sw.generic_ode && a.fixed_steps == 0;
     if (w->n_armed > 0 && fast_path) {
       const int B = x->cfg.n_chain_local;
       nz.gn = w->d_keys; nz.st = w->d_keys + 2 * (size_t)w->n_armed; nz.n_slots = w->n_armed;
@@ -1109,6 +1113,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
   int rc = 0;
   {
     ProfScope ps_(x, PROF_FLOW);
+    if ((x->wide || x->wide_ex) && a.fixed_steps > 0) return fail(MFM_EUNSUPPORTED, "fixed-step mode (ode_method / ode_steps): built for the shape-specialised solver");
     if (wide::Ctx* ws = x->wide ? x->wide : x->wide_ex) {
       launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 0, a.n, x->net.d, const_cast<float*>(a.zgen), x->stream);     // key_gen
       launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 3, a.n, x->net.d, const_cast<float*>(a.z1), x->stream);       // key_hutch2
@@ -1122,6 +1127,7 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
       if (rcw) return fail(rcw, "wide flow step failed: %s", hipGetErrorString(hipGetLastError()));
     } else {
       rc = launch_flow_step(a, f, nz, x->stream);
+      if (rc == -4) return fail(MFM_EUNSUPPORTED, "fixed-step mode (ode_method / ode_steps): built for the shape-specialised solver -- default widths, PhiFour, relu, hutch, random-walk flow step");
       if (rc) return fail(rc, "flow step cannot be launched for this configuration");
     }
     LAUNCHCHK();
@@ -1206,7 +1212,7 @@ extern "C" int mfm_max_mean_disc(mfm_ctx* x, const float* d_x, const float* d_y,
 extern "C" int mfm_noise_prefetch(mfm_ctx* x, int n_slots, const uint32_t* h_keys_gn, const uint32_t* h_keys_step) { use_ctx(x);
   NEED_TARGET();
   if (!h_keys_gn || !h_keys_step || n_slots <= 0) return fail(MFM_EINVAL, "bad arguments");
-  if (x->wide || !x->cfg.cond_flow || !fast::shape_ok(x->net, x->cfg.hutch))
+  if (x->wide || !x->cfg.cond_flow || !fast::shape_ok(x->net, x->cfg.hutch) || (x->cfg.ode_method != MFM_ODE_DOPRI5 && x->cfg.ode_steps > 0))
     return fail(MFM_EUNSUPPORTED, "the noise prefetch rides in the tail of the shape-specialised flow-step kernel (headline network shape, PhiFour, --hutch)");
   if (!x->noise) x->noise = new NoiseWs();
   NoiseWs* w = x->noise;

@@ -330,6 +330,19 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   }
 
   FM_STAMP(2);
+  // clip(grad log pi(cond)) of this lane's output elements (:88-89), PhiFour: a function of the batch alone, formed HERE -- in the
+  // same scheduling region as the first layer's MFMAs, under which its LDS reads and ~20 vector instructions per element issue --
+  // instead of in the output layer's epilogue, where both waves of a SIMD ran it at once with the matrix pipe idle (round 5,
+  // tools/fm_stamps.py: out layer + loss 11.2 k cycles for a 4.1 k matrix floor).  Same function, same values.
+  float gcp[TPW][4];
+  const bool gc_early = n.T.kind == MFM_TARGET_PHI4;
+#pragma unroll
+  for (int q = 0; q < TPW; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = (wave + MLP_WAVES_FM * q) * 16 + c;
+      gcp[q][i] = gc_early && col < d ? target_gclip(n, bX, L.ldx, gcs, bGC, L.ldg, 4 * g + i, col) : 0.f;
+    }
   // ---------------- forward ----------------------------------------------------------------------------------
   auto relu_store = [&](const LayerDesc& ld, float* out, int ldo, int coff, int a_tile) {
     return [&, out, ldo, coff, a_tile](int q, int nt, int m, f32x4 acc, float bias) {
@@ -398,12 +411,12 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                      for (int i = 0; i < 4; ++i) {
                        const int row = 4 * g + i;
                        if (col < d) {
-                         const float gc = target_gclip(n, bX, L.ldx, gcs, bGC, L.ldg, row, col);
-                         const float v = acc[i] + bias + bG[row * L.ldg + col] * gc;
-                         // tgt is indexed by the static slot q: select without dynamic register indexing
-                         float tg = 0.f;
+                         // tgt / gcp are indexed by the static slot q: select without dynamic register indexing
+                         float tg = 0.f, gce = 0.f;
 #pragma unroll
-                         for (int qq = 0; qq < TPW; ++qq) tg = (qq == q) ? tgt[qq][i] : tg;
+                         for (int qq = 0; qq < TPW; ++qq) { tg = (qq == q) ? tgt[qq][i] : tg; gce = (qq == q) ? gcp[qq][i] : gce; }
+                         const float gc = gc_early ? gce : target_gclip(n, bX, L.ldx, gcs, bGC, L.ldg, row, col);
+                         const float v = acc[i] + bias + bG[row * L.ldg + col] * gc;
                          const float r = b0 + row < a.n_valid ? v - tg : 0.f;
                          loss_loc += r * r;
                          dv[i] = 2.f * r;
@@ -416,18 +429,21 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                        store_chk(a.dzs, a.ws.z_gate + nt, dg);
                      }
                    }, TRAIN ? n.WpT + n.L[7].w_off : nullptr, n.L[7].Np / 16);
-  {
-    double lw = wave_sum((double)loss_loc);
+  // the tile's loss: per-wave sums now (forward only), or after the backward pass (training: the shuffles, the barrier's single-lane
+  // tail and the store leave the path between the output layer and the first data-gradient GEMM)
+  auto loss_total = [&]() {
+    const double lw = wave_sum((double)loss_loc);
     if (lane == 0) red[wave] = lw;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int w = 0; w < MLP_WAVES_FM; ++w) tot += red[w];
-    a.loss_part[blockIdx.x] = tot;
-  }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < MLP_WAVES_FM; ++w) tot += red[w];
+      a.loss_part[blockIdx.x] = tot;
+    }
+  };
+  if (!TRAIN) { loss_total(); FM_STAMP(4); return; }
+  __syncthreads();      // dv / dgate of every wave are in LDS
   FM_STAMP(4);
-  if (!TRAIN) return;
 
   // ---------------- backward (data gradients only; weight gradients: wgrad_kernel) -----------------------------
   // tangent of the loss through a hidden activation: from the stored OUTPUT (relu / tanh / elu), or times the derivative the
@@ -513,6 +529,7 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                      store_chk(a.dzs, a.ws.z_t1 + nt, z);
                    }, nullptr, 0);
   if (a.sus_set && __ballot(!(sq_acc <= FM_SAFE * FM_SAFE)) != 0ull && lane == 0) atomicOr(a.sus_set, 1);
+  loss_total();
   FM_STAMP(5);
 }
 

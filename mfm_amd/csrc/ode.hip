@@ -101,6 +101,7 @@ struct OdeArgs {
   const float* zgen;        // latent proposal noise (flow step)
   f32x4* fast_scr;          // time-branch scratch of the shape-specialised kernels (ode_fast.hip)
   Replay rp;                // rp.dt == nullptr: off (production)
+  int fixed_method, fixed_steps;      // fixed_steps > 0: the fixed-step mode (ode_fixed.hip; mfm_config.ode_method / ode_steps)
 };
 
 struct FlowArgs {
@@ -116,6 +117,7 @@ static OdeArgs ode_args(const NetDev& n, const mfm_config& c, const OdeWs& w) {
   a.z1 = w.noise; a.z2 = w.noise + w.rows * n.d; a.zgen = w.noise + 2 * w.rows * n.d; a.fast_scr = w.fast_scr; t_pad = &w.pad;
   a.net = n; a.hutch = c.hutch; a.rtol = (float)c.rtol; a.atol = (float)c.atol;
   a.max_attempts = c.mxstep * (c.n_ts > 1 ? c.n_ts - 1 : 1);
+  a.fixed_method = c.ode_method; a.fixed_steps = c.ode_method != MFM_ODE_DOPRI5 ? c.ode_steps : 0;
   return a;
 }
 
@@ -1254,6 +1256,7 @@ __global__ __launch_bounds__(NW * 64) void flow_step_kernel(OdeArgs a, FlowArgs 
 }
 
 #include "ode_fast.hip"
+#include "ode_fixed.hip"
 #include "ode_d2.hip"
 
 // ---- launchers -----------------------------------------------------------------------------------------------
@@ -1286,6 +1289,10 @@ int launch_ode_transform(const OdeArgs& a, hipStream_t stream) {
   size_t sm; int tpw;
   if (ode_check(a.net, sm, tpw)) return -3;
   if (a.hutch) launch_probe(a.per_chain_keys ? 0 : 1, a.keys, a.key, 0, 0, 0, a.n, a.net.d, const_cast<float*>(a.z1), stream);
+  if (a.fixed_steps > 0) {
+    if (!fast::shape_ok(a.net, a.hutch) || a.rp.dt) return -4;
+    return fast::launch_transform_fixed(a, a.fixed_method, a.fixed_steps, a.fast_scr, stream);
+  }
   if (d2::use_for(a.net, a.hutch, a.n)) return d2::launch_transform(a, stream);
   if (fast::shape_ok(a.net, a.hutch) && !g_sw.generic_ode)
     return fast::tile_width(a.net) == 256 ? fast::launch_transform_t<256>(a, a.fast_scr, stream) : fast::launch_transform_t<128>(a, a.fast_scr, stream);
@@ -1305,6 +1312,10 @@ int launch_flow_step(const OdeArgs& a, const FlowArgs& f, const NoiseArgs& nz, h
   if (a.hutch) {
     launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 3, a.n, a.net.d, const_cast<float*>(a.z1), stream);     // key_hutch2
     launch_probe(2, nullptr, f.key, f.n_total, f.chain_offset, 2, a.n, a.net.d, const_cast<float*>(a.z2), stream);     // key_hutch1
+  }
+  if (a.fixed_steps > 0) {
+    if (!fast::shape_ok(a.net, a.hutch) || a.rp.dt || (f.mode & 0xFF) != MFM_FLOW_RWMH) return -4;
+    return fast::launch_flow_fixed(a, f, a.fixed_method, a.fixed_steps, a.fast_scr, stream);
   }
   if (d2::use_for(a.net, a.hutch, a.n)) return d2::launch_flow(a, f, stream);
   if (fast::shape_ok(a.net, a.hutch) && !g_sw.generic_ode)

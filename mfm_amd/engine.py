@@ -143,7 +143,10 @@ class Engine:
             update_clip=float(args.gradient_clip), learning_iter=int(args.learning_iter),
             warmup_steps=int(args.warmup_steps), max_eval_samples=int(max_eval_samples),
             activation=_lib.ACTIVATIONS[getattr(args, "non_linearity", "relu")],
-            ref_std=float(np.sqrt(ref_vars[getattr(args, "ref_dist", "stdgauss")])))
+            ref_std=float(np.sqrt(ref_vars[getattr(args, "ref_dist", "stdgauss")])),
+            # build-side mode (not in the reference): the CNF solves on N equal RK4 / Euler steps (include/mfm.h: ode_method)
+            ode_method=_lib.ODE_METHODS[getattr(args, "ode_method", "dopri5")] if int(getattr(args, "ode_steps", 0) or 0) > 0 else 0,
+            ode_steps=int(getattr(args, "ode_steps", 0) or 0))
         kind, blk = dist.target_block()
         self.ctx.set_target(kind, blk)
         self.dist = dist

@@ -3,7 +3,8 @@ overrides, ``multi_modal.py:21-101,147-220``), running the MFM loop on MI355X.
 
 Additions (defaults leave the reference behaviour untouched): ``--force_dim`` / ``--force_num_chain`` override the
 values ``main`` hard-codes per example (needed for BASELINE.json's phi-four d=256 / 4096-chain configuration;
-``multi_modal.py:52,55`` fix 64 / 1024), ``--log_every`` sets how often metrics are copied to the host.
+``multi_modal.py:52,55`` fix 64 / 1024), ``--log_every`` sets how often metrics are copied to the host,
+``--ode_method rk4|euler --ode_steps N`` integrates the flow on N equal steps instead of the reference's adaptive Dopri5.
 ``--do_smc`` runs the tempered-SMC baseline on the same MALA kernel (``exe_others.py:79-111``); the other baselines
 (``--do_flowmc`` ... ``--do_fab``) wrap third-party samplers outside the hot-path scope and raise.
 
@@ -146,6 +147,10 @@ def build_parser():
     parser.add_argument('--force_dim', type=int, default=None)
     parser.add_argument('--force_num_chain', type=int, default=None)
     parser.add_argument('--log_every', type=int, default=1)
+    # the fixed-step mode of the CNF solver (BASELINE.json's "RK4/Euler ODE integrator"; the reference integrates with the adaptive
+    # Dopri5 of jax.experimental.ode.odeint, exe_flow_matching.py:345-349, which stays the default): --ode_method rk4 --ode_steps 64
+    parser.add_argument('--ode_method', type=str, default='dopri5', choices=['dopri5', 'rk4', 'euler'])
+    parser.add_argument('--ode_steps', type=int, default=0)
     return parser
 
 

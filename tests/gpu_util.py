@@ -54,6 +54,8 @@ def make_ctx(dist, args, n_local=None, n_total=None, offset=0, fourier=None, par
         weight_decay=args.weight_decay, update_clip=args.gradient_clip, learning_iter=args.learning_iter,
         warmup_steps=args.warmup_steps, max_eval_samples=max_eval, activation=_lib.ACTIVATIONS[args.non_linearity],
         ref_std=float(np.sqrt(targets.REF_VARS[getattr(args, "ref_dist", "stdgauss")])),
+        ode_method=_lib.ODE_METHODS[getattr(args, "ode_method", "dopri5")] if int(getattr(args, "ode_steps", 0) or 0) > 0 else 0,
+        ode_steps=int(getattr(args, "ode_steps", 0) or 0),
         **({} if family is None else {"kernel_family": family}))
     kind, blk = target_block(dist)
     ctx.set_target(kind, blk)
