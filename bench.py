@@ -66,20 +66,60 @@ def flops_per_chain(d=256, h=128, F=128, lgcp=False):
     return dict(fwd=2 * P_w + kinv, fm_fwd_bwd=2 * P_w + 2 * dgrad + kinv, wgrad=2 * P_w, field_eval=2 * P_w + 2 * P_x + kinv)
 
 
+def fixed_step_report(dist, args, fourier, params_flat, pos, logp, grad, field_eval_flops, key):
+    """Flow-MH step time in the fixed-step mode (RK4 x 64, Euler x 256: 256 field evaluations per solve each) on a context of its own
+    that shares nothing with the timed one but copies of its parameters and chain states."""
+    import copy
+    import torch
+    from mfm_amd._lib import FLOW_RWMH
+    from mfm_amd.engine import Engine
+    res = {}
+    for method, steps in (("rk4", 64), ("euler", 256)):
+        a2 = copy.copy(args); a2.ode_method, a2.ode_steps = method, steps
+        d2_ = copy.copy(dist)
+        eng2 = Engine(d2_, a2, fourier)
+        eng2.ctx.set_params(params_flat)
+        B = pos.shape[0]
+        acc = torch.empty(B, device=pos.device); ns = torch.empty(B, dtype=torch.int32, device=pos.device)
+        ms = []
+        for rep in range(4):
+            p, l, g = pos.clone(), logp.clone(), grad.clone()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            eng2.ctx.sync(); torch.cuda.synchronize()
+            eng2.ctx.profile(True, classes=["flow_step"])
+            eng2.ctx.flow_step(FLOW_RWMH, key, 1.0, p, l, g, acc, None, None, ns)
+            pr = eng2.ctx.profile_read(); eng2.ctx.profile(False)
+            if rep:
+                ms.append(pr["flow_step"]["ms"])
+        t = sum(ms) / len(ms)
+        evals = 2 * steps * (4 if method == "rk4" else 1)
+        # executed matrix work per chain: the x branch of every evaluation (320 MFMAs per wave and 16 chains: 327,680 flop per chain) and the
+        # time branch once per slot of a five-slot batch (196,608 flop per chain and stage time: one batch per two RK4 / five Euler steps)
+        batches = 2 * -(-steps // (2 if method == "rk4" else 5))
+        executed = evals * 327680.0 + batches * 5 * 196608.0
+        res[f"{method}_x{steps}"] = {"flow_step_ms": round(t, 4), "field_evaluations_per_chain": evals,
+                                    "tflops_on_algorithmic_flops": round(B * evals * field_eval_flops / (t * 1e-3) / 1e12, 1),
+                                    "executed_matrix_flops_frac_of_f32_mfma_peak": round(B * executed / (t * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        eng2.close()
+    res["note"] = ("build-side mode (BASELINE north star's RK4/Euler integrator), not the reference's adaptive Dopri5 (tests/test_gpu_fixed.py states its distance "
+                   "to it).  tflops_on_algorithmic_flops uses the roofline's convention, (2 P_w + 2 P_x) per field evaluation, and may exceed the matrix peak: "
+                   "the time branch is evaluated once per distinct stage time of a batch, the tangent skips the output layer")
+    return res
+
+
 def cpu_baseline(params_flat, fourier, steps_mala, chains, seed=1):
     """Oracle (float64 numpy, multi-threaded BLAS) on a bounded sample: `chains` chains, `steps_mala` MALA+train
     iterations and ONE flow-MH step + train step, with the network the GPU run has after its warm-up.  Composed into
     one 101-iteration cycle: 100 * t(MALA+train) + t(flow+train)."""
     import numpy as np
     from oracle import flow, fm, loop, mala, optim, prng, targets
-    from oracle.vfield import VectorFieldNet
-    from tests import gpu_util as gu
+    from oracle.vfield import VectorFieldNet, unflat_params
     args = loop.default_args(example="phi-four", dim=256, num_chain=chains, hutchs=True, step_size=1e-4, seed=seed,
                              mcmc_per_flow_steps=100.0, learning_iter=10000)
     dist = targets.PhiFour(256)
     dist.initialize_model(prng.PRNGKey(seed), chains)
     model = VectorFieldNet(fourier, dist, args.hidden_x, args.hidden_t, args.hidden_xt, "relu", 1.0)
-    params = gu.unflat_params(model, params_flat)
+    params = unflat_params(model, params_flat)
     state = optim.TrainState(params, optim.learning_rate_fn(10000, 0, 1e-3))
     vg = targets.Tempered(dist, 1.0).value_and_grad
     st = mala.init(dist.init_params, vg)
@@ -112,8 +152,7 @@ def cpu_baseline_d2(workload, params_flat, fourier, chains, n_eval, K, seed=1):
     chains (x chains / 128), composed into one (K + 1)-iteration cycle."""
     import numpy as np
     from oracle import flow, fm, loop, mala, optim, prng, targets
-    from oracle.vfield import VectorFieldNet
-    from tests import gpu_util as gu
+    from oracle.vfield import VectorFieldNet, unflat_params
     if workload == "gaussian-mixture":
         g = np.load(os.path.join(ROOT, "tests", "golden", "gmm16_params.npz"))
         dist = targets.GaussianMixture(g["modes"], g["covs"], g["weights"])
@@ -122,7 +161,7 @@ def cpu_baseline_d2(workload, params_flat, fourier, chains, n_eval, K, seed=1):
     args = loop.default_args(example=workload, dim=2, num_chain=chains, hutchs=False, step_size=0.2, seed=seed, mcmc_per_flow_steps=float(K), learning_iter=10000)
     dist.initialize_model(prng.PRNGKey(seed), chains)
     model = VectorFieldNet(fourier, dist, args.hidden_x, args.hidden_t, args.hidden_xt, "relu", None)
-    params = gu.unflat_params(model, params_flat)
+    params = unflat_params(model, params_flat)
     state = optim.TrainState(params, optim.learning_rate_fn(10000, 0, 1e-3))
     vg = targets.Tempered(dist, 1.0).value_and_grad
     st = mala.init(dist.init_params, vg)
@@ -158,8 +197,7 @@ def cpu_baseline_pines(params_flat, fourier, dim, hidden, chains, K, seed=1):
     after its warm-up; composed into one (K + 1)-iteration cycle."""
     import numpy as np
     from oracle import flow, fm, loop, mala, optim, prng, targets
-    from oracle.vfield import VectorFieldNet
-    from tests import gpu_util as gu
+    from oracle.vfield import VectorFieldNet, unflat_params
     n = int(round(dim ** 0.5))
     counts = np.load(os.path.join(ROOT, "mfm_amd", "data", "pines_counts.npz"))[f"counts_{n}"]
     nm, nf = min(256, chains), min(32, chains)
@@ -168,7 +206,7 @@ def cpu_baseline_pines(params_flat, fourier, dim, hidden, chains, K, seed=1):
     dist = targets.LogGaussianCoxPines(dim, counts)
     dist.initialize_model(prng.PRNGKey(seed), nm)
     model = VectorFieldNet(fourier, dist, args.hidden_x, args.hidden_t, args.hidden_xt, "relu", 1.0)
-    params = gu.unflat_params(model, params_flat)
+    params = unflat_params(model, params_flat)
     state = optim.TrainState(params, optim.learning_rate_fn(10000, 0, 1e-3))
     vg = targets.Tempered(dist, 1.0).value_and_grad
     st = mala.init(dist.init_params, vg)
@@ -261,6 +299,7 @@ def main():
                     help="phi-four: BASELINE configs[2] (the metric's configuration, default); pines: configs[4] per-GPU shape; "
                          "gaussian-mixture / 4-mode: the d = 2 mixtures of configs[1] / configs[0] (exact trace + eval_step every iteration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fixed-step", action="store_true", help="skip the fixed-step (RK4 / Euler) flow-step report that follows the timed region")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -508,6 +547,13 @@ def main():
             "counters": ctx.counters(),
             "comm": comm,
         }
+        if world == 1 and a.workload == "phi-four" and not a.no_fixed_step:
+            # NS1, reported BESIDE the benchmarked (adaptive Dopri5) flow step, never instead of it: the same flow-MH step on the same
+            # chains and network with both solves on N equal steps (mfm_config.ode_method; mfm_amd/csrc/ode_fixed.hip)
+            try:
+                out["fixed_step_flow_step"] = fixed_step_report(dist, args, fourier, ctx.get_params(), pos, logp, grad, fl["field_eval"], keys[0, 0])
+            except Exception as e:
+                out["fixed_step_flow_step"] = {"failed": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 from threadpoolctl import threadpool_limits

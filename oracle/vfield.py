@@ -216,3 +216,18 @@ class VectorFieldNet:
             dW[li] = acts_in[li].T @ dz; db[li] = dz.sum(0)
             ds = dz @ W[li].T
         return [{"kernel": dW[i].astype(np.float32), "bias": db[i].astype(np.float32)} for i in range(n)]
+
+
+def flat_params(params):
+    """The canonical flat float32 vector (flax creation order; kernel [in][out] then bias, per layer) of a parameter list."""
+    return np.concatenate([np.concatenate([p["kernel"].reshape(-1), p["bias"].reshape(-1)]) for p in params]).astype(np.float32)
+
+
+def unflat_params(model, flat):
+    """Inverse of ``flat_params`` for ``model``'s layer shapes."""
+    out, o = [], 0
+    for (fi, fo) in model.layer_shapes():
+        W = flat[o:o + fi * fo].reshape(fi, fo); o += fi * fo
+        b = flat[o:o + fo]; o += fo
+        out.append({"kernel": W.astype(np.float32), "bias": b.astype(np.float32)})
+    return out

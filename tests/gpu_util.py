@@ -5,17 +5,7 @@ from oracle import loop, prng, targets
 from oracle.vfield import VectorFieldNet
 
 
-def flat_params(params):
-    return np.concatenate([np.concatenate([p["kernel"].reshape(-1), p["bias"].reshape(-1)]) for p in params]).astype(np.float32)
-
-
-def unflat_params(model, flat):
-    out, o = [], 0
-    for (fi, fo) in model.layer_shapes():
-        W = flat[o:o + fi * fo].reshape(fi, fo); o += fi * fo
-        b = flat[o:o + fo]; o += fo
-        out.append({"kernel": W.astype(np.float32), "bias": b.astype(np.float32)})
-    return out
+from oracle.vfield import flat_params, unflat_params      # noqa: E402,F401  (re-exported: the tests' historical home of the two)
 
 
 def rand_params(model, seed=0, scale=1.0, out_scale=0.3):
