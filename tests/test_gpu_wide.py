@@ -368,9 +368,13 @@ def test_wide_exact_trace_at_the_pines_width_on_prescribed_steps():
     x4 = dist.init_params[:Bo].astype(np.float32).astype(np.float64)
     k4 = prng.split(prng.PRNGKey(23), B)[:Bo]
     o = (False, args.rtol, args.atol, args.mxstep)
-    st = {}
-    ode.transform_and_logdet(model, params, k4, x4, *o, stats=st)
-    dt, acc = _replay_arrays([st])
+    def natural():                                  # the oracle's own controller (cached: tests/gpu_util.py cached_oracle)
+        st_ = {}
+        ode.transform_and_logdet(model, params, k4, x4, *o, stats=st_)
+        dt_n, ac_n = _replay_arrays([st_])
+        return dict(dt=dt_n, acc=ac_n, n_attempted=st_["n_attempted"])
+    seq = gu.cached_oracle("natseq_wide_exact_pines_width", natural, x4, k4, gu.flat_params(params))
+    dt, acc, st = seq["dt"], seq["acc"], dict(n_attempted=seq["n_attempted"])
     y_o, l_o = ode.transform_and_logdet(model, params, k4, x4, *o, stats={}, replay=dict(dt=dt[0].astype(np.float64), acc=acc[0]))
     rep = lambda a: np.concatenate([a] * (B // Bo), axis=0)
     ratio = torch.zeros(B, dt.shape[2], device="cuda"); own = torch.zeros(B, dt.shape[2], device="cuda")
@@ -437,9 +441,13 @@ def test_wide_flow_step_at_the_reference_pines_default_on_prescribed_steps():
     st0 = mala.MALAState(x32[:Bo].astype(np.float64), logp.cpu().numpy()[:Bo], grad.cpu().numpy()[:Bo].astype(np.float64))
     key = prng.PRNGKey(47)
     keys = prng.split(key, B)[:Bo]                                                       # :303: chain b uses split(key, B)[b]
-    nat = {}
-    flow.rwmh_step(keys, st0, vg, model, params, args, nat)
-    dt_s, ac_s = _replay_arrays([nat["inv"], nat["fwd"]])
+    def natural():                                  # the oracle's own controller (cached: tests/gpu_util.py cached_oracle)
+        nat = {}
+        flow.rwmh_step(keys, st0, vg, model, params, args, nat)
+        dt_n, ac_n = _replay_arrays([nat["inv"], nat["fwd"]])
+        return dict(dt=dt_n, acc=ac_n)
+    seq = gu.cached_oracle("natseq_wide_flow_pines_default", natural, x32[:Bo], keys, gu.flat_params(params))
+    dt_s, ac_s = seq["dt"], seq["acc"]
     rp = dict(inv=dict(dt=dt_s[0].astype(np.float64), acc=ac_s[0]), fwd=dict(dt=dt_s[1].astype(np.float64), acc=ac_s[1]))
     so = {}
     new_o, info_o = flow.rwmh_step(keys, st0, vg, model, params, args, so, replay=rp)
