@@ -257,7 +257,7 @@ def pmc_traffic(kernel_class, workload="phi-four"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc passes of this
     same command, tools/prof_round.sh): 2 * FETCH_SIZE + WRITE_SIZE, both reported in KB; the factor 2 is the gfx950
     correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section).  None when no summary is present."""
-    files = {"phi-four": ("profiles/r04_pmc_summary.json", "profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"),    # newest committed summary first
+    files = {"phi-four": ("profiles/r05_pmc_summary.json", "profiles/r04_pmc_summary.json", "profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"),    # newest committed summary first
              "gaussian-mixture": ("profiles/r04_gmm_pmc_summary.json", "profiles/r03_gmm_pmc_summary.json", "profiles/r02_gmm_pmc_summary.json"),
              "4-mode": ("profiles/r04_4mode_pmc_summary.json", "profiles/r03_4mode_pmc_summary.json", "profiles/r02_4mode_pmc_summary.json"),
              "pines": ("profiles/r03_pines_pmc_summary.json", "profiles/r02_pines_pmc_summary.json")}.get(workload, ())

@@ -1132,7 +1132,8 @@ extern "C" int mfm_flow_step(mfm_ctx* x, int mode, uint32_t k0, uint32_t k1, dou
     }
     LAUNCHCHK();
   }
-  tally_solves(x, d_nsteps, a.n, 2);
+  // (rows >= n_chain_valid of a padded shard are integrated like any other but are no chains: not counted)
+  tally_solves(x, d_nsteps, x->cfg.n_chain_valid > 0 && x->cfg.n_chain_valid < a.n ? x->cfg.n_chain_valid : a.n, 2);
   return MFM_OK;
 }
 

@@ -219,12 +219,26 @@ class Engine:
         if self.world == 1 and not self._split_calls:
             self.ctx.train_iter(count, K, flow_mode, key_gen, key_train, beta, step_size, pos, logp, grad, loss, self.grads,
                                 acc=acc, nsteps=nsteps)
+            self.reseed_padding(pos, logp, grad)
             return loss
         if count % (int(K) + 1) == 0:
             self.ctx.flow_step(flow_mode, key_gen, beta, pos, logp, grad, acc, None, None, nsteps)
         else:
             self.ctx.mala_step(key_gen, beta, step_size, pos, logp, grad, acc)
-        return self.train_step(key_train, pos, loss_out)
+        out = self.train_step(key_train, pos, loss_out)
+        self.reseed_padding(pos, logp, grad)
+        return out
+
+    def reseed_padding(self, pos, logp, grad):
+        """Padding rows of a shard whose chain count is not a multiple of 16 restart every iteration from the LAST CHAIN's state.  They
+        are integrated with draws of their own (global ids past the chains'), so left alone they would wander like chains nobody looks at --
+        and a padding row that ever went non-finite would poison the weight-gradient GEMM (0 x NaN) and make apply_if_finite reject
+        every step.  Restarted from a chain, a padding row is never more than one step away from a state the run itself depends on."""
+        if self.n_valid < self.n_local:
+            v = self.n_valid
+            for t in (pos, logp, grad):
+                if t is not None:
+                    t[v:] = t[v - 1]
 
     def flush(self):
         """Apply a deferred optimizer step now (before reading parameters / optimizer state from outside the ctx)."""

@@ -386,6 +386,7 @@ def run(dist, args, target_gn=None, log_every=1, return_extras=False):
         else:
             train_states, infos = train_data_generator(key_train_gn, train_states, count, state.params, beta)    # :438
             eng.train_step(key_train_step, train_states.position, loss_out=row[0:1])        # :439 (:362-368)
+            eng.reseed_padding(train_states.position, train_states.logdensity, train_states.logdensity_grad)
         lrs.append(learning_rate_fn(count - 1))                                             # :367 (pre-increment step)
         if not use_real_samples and count % iter_per_temp == 0 and beta < 1.0:              # :440-441, :417
             beta = eng.ctx.beta_update(beta, eng.all_logliks(train_states.position), args.alpha)              # :413

@@ -158,7 +158,7 @@ def test_end_to_end_fixtures_are_complete_and_self_consistent():
         z = np.load(os.path.join(gold, f"e2e_{case}.npz"))
         assert list(z["seeds"]) == [1, 2, 3]
         n_it, K = cfg["learning_iter"], int(cfg["mcmc_per_flow_steps"])
-        lr = optim.learning_rate_fn(n_it, 0, 1e-3)
+        lr = optim.learning_rate_fn(n_it, 0, cfg.get("learning_rate", 1e-3))
         for s in (1, 2, 3):
             for key in ("loss", "learning_rate", "beta", "acc_mean", "acc_std"):
                 assert z[f"s{s}_{key}"].shape == (n_it,), (case, s, key)
