@@ -258,15 +258,15 @@ def pmc_traffic(kernel_class, workload="phi-four"):
     same command, tools/prof_round.sh): 2 * FETCH_SIZE + WRITE_SIZE, both reported in KB; the factor 2 is the gfx950
     correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section).  None when no summary is present."""
     files = {"phi-four": ("profiles/r05_pmc_summary.json", "profiles/r04_pmc_summary.json", "profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json"),    # newest committed summary first
-             "gaussian-mixture": ("profiles/r04_gmm_pmc_summary.json", "profiles/r03_gmm_pmc_summary.json", "profiles/r02_gmm_pmc_summary.json"),
-             "4-mode": ("profiles/r04_4mode_pmc_summary.json", "profiles/r03_4mode_pmc_summary.json", "profiles/r02_4mode_pmc_summary.json"),
+             "gaussian-mixture": ("profiles/r05_gmm_pmc_summary.json", "profiles/r04_gmm_pmc_summary.json", "profiles/r03_gmm_pmc_summary.json", "profiles/r02_gmm_pmc_summary.json"),
+             "4-mode": ("profiles/r05_4mode_pmc_summary.json", "profiles/r04_4mode_pmc_summary.json", "profiles/r03_4mode_pmc_summary.json", "profiles/r02_4mode_pmc_summary.json"),
              "pines": ("profiles/r03_pines_pmc_summary.json", "profiles/r02_pines_pmc_summary.json")}.get(workload, ())
     # kernel class -> what its kernel is called in the summaries (the d = 2 flow step runs d2::flow_kernel since round 3)
     patterns = {"fm_eval": ("fm_eval_kernel", "fm_eval64"), "flow_step": ("flow_step", "d2::flow_kernel")}.get(kernel_class, (kernel_class,))
     if workload == "pines":
         # its roofline entry is the whole training step (many launches): the summary's `_fm_train_step` entry sums FETCH / WRITE
         # over the dispatches from fm_prologue_kernel to adamw_vec_kernel of every training step of the PMC passes (tools/prof_workload.sh)
-        for rel in ("profiles/r04_pines_pmc_summary.json",):
+        for rel in ("profiles/r05_pines_pmc_summary.json", "profiles/r04_pines_pmc_summary.json"):
             try:
                 c = json.load(open(os.path.join(ROOT, rel)))["_fm_train_step"]
                 return int((2.0 * c["FETCH_SIZE"]["mean_per_step"] + c["WRITE_SIZE"]["mean_per_step"]) * 1024), rel

@@ -194,9 +194,11 @@ int mfm_flow_step(mfm_ctx* ctx, int mode, uint32_t key0, uint32_t key1, double b
  * and d_nsteps may be NULL; d_nsteps is written by flow iterations only.  Returns MFM_OK or the first failing step's status.
  * On a MALA iteration of a phi-four target (relu network on the tile family) the step runs INSIDE the training kernel's workgroups
  * -- the arithmetic and draws of mfm_mala_step, bit for bit, one launch less (MFM_NO_FUSED_MALA=1 in the environment keeps the
- * two launches).  With apply_update != 0 on one rank (tile family, no context-owned communicator) the slab reduction, the
- * apply_if_finite decision and AdamW are ONE launch behind the weight-gradient kernel, bit-identical with mfm_fm_loss_grad +
- * mfm_adamw_step including skipped (non-finite) updates; MFM_NO_FUSED_OPT=1 keeps them apart. */
+ * two launches).  With apply_update != 0 on one rank (tile family, no context-owned communicator) the weight gradients, their
+ * reduction over the chain slices, the apply_if_finite decision and AdamW are ONE launch (wgrad_sk.hip), bit-identical with
+ * mfm_fm_loss_grad + mfm_adamw_step including skipped (non-finite) updates; MFM_NO_FUSED_OPT=1 keeps the optimizer apart.  That
+ * launch's workgroups wait for one another: one context per device at a time (two contexts of one process launching it concurrently
+ * on different streams could starve each other of workgroup slots). */
 int mfm_train_iter(mfm_ctx* ctx, int64_t count, int mcmc_per_flow_steps, int flow_mode,
                    uint32_t gen_key0, uint32_t gen_key1, uint32_t train_key0, uint32_t train_key1,
                    double beta, double step_size, float* d_pos, double* d_logp, float* d_grad,

@@ -330,19 +330,6 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   }
 
   FM_STAMP(2);
-  // clip(grad log pi(cond)) of this lane's output elements (:88-89), PhiFour: a function of the batch alone, formed HERE -- in the
-  // same scheduling region as the first layer's MFMAs, under which its LDS reads and ~20 vector instructions per element issue --
-  // instead of in the output layer's epilogue, where both waves of a SIMD ran it at once with the matrix pipe idle (round 5,
-  // tools/fm_stamps.py: out layer + loss 11.2 k cycles for a 4.1 k matrix floor).  Same function, same values.
-  float gcp[TPW][4];
-  const bool gc_early = n.T.kind == MFM_TARGET_PHI4;
-#pragma unroll
-  for (int q = 0; q < TPW; ++q)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int col = (wave + MLP_WAVES_FM * q) * 16 + c;
-      gcp[q][i] = gc_early && col < d ? target_gclip(n, bX, L.ldx, gcs, bGC, L.ldg, 4 * g + i, col) : 0.f;
-    }
   // ---------------- forward ----------------------------------------------------------------------------------
   auto relu_store = [&](const LayerDesc& ld, float* out, int ldo, int coff, int a_tile) {
     return [&, out, ldo, coff, a_tile](int q, int nt, int m, f32x4 acc, float bias) {
@@ -411,12 +398,12 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
                      for (int i = 0; i < 4; ++i) {
                        const int row = 4 * g + i;
                        if (col < d) {
-                         // tgt / gcp are indexed by the static slot q: select without dynamic register indexing
-                         float tg = 0.f, gce = 0.f;
-#pragma unroll
-                         for (int qq = 0; qq < TPW; ++qq) { tg = (qq == q) ? tgt[qq][i] : tg; gce = (qq == q) ? gcp[qq][i] : gce; }
-                         const float gc = gc_early ? gce : target_gclip(n, bX, L.ldx, gcs, bGC, L.ldg, row, col);
+                         const float gc = target_gclip(n, bX, L.ldx, gcs, bGC, L.ldg, row, col);
                          const float v = acc[i] + bias + bG[row * L.ldg + col] * gc;
+                         // tgt is indexed by the static slot q: select without dynamic register indexing
+                         float tg = 0.f;
+#pragma unroll
+                         for (int qq = 0; qq < TPW; ++qq) tg = (qq == q) ? tgt[qq][i] : tg;
                          const float r = b0 + row < a.n_valid ? v - tg : 0.f;
                          loss_loc += r * r;
                          dv[i] = 2.f * r;
