@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libmfm_hip.so")
 SOURCES = ["api.hip"]          # unity build: api.hip includes the kernel translation units
-SCHED_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+SCHED_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-kernarg-preload-count=8"]
 
 
 def _stale():

@@ -47,7 +47,7 @@ struct Prof {
 // draws of the coming MALA + training iterations, produced in the tail of the flow-step kernel (noise.hip)
 struct NoiseWs {
   int cap = 0;                                  // slots allocated
-  double *mala_n = nullptr, *mala_u = nullptr, *fm_x0 = nullptr, *fm_eps = nullptr;
+  draw_t *mala_n = nullptr, *fm_x0 = nullptr, *fm_eps = nullptr; double* mala_u = nullptr;
   float* fm_t = nullptr; uint32_t* d_keys = nullptr;      // [2][cap][2]
   int* counter = nullptr;
   std::vector<uint32_t> h_keys;                 // staging copy of the keys

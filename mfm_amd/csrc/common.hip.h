@@ -3,6 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Storage type of the Gaussian draws of the MALA step and of the flow-matching batch in the fused-tile family (mala.hip, fm.hip,
+// noise.hip): drawn in float64 (threefry + erfinv, as the reference under jax_enable_x64), ROUNDED to this type at the point of use,
+// whether they were produced ahead of time (noise.hip) or in line -- the chain positions they are added to are float32, and the
+// prefetched draws are the largest HBM stream of the MALA + training iteration (float64: 6 KB of its 8 KB per chain).
+typedef float draw_t;
+
+// section time stamps of the training kernel and of the MALA step inside it (development build only: tools/fm_stamps.py)
+#ifdef MFM_FM_STAMPS
+__device__ unsigned long long* g_fm_dbg = nullptr;      // [WG][32] section time stamps (development build only)
+#define FM_STAMP(id) do { if (g_fm_dbg && threadIdx.x == 0) g_fm_dbg[blockIdx.x * 32 + (id)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FM_STAMP(id) do {} while (0)
+#endif
+
 #define MFM_WAVE 64
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -9,12 +9,6 @@
 #include "mlp.hip.h"
 #include "prng.hip.h"
 
-#ifdef MFM_FM_STAMPS
-__device__ unsigned long long* g_fm_dbg = nullptr;      // [WG][32] section time stamps (development build only)
-#define FM_STAMP(id) do { if (g_fm_dbg && threadIdx.x == 0) g_fm_dbg[blockIdx.x * 32 + (id)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define FM_STAMP(id) do {} while (0)
-#endif
 
 struct WsLayout {            // tile-row offsets (units: NBB * 256 floats) into the packed activation workspaces
   int a_ffat, a_t1, a_st, a_cond, a_x1, a_sx, a_j1, a_j2, a_tiles;
@@ -28,7 +22,7 @@ struct FmMala {
   Key2 key;
   double beta, eps;
   double* logp; float* grad; float* acc_prob;      // chain state beside `pos` (updated in place), acceptance probability (may be null)
-  const double* pre_n; const double* pre_u;        // draws produced ahead of time (noise.hip), or null
+  const draw_t* pre_n; const double* pre_u;        // draws produced ahead of time (noise.hip), or null
 };
 
 struct FmArgs {
@@ -47,7 +41,7 @@ struct FmArgs {
                          // pass cannot recover f' from the stored output (relu, tanh, elu can), and LDS has no room for it
   double* loss_part;     // [gridDim.x] partial sums of squared residuals
   double ref_std;        // reference distribution of the flow: x0 = ref_std * normal (IndepGaussian(dim, var), distributions.py:93-97)
-  const double* pre_x0; const double* pre_eps; const float* pre_t;   // non-null: the batch's draws, produced ahead of time by noise_kernel
+  const draw_t* pre_x0; const draw_t* pre_eps; const float* pre_t;   // non-null: the batch's draws, produced ahead of time by noise_kernel
   int stagger_cycles;    // fm_eval_kernel<2, .>: start delay of the second workgroup of every CU (0: none)
   FmMala mala;           // fm_fwd_bwd_kernel<.., MALA = true> only
   int* flags_clear;      // non-null (TRAIN): flag words [0], [3], [4] of the optimizer's scratch, cleared here for the weight-gradient kernel
@@ -160,12 +154,11 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   }
   FM_STAMP(0);
   // ---------------- prologue: K3 batch construction (exe_flow_matching.py:151-169 / :139-147) ----------------
-  for (int i = threadIdx.x; i < 16 * L.ldx; i += (MLP_WAVES_FM * 64)) bX[i] = 0.f;      // pads (incl. x[-1], x[d..])
-  // draws produced ahead of time (noise.hip): every load of the tile is issued here, before the first use -- and before the MALA
-  // step, whose own HBM round trip they then share (behind the per-element `drawn ? load : threefry + erfinv` selection each
-  // load used to wait for the previous one: 24 HBM round trips)
+  // draws produced ahead of time (noise.hip): every load of the tile is issued in one go, well before the first use (behind the
+  // per-element `drawn ? load : threefry + erfinv` selection each load used to wait for the previous one: 24 HBM round trips) --
+  // with the MALA step in this kernel, right behind that step's own loads (mala.hip: after_loads)
   const bool drawn = a.cond_flow && a.pre_x0;
-  double x0d[TPW][4], ned[TPW][4]; float x1f[TPW][4], tpre[4] = {0.f, 0.f, 0.f, 0.f};
+  draw_t x0d[TPW][4], ned[TPW][4]; float x1f[TPW][4], tpre[4] = {0.f, 0.f, 0.f, 0.f};
   auto issue_batch_loads = [&]() {
     if (drawn) {
 #pragma unroll
@@ -180,12 +173,76 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
         }
       }
     }
-    if (a.pre_t) {
+  };
+  // The times of the tile's rows and everything that depends on them alone -- the Fourier features (:70-71) -- come FIRST: their
+  // loads (64 B of times, one frequency per lane) are issued ahead of the MALA step's and the batch's, and the features are formed
+  // while those are in flight (`early_work`: the hook of mala_chain_step, or straight away); the zero pads of the x buffer too.
+  if (a.pre_t) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) tpre[i] = a.pre_t[b0 + 4 * g + i];
+    for (int i = 0; i < 4; ++i) tpre[i] = a.pre_t[b0 + 4 * g + i];
+  }
+  // the wave's first frequency tile: an UNCONDITIONAL load kept in its storage type until `early_work` (behind a branch, or converted
+  // here, the compiler waits for it -- and for the weight fragments requested above -- on the spot: s_waitcnt vmcnt(0) before any
+  // other load of the prologue has been issued)
+  const float f_first_raw = n.fourier[(wave * 16 + c) < n.F ? wave * 16 + c : 0];
+  float tt[4];
+  Key2 kref[4];
+  uint32_t bglob[4];
+  auto early_work = [&]() {
+    issue_batch_loads();
+    for (int i = threadIdx.x; i < 16 * L.ldx; i += (MLP_WAVES_FM * 64)) bX[i] = 0.f;      // pads (incl. x[-1], x[d..])
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bglob[i] = a.chain_offset + (uint32_t)(b0 + 4 * g + i);
+      if (a.pre_t) { tt[i] = tpre[i]; kref[i] = Key2{0, 0}; continue; }
+      tt[i] = (float)uniform01(a.key_time, bglob[i], a.n_total);                  // :154 / :142
+      kref[i] = split_at(a.key_ref, a.n_total, bglob[i]);                         // :155
+    }
+    // Fourier features of t (:70-71): cos block then sin block
+    if (n.F % 16 == 0) {          // tile-aligned halves: one sincos per (row, frequency) feeds both
+      const int FT = n.F / 16;
+      for (int nt = wave; nt < FT; nt += MLP_WAVES_FM) {
+        const int col = nt * 16 + c;
+        const double f = nt == wave ? (double)f_first_raw : (double)n.fourier[col];
+        f32x4 cs, sn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          double ft = f * (double)tt[i];
+          ft -= rint(ft);
+          float sv, cvv;
+          sincospif(2.f * (float)ft, &sv, &cvv);
+          cs[i] = cvv; sn[i] = sv;
+          bFF[(4 * g + i) * L.ldff + col] = cvv;
+          bFF[(4 * g + i) * L.ldff + n.F + col] = sv;
+        }
+        if (TRAIN) {
+          store_chk(a.acts, a.ws.a_ffat + nt, cs);
+          store_chk(a.acts, a.ws.a_ffat + FT + nt, sn);
+        }
+      }
+    } else {
+      for (int nt = wave; nt * 16 < n.F2p; nt += MLP_WAVES_FM) {
+        const int col = nt * 16 + c;
+        f32x4 fv = {0.f, 0.f, 0.f, 0.f};
+        if (col < 2 * n.F) {
+          const bool is_sin = col >= n.F;
+          const double f = n.fourier[is_sin ? col - n.F : col];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            double ft = f * (double)tt[i];
+            ft -= rint(ft);
+            float sv, cvv;
+            sincospif(2.f * (float)ft, &sv, &cvv);
+            fv[i] = is_sin ? sv : cvv;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bFF[(4 * g + i) * L.ldff + col] = fv[i];
+        if (TRAIN) store_chk(a.acts, a.ws.a_ffat + nt, fv);
+      }
     }
   };
-  if constexpr (!MALA) issue_batch_loads();
+  if constexpr (!MALA) early_work();
   if constexpr (MALA) {
     // rows `wave` and `wave + 8` of the tile; their LDS rows live in the dv buffer (first written by the output layer's epilogue)
     MalaArgs m;
@@ -198,23 +255,13 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     float* const xs[2] = {bDV + wave * L.lddv + 4, bDV + (wave + 8) * L.lddv + 4};
     float* const gsm[2] = {gcs + wave * 8, gcs + (wave + 8) * 8};
     FM_STAMP(6);
-    mala_chain_step<2 * TPW, 2>(m, bs, xs, gsm, lane, issue_batch_loads);      // the batch's loads queue up behind the step's
+    mala_chain_step<2 * TPW, 2>(m, bs, xs, gsm, lane, early_work);
     FM_STAMP(7);
   }
   __syncthreads();
   FM_STAMP(8);
   // x1 of (tile row, column): the chain's position -- from HBM, or what the MALA step above left in LDS
   auto x1_at = [&](int row, int col) -> float { return MALA ? bDV[row * L.lddv + 4 + col] : a.pos[(size_t)(b0 + row) * d + col]; };
-  float tt[4];
-  Key2 kref[4];
-  uint32_t bglob[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    bglob[i] = a.chain_offset + (uint32_t)(b0 + 4 * g + i);
-    if (a.pre_t) { tt[i] = tpre[i]; kref[i] = Key2{0, 0}; continue; }
-    tt[i] = (float)uniform01(a.key_time, bglob[i], a.n_total);                  // :154 / :142
-    kref[i] = split_at(a.key_ref, a.n_total, bglob[i]);                         // :155
-  }
   float tgt[TPW][4];
   if (drawn) {
     if constexpr (MALA) {
@@ -235,8 +282,8 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
       for (int i = 0; i < 4; ++i) {
         tgt[q][i] = 0.f;
         if (live) {
-          const double x1v = x1f[q][i], t = tt[i], x0 = a.ref_std * x0d[q][i];
-          cv[i] = (float)((double)a.sigma * ned[q][i] + t * x1v + (1.0 - t) * x0);      // :167
+          const double x1v = x1f[q][i], t = tt[i], x0 = a.ref_std * (double)x0d[q][i];
+          cv[i] = (float)((double)a.sigma * (double)ned[q][i] + t * x1v + (1.0 - t) * x0);      // :167
           tgt[q][i] = (float)(x1v - x0);                                              // :168
           bX[(4 * g + i) * L.ldx + 4 + col] = cv[i];
         }
@@ -258,8 +305,8 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
         double cnd, tg;
         if (a.cond_flow) {
           const size_t po = (size_t)(b0 + row) * d + col;
-          const double x0 = a.ref_std * (a.pre_x0 ? a.pre_x0[po] : normal64(kref[i], (uint32_t)col, (uint32_t)d));
-          const double ne = a.pre_x0 ? a.pre_eps[po] : normal64(a.key_gauss, bglob[i] * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d);  // :166
+          const double x0 = a.ref_std * (double)(a.pre_x0 ? a.pre_x0[po] : (draw_t)normal64(kref[i], (uint32_t)col, (uint32_t)d));
+          const double ne = (double)(a.pre_x0 ? a.pre_eps[po] : (draw_t)normal64(a.key_gauss, bglob[i] * (uint32_t)d + (uint32_t)col, a.n_total * (uint32_t)d));  // :166
           cnd = (double)a.sigma * ne + t * x1v + (1.0 - t) * x0;               // :167
           tg = x1v - x0;                                                       // :168
         } else {
@@ -276,49 +323,6 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     if (TRAIN && nt * 16 < n.dp) store_chk(a.acts, a.ws.a_cond + nt, cv);
   }
   FM_STAMP(1);
-  // Fourier features of t (:70-71): cos block then sin block
-  if (n.F % 16 == 0) {          // tile-aligned halves: one sincos per (row, frequency) feeds both
-    const int FT = n.F / 16;
-    for (int nt = wave; nt < FT; nt += MLP_WAVES_FM) {
-      const int col = nt * 16 + c;
-      const double f = n.fourier[col];
-      f32x4 cs, sn;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        double ft = f * (double)tt[i];
-        ft -= rint(ft);
-        float sv, cvv;
-        sincospif(2.f * (float)ft, &sv, &cvv);
-        cs[i] = cvv; sn[i] = sv;
-        bFF[(4 * g + i) * L.ldff + col] = cvv;
-        bFF[(4 * g + i) * L.ldff + n.F + col] = sv;
-      }
-      if (TRAIN) {
-        store_chk(a.acts, a.ws.a_ffat + nt, cs);
-        store_chk(a.acts, a.ws.a_ffat + FT + nt, sn);
-      }
-    }
-  } else {
-    for (int nt = wave; nt * 16 < n.F2p; nt += MLP_WAVES_FM) {
-      const int col = nt * 16 + c;
-      f32x4 fv = {0.f, 0.f, 0.f, 0.f};
-      if (col < 2 * n.F) {
-        const bool is_sin = col >= n.F;
-        const double f = n.fourier[is_sin ? col - n.F : col];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          double ft = f * (double)tt[i];
-          ft -= rint(ft);
-          float sv, cvv;
-          sincospif(2.f * (float)ft, &sv, &cvv);
-          fv[i] = is_sin ? sv : cvv;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bFF[(4 * g + i) * L.ldff + col] = fv[i];
-      if (TRAIN) store_chk(a.acts, a.ws.a_ffat + nt, fv);
-    }
-  }
   __syncthreads();
   if (n.T.kind == MFM_TARGET_GMM && (n.T.n_modes <= 16 ? threadIdx.x < 256 : threadIdx.x < 16)) {      // one mode per lane (targets.hip.h)
     double lp; float gg[8];

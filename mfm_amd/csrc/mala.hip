@@ -27,7 +27,7 @@ struct MalaArgs {
   int textbook;
   float* pos; double* logp; float* grad;                    // state, updated in place
   float* acc_prob; uint8_t* accepted; float* proposed; float* prop_weight;   // info (may be null)
-  const double* pre_n; const double* pre_u;   // non-null: the step's Gaussian / uniform draws, produced ahead of time by noise_kernel
+  const draw_t* pre_n; const double* pre_u;   // non-null: the step's Gaussian / uniform draws, produced ahead of time by noise_kernel
 };
 
 // value (float64, wave-reduced) and gradient of the tempered target for the row staged in `xs`.
@@ -136,7 +136,10 @@ __global__ __launch_bounds__(MALA_WAVES * 64) void loglik_kernel(MalaArgs a, dou
 // going back to HBM.  The chains of a wave are independent: their loads and float64 butterfly sums interleave.  Only the wave's
 // own lanes touch xs[c], so the staging needs no workgroup barrier.
 // `after_loads()` runs once the step's own loads are in flight and before their first use: a caller with loads of its own issues
-// them there, BEHIND these in the (in-order) memory queue, so that the step's data comes first and theirs arrives while it computes.
+// them there, BEHIND these in the (in-order) memory queue, so that the step's data comes first and theirs arrives while it computes
+// -- and does there whatever needs none of the loads.  (Every workgroup of the grid is in this prologue at once: the memory
+// system delivers ~10 B/clk/CU and the ISSUE of a load stalls behind it; issuing the caller's loads later, after the proposal, stalled
+// just as long there and was slower: tools/fm_stamps.py --loop, 8.3 k cycles for that section.)
 struct MalaNoHook { __device__ __forceinline__ void operator()() const {} };
 template <int MAXIT, int NCH, typename Hook = MalaNoHook>
 __device__ __forceinline__ void mala_chain_step(const MalaArgs& a, const int (&b)[NCH], float* const (&xs)[NCH], float* const (&gsm)[NCH], int lane,
@@ -150,7 +153,7 @@ __device__ __forceinline__ void mala_chain_step(const MalaArgs& a, const int (&b
   double th1[NCH];                        // |x' - x - eps g|^2 = 2 eps |noise|^2
   Key2 k_int[NCH], k_rmh[NCH];
   const double s2e = sqrt(2.0 * a.eps);
-  double nz[NCH][MAXIT];                  // prefetched draws: all loads in flight before the first use
+  draw_t nz[NCH][MAXIT];                  // prefetched draws: all loads in flight before the first use
   double lp0[NCH], u0[NCH];               // the accept step's two scalars: requested here, a whole HBM round trip before their use
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -165,7 +168,7 @@ __device__ __forceinline__ void mala_chain_step(const MalaArgs& a, const int (&b
       k_rmh[c] = split_at(kb, 2, 1);
     } else {
 #pragma unroll
-      for (int it = 0; it < MAXIT; ++it) { const int j = lane + 64 * it; nz[c][it] = j < d ? a.pre_n[row + j] : 0.0; }
+      for (int it = 0; it < MAXIT; ++it) { const int j = lane + 64 * it; nz[c][it] = j < d ? a.pre_n[row + j] : (draw_t)0; }
     }
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
@@ -173,16 +176,18 @@ __device__ __forceinline__ void mala_chain_step(const MalaArgs& a, const int (&b
       if (j < d) { x[c][it] = a.pos[row + j]; g[c][it] = a.grad[row + j]; }
     }
   }
+  FM_STAMP(10);
   __builtin_amdgcn_sched_barrier(0);
   after_loads();
   __builtin_amdgcn_sched_barrier(0);
+  FM_STAMP(11);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
       const int j = lane + 64 * it;
       if (j < d) {
-        const double n = a.pre_n ? nz[c][it] : normal64(k_int[c], (uint32_t)j, (uint32_t)d);   // util.py:80-82
+        const double n = a.pre_n ? (double)nz[c][it] : (double)(draw_t)normal64(k_int[c], (uint32_t)j, (uint32_t)d);   // util.py:80-82
         const double th = s2e * n;
         th1[c] += th * th;
         xn[c][it] = (float)((double)x[c][it] + a.eps * (double)g[c][it] + th);     // diffusions.py:25-30
@@ -194,6 +199,7 @@ __device__ __forceinline__ void mala_chain_step(const MalaArgs& a, const int (&b
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
+  FM_STAMP(12);
   float gn[NCH][MAXIT];
   double lpn[NCH], th2[NCH];              // th2 = |x - x' - eps g'|^2
 #pragma unroll
@@ -209,8 +215,10 @@ __device__ __forceinline__ void mala_chain_step(const MalaArgs& a, const int (&b
       }
     }
   }
+  FM_STAMP(13);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) { th1[c] = wave_sum(th1[c]); th2[c] = wave_sum(th2[c]); }
+  FM_STAMP(14);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const size_t row = (size_t)b[c] * d;

@@ -133,7 +133,13 @@ __device__ __forceinline__ WskElem wsk_decode(const NetDev& n, const WskJob& J, 
   return e;
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_sk_kernel(WskArgs a) {      // (two workgroups per CU: 2 waves per SIMD, at most 256 registers per lane)
+// The first six arguments repeat fields of `a`: scalar arguments at the head of the argument list are PRELOADED into SGPRs by the
+// command processor (-mllvm -amdgpu-kernarg-preload-count=8, mfm_amd/build.py), so the unit-range lookup and the first fetches of the
+// ring do not wait for a read of the kernel-argument segment first (three dependent scalar-load round trips in the by-value form:
+// xcd flag -> G -> pointers; tools/wsk_stamps.py: 3.6 us from the workgroup's start to the ring's last prime fetch).  On a stack
+// without the preload the compiler's compatibility prologue loads them the usual way.
+__global__ __launch_bounds__(256, 2) void wgrad_sk_kernel(const WskWg* wg_tab, const float* acts_p, const float* dzs_p, int nbb_p, int G_remap,
+                                                          WskArgs a) {      // (two workgroups per CU: 2 waves per SIMD, at most 256 registers per lane)
   // ONE __shared__ object: with a second one beside the LDS-DMA ring hipcc waits vmcnt(0) before the first ds_read of every stage
   // and the ring drains (cdna_hip_programming.md section 5, trap 4(a)); the flag word lives behind the ring
   __shared__ f32x4 sh_all[WSK_NS * WSK_TB * 8 * 64 + 1];
@@ -144,20 +150,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_sk_kernel(WskArgs a) {      // (
   WSK_STAMP(0);
   // workgroup -> unit range
   int w = blockIdx.x;
-  if (a.xcd_remap) {           // bijective for any G (cdna_hip_programming.md, XCD swizzle): the blockIdx.x % 8 class x gets a contiguous run of w
-    const int q = a.G >> 3, r = a.G & 7, x = w & 7, i = w >> 3;
+  if (G_remap > 0) {           // (G_remap: G, negated when the remap is off) bijective for any G (cdna_hip_programming.md, XCD swizzle): the blockIdx.x % 8 class x gets a contiguous run of w
+    const int q = G_remap >> 3, r = G_remap & 7, x = w & 7, i = w >> 3;
     w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
   }
-  const WskWg& D = a.wg[w];
-  const int nbb = a.nbb, j0 = D.j0, bb0 = D.bb0, cnt = D.cnt;
+  const WskWg& D = wg_tab[w];
+  const int nbb = nbb_p, j0 = D.j0, bb0 = D.bb0, cnt = D.cnt;
   const int n0 = D.n0;                                               // tiles of the first segment (block j0); the rest belong to block j0 + 1
   const int nseg = n0 < cnt ? 2 : 1;
   // per segment: the tiles this wave FETCHES (A tile `wave`, dZ tile `wave` of the block)
   const f32x4* Af[2]; const f32x4* Zf[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    Af[s] = reinterpret_cast<const f32x4*>(a.acts) + (size_t)D.a_row[s][wave] * nbb * 64 + lane;
-    Zf[s] = reinterpret_cast<const f32x4*>(a.dzs) + (size_t)D.z_row[s][wave] * nbb * 64 + lane;
+    Af[s] = reinterpret_cast<const f32x4*>(acts_p) + (size_t)D.a_row[s][wave] * nbb * 64 + lane;
+    Zf[s] = reinterpret_cast<const f32x4*>(dzs_p) + (size_t)D.z_row[s][wave] * nbb * 64 + lane;
   }
   typedef __attribute__((address_space(3))) void lds_void;
   typedef __attribute__((address_space(1))) const void glb_void;
@@ -206,6 +212,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_sk_kernel(WskArgs a) {      // (
     acc00 = f32x4{0, 0, 0, 0}; acc01 = acc00; acc10 = acc00; acc11 = acc00; bs0 = acc00; bs1 = acc00;
   };
 
+  // (Tried: the fragments of tile i + 1 requested from LDS, and the stage hand-over done, between the first four and the other twelve
+  // MFMAs of tile i, so that one wave per SIMD would keep the matrix pipe busy and 256 equal workgroups could replace 416 -- slower in
+  // every decomposition: 38.1 us at 416 workgroups against 36.5, 40.3 - 40.8 at 256, 43.6 at 512; tools/dbg/wsk_sweep.sh.)
   for (int it = 0; it < nst; ++it) {
     if (it == 1) WSK_STAMP(2);
     // stage `it` has landed for this wave once at most the (WSK_NS - 2) younger stages are outstanding; the barrier makes that true for
@@ -416,6 +425,6 @@ static void wsk_plan(int n_jobs, int nbb, int cap, int& G, int& q, int& r) {
   q = U / G; r = U - q * G;                      // a range is never longer than one block's chain axis: at most two partial blocks per workgroup
 }
 int launch_wgrad_sk(const WskArgs& a, int G, hipStream_t stream) {
-  hipLaunchKernelGGL(wgrad_sk_kernel, dim3(G), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(wgrad_sk_kernel, dim3(G), dim3(256), 0, stream, a.wg, a.acts, a.dzs, a.nbb, a.xcd_remap ? a.G : -a.G, a);
   return 0;
 }

@@ -52,12 +52,18 @@ if "--loop" in sys.argv:            # the benchmarked regime end to end: a flow 
     for i in range(K):
         ctx.train_iter(i + 1, K, _lib.FLOW_RWMH, kk[i, 0], kk[i, 1], 1.0, 1e-4, pos, logp, grad, loss, grads, acc=acc)
     torch.cuda.synchronize()
-    s = buf.cpu().numpy().reshape(256, 32).astype(np.float64)[:, [0, 6, 7, 8, 1, 2, 3, 4, 5]]
+    raw = buf.cpu().numpy().reshape(256, 32).astype(np.float64)
+    s = raw[:, [0, 6, 7, 8, 1, 2, 3, 4, 5]]
     for n, v in zip(["zero pads + issue loads", "MALA step (wave 0)", "barrier", "batch construction", "fourier", "forward 7 layers", "out layer+loss", "backward 6 dgrads"],
                     np.diff(s, axis=1).mean(0)):
         print(f"{n:26s} {v:10.0f}")
     tot = s[:, -1] - s[:, 0]
     print("total: mean", tot.mean(), "min", tot.min(), "max", tot.max())
+    if raw[:, 10].all():           # stamps inside mala_chain_step (wave 0)
+        f = raw[:, [6, 10, 11, 12, 13, 14, 7]]
+        for n, v in zip(["  MALA: issue own loads", "  MALA: batch loads issued, times, Fourier features, pads", "  MALA: proposal (waits for the loads)", "  MALA: value + gradient at the proposal",
+                         "  MALA: four float64 wave sums", "  MALA: accept + stores"], np.diff(f, axis=1).mean(0)):
+            print(f"{n:44s} {v:10.0f}")
     sys.exit(0)
 if "--mala" in sys.argv:            # mfm_train_iter: the MALA step inside the training kernel (stamps 6 / 7 / 8 around it)
     if "--prefetch" not in sys.argv:
