@@ -21,7 +21,8 @@ Prints ONE JSON line (rank 0).  value = (chains over all GPUs) * K / (max-over-r
 config.cycle_weighted_value = the same run's per-iteration and per-flow-step times composed into one full (K + 1)-iteration cycle
 (what `value` converges to when --steps is a multiple of the cycle).
 "roofline": the kernel with the largest share of GPU time in the timed region (HIP events recorded by the library on
-its stream, mfm_profile); "cpu_baseline": the float64 numpy oracle (a port of the reference semantics, NOT JAX/XLA)
+its stream, mfm_profile); "cpu_baseline": libmfm_ref, the float64 C / OpenMP oracle (a port of the reference semantics, NOT JAX/XLA;
+the numpy oracle beside it on the headline workload, alone on the others)
 timed on this host on a bounded sample of the same workload.
 """
 import argparse
@@ -107,10 +108,12 @@ def fixed_step_report(dist, args, fourier, params_flat, pos, logp, grad, field_e
     return res
 
 
-def cpu_baseline(params_flat, fourier, steps_mala, chains, seed=1):
-    """Oracle (float64 numpy, multi-threaded BLAS) on a bounded sample: `chains` chains, `steps_mala` MALA+train
-    iterations and ONE flow-MH step + train step, with the network the GPU run has after its warm-up.  Composed into
-    one 101-iteration cycle: 100 * t(MALA+train) + t(flow+train)."""
+def cpu_baseline(params_flat, fourier, steps_mala, chains, seed=1, c_threads=0):
+    """Oracle on a bounded sample: `chains` chains, `steps_mala` MALA+train iterations and ONE flow-MH step + train step, with the
+    network the GPU run has after its warm-up.  Composed into one 101-iteration cycle: 100 * t(MALA+train) + t(flow+train).
+    c_threads = 0: the float64 numpy restatement (multi-threaded BLAS); > 0: libmfm_ref, its C / OpenMP restatement (oracle/cref:
+    the target, the MALA arithmetic, the network and the adaptive solves in C on that many threads; keys, draws and the AdamW step by
+    the numpy modules).  Same keys, same chains: the two legs do the same work."""
     import numpy as np
     from oracle import flow, fm, loop, mala, optim, prng, targets
     from oracle.vfield import VectorFieldNet, unflat_params
@@ -125,20 +128,37 @@ def cpu_baseline(params_flat, fourier, steps_mala, chains, seed=1):
     st = mala.init(dist.init_params, vg)
     key = prng.PRNGKey(seed + 1)
 
+    cr = None
+    if c_threads:
+        from oracle import cref
+        cr = cref.CRef(model, params)
+        cr.set_threads(c_threads)
+
     def train(st, k):
-        loss, grads = fm.loss_and_grad(model, state.params, k, st.position, args.sigma)
+        if cr is not None:
+            cr.set_params(state.params)
+            loss, grads = cr.fm_loss_grad(*fm.cond_flow_batch(k, st.position, args.sigma))
+        else:
+            loss, grads = fm.loss_and_grad(model, state.params, k, st.position, args.sigma)
         state.apply_gradients(grads)
 
     t0 = time.perf_counter()
     for i in range(steps_mala):
         key, k1, k2 = prng.split(key, 3)
-        st, _, _ = mala.kernel(prng.split(k1, chains), st, vg, args.step_size)
+        if cr is not None:
+            st, _ = cr.mala_kernel(prng.split(k1, chains), st, args.step_size)
+        else:
+            st, _, _ = mala.kernel(prng.split(k1, chains), st, vg, args.step_size)
         train(st, k2)
     t_mala = (time.perf_counter() - t0) / steps_mala
     key, k1, k2 = prng.split(key, 3)
     t0 = time.perf_counter()
     stats = {}
-    st, _ = flow.rwmh_step(prng.split(k1, chains), st, vg, model, state.params, args, stats)
+    if cr is not None:
+        cr.set_params(state.params)
+        st, _ = cr.rwmh_step(prng.split(k1, chains), st, args, stats=stats)
+    else:
+        st, _ = flow.rwmh_step(prng.split(k1, chains), st, vg, model, state.params, args, stats)
     train(st, k2)
     t_flow = time.perf_counter() - t0
     cycle = 100 * t_mala + t_flow
@@ -567,11 +587,19 @@ def main():
                         cb = cpu_baseline_d2(a.workload, params_flat, fourier, chains=a.chains_per_gpu, n_eval=n_eval, K=wl_K)
                         sample = cb.pop("sample")
                     else:
-                        cb = cpu_baseline(params_flat, fourier, steps_mala=4, chains=512)
+                        # two legs on the same 512 chains, keys and network: libmfm_ref (C / OpenMP, the reported value) and the numpy restatement
+                        cb = cpu_baseline(params_flat, fourier, steps_mala=4, chains=512, c_threads=cores)
+                        cn = cpu_baseline(params_flat, fourier, steps_mala=4, chains=512)
                         sample = (f"512 chains: 4 MALA+train iterations and 1 flow-MH+train iteration (mean {cb['n_att']:.1f} "
                                   f"Dopri5 attempts), same network as the GPU after warm-up; composed into a 101-iteration cycle "
-                                  f"(t_mala_train={cb['t_mala_train_s']:.3f}s, t_flow_train={cb['t_flow_train_s']:.3f}s); float64 numpy oracle")
+                                  f"(t_mala_train={cb['t_mala_train_s']:.3f}s, t_flow_train={cb['t_flow_train_s']:.3f}s); libmfm_ref: float64 C / OpenMP "
+                                  f"restatement (oracle/cref), one chain per task; the float64 numpy restatement on the same sample and threads: "
+                                  f"{cn['value']:.1f} chain-steps/s (t_mala_train={cn['t_mala_train_s']:.3f}s, t_flow_train={cn['t_flow_train_s']:.3f}s, "
+                                  f"mean {cn['n_att']:.1f} attempts)")
+                        extra = {"numpy_value": round(cn["value"], 1)}
                 out["cpu_baseline"] = {"value": round(cb["value"], 1), "unit": "chain-steps/s", "cores": cores, "kind": "port", "sample": sample}
+                if a.workload == "phi-four":
+                    out["cpu_baseline"].update(extra)
             except Exception as e:  # the baseline must never hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "chain-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)

@@ -28,6 +28,11 @@ restatement instead (tests/test_oracle_*.py):
 * Dormand-Prince against closed-form linear flows and ``scipy`` RK45;
 * the MALA energy algebra against a literal per-chain transcription.
 
+``oracle/cref/`` holds ``libmfm_ref``: the same arithmetic for the headline configuration (PhiFour target, MALA step, relu
+network forward / JVP / parameter gradient, adaptive Dopri5 CNF solves with the Hutchinson log-det) in C with OpenMP, one chain
+per task -- checked function by function against this package (tests/test_oracle_cref.py) and timed as the CPU baseline of
+``bench.py``.  Same standing: test infrastructure, parity unpinned.
+
 Fixtures under ``tests/golden/`` are OUTPUTS OF THIS ORACLE (script:
 ``tools/make_golden.py``), frozen so the GPU tests have fixed inputs and
 expected outputs; they are not outputs of the reference.
