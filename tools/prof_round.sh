@@ -1,14 +1,11 @@
 #!/bin/bash
-# rocprofv3 evidence for profiles/: kernel trace + stats of the bench command, then PMC passes (separate runs, no trace
-# domains besides --kernel-trace).  usage (on the GPU box): tools/prof_round.sh TAG
+# rocprofv3 evidence for profiles/: PMC passes of the bench command (separate runs, no trace domains besides --kernel-trace),
+# then kernel trace + stats of it.  usage (on the GPU box): tools/prof_round.sh TAG
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r02}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
-echo "trace done"; head -5 $OUT/kernel_stats.csv | cut -c1-150
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE FETCH_SIZE" \
@@ -31,3 +28,9 @@ json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1)
 for k, cs in res.items():
     if "flow_step" in k or "fm_fwd" in k: print(k, {c: "%.4g" % v["mean_per_launch"] for c, v in cs.items()})
 PY
+# the PMC summary goes into profiles/ BEFORE the traced run, whose JSON line quotes `traffic` from that committed file
+cp $OUT/pmc_summary.json $R/profiles/${TAG}_pmc_summary.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+echo "trace done"; head -5 $OUT/kernel_stats.csv | cut -c1-150
+cp $OUT/kernel_stats.csv $R/gpurun_out/${TAG}_bench_kernel_stats.csv; cp $OUT/bench_under_rocprof.json $R/gpurun_out/${TAG}_bench_under_rocprof.json; cp $OUT/pmc_summary.json $R/gpurun_out/${TAG}_pmc_summary.json
