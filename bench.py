@@ -551,7 +551,8 @@ def main():
         par = ("single GPU" + (f" (REHEARSAL: the multi-rank call sequence with its collectives on a one-rank '{backend}' communicator)" if td is not None else "")) if world == 1 else (f"chains sharded x{world}, one gradient all-reduce(SUM) per iteration over torch.distributed backend "
                                                f"'{backend}'" + (" (RCCL over xGMI)" if backend == "nccl" else " (rehearsal backend, NOT RCCL)"))
         if getattr(eng, "rccl_in_lib", False):
-            par += "; gradient all-reduce inside the library on a context-owned RCCL communicator (mfm_comm_init, MFM_RCCL_IN_LIB=1)"
+            par += ("; gradient all-reduce inside the library on a context-owned RCCL communicator (mfm_comm_init)"
+                    + (", in line behind the weight-gradient kernel of one mfm_train_iter per iteration" if getattr(eng, "_fused_n", False) else ", on its communication stream, optimizer step deferred"))
         out = {
             "metric": f"MFM train-steps/s x chains ({desc[0]})", "value": round(value, 1),
             "unit": "chain-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

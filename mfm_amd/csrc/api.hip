@@ -912,10 +912,15 @@ extern "C" int mfm_adamw_step(mfm_ctx* x, const float* d_grads) { use_ctx(x);
     // earlier by mfm_grad_allreduce_begin, or here
     if (x->comm_pending != d_grads) {
       if (x->comm_pending) return fail(MFM_EINVAL, "an all-reduce of another buffer is in flight");
-      const int rc = mfm_grad_allreduce_begin(x, const_cast<float*>(d_grads));
-      if (rc) return rc;
+      if (!g_sw.rccl_comm_stream) {     // nothing to overlap with: the collective in line on the context's stream, no event hops
+        RcclApi* R = rccl_api();
+        RCCLCHK(R->AllReduce(d_grads, const_cast<float*>(d_grads), (size_t)x->net.n_params, ncclFloat32, ncclSum, x->comm, x->stream));
+      } else {
+        const int rc = mfm_grad_allreduce_begin(x, const_cast<float*>(d_grads));
+        if (rc) return rc;
+      }
     }
-    HIPCHK(hipStreamWaitEvent(x->stream, x->ev_comm, 0));
+    if (x->comm_pending) HIPCHK(hipStreamWaitEvent(x->stream, x->ev_comm, 0));
     x->comm_pending = nullptr;
     if (x->comm_nranks > 1) a.inline_decide = 0;      // the finite check must see the reduced gradient
   }

@@ -36,6 +36,8 @@ struct Switches {
   bool wide_nocompact = false, wide_no_tbatch = false;
   bool tile_exact = false;  // exact-trace solves of the fused family on its own generic tile instead of the wide family's solver (api.hip: wide_ex)
   bool wsk_xcd = false;     // wgrad_sk.hip: consecutive unit ranges on one XCD instead of workgroup w = blockIdx.x (A/B, with MFM_WSK_G)
+  bool rccl_comm_stream = false;   // api.hip: the gradient all-reduce of an mfm_adamw_step that has none in flight goes through the communication stream
+                                   // (two event hops) instead of in line on the context's own stream (A/B)
   int flow_live = 0;        // chains per workgroup of the shape-specialised flow step: 0 automatic, 16 / 8 / 4 / 2 forced (ode_fast.hip: flow_live_rows)
 };
 static Switches g_sw;
@@ -52,7 +54,7 @@ static void switches_read() {
   s.wide_ring8 = on("MFM_WIDE_RING8"); s.wide_wgrad_nosplit = on("MFM_WIDE_WGRAD_NOSPLIT");
   s.wide_nocompact = on("MFM_WIDE_NOCOMPACT"); s.wide_no_tbatch = on("MFM_WIDE_NO_TBATCH");
   if (const char* e = getenv("MFM_FLOW_LIVE")) s.flow_live = atoi(e);
-  s.tile_exact = on("MFM_TILE_EXACT"); s.wsk_xcd = on("MFM_WSK_XCD");
+  s.tile_exact = on("MFM_TILE_EXACT"); s.wsk_xcd = on("MFM_WSK_XCD"); s.rccl_comm_stream = on("MFM_RCCL_COMM_STREAM");
   g_sw = s;
 }
 

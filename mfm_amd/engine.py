@@ -81,7 +81,7 @@ class DeferredAllReduce:
 
     def __init__(self, apply, begin_in_lib=None):
         self.apply = apply
-        self.begin_in_lib = begin_in_lib     # context-owned communicator (MFM_RCCL_IN_LIB=1): the library starts and awaits the all-reduce
+        self.begin_in_lib = begin_in_lib     # context-owned communicator: the library starts and awaits the all-reduce
         self.work = None
         self.armed = False
 
@@ -161,14 +161,27 @@ class Engine:
         import os
         self._split_calls = bool(os.environ.get("MFM_SPLIT_CALLS")) or _collective(td)   # development: the multi-rank call sequence on one rank
         begin = None
-        if os.environ.get("MFM_RCCL_IN_LIB") and _collective(td):
-            # the gradient all-reduce inside the library, on a communicator the context owns (include/mfm.h: mfm_comm_*); the
-            # 128-byte id travels over the process group that is already up (control plane only)
-            ids = [self.ctx.comm_unique_id() if self.rank == 0 else None]
+        # More than one rank: the gradient all-reduce runs inside the library, on a communicator the context owns (include/mfm.h:
+        # mfm_comm_*), IN LINE on the context's stream right behind the weight-gradient kernel, and every iteration is ONE
+        # mfm_train_iter like on one rank (MALA step inside the training kernel).  Measured on a one-rank communicator (tools/dbg/
+        # rehearse_n.sh): 84.1 us per MALA + training iteration against 78.8 without collectives -- torch.distributed's all-reduce on RCCL's
+        # own stream with the optimizer step deferred behind the next MALA step: 109.3 (two cross-stream event hops cost more than the 9 us
+        # of overlap they buy).  MFM_TORCH_ALLREDUCE=1 keeps that form; so does a process group that is not RCCL.  The 128-byte id travels
+        # over the process group that is already up (control plane only); a rank-0 failure to produce it sends every rank to the fallback.
+        if _collective(td) and td.get_backend() == "nccl" and not os.environ.get("MFM_TORCH_ALLREDUCE"):
+            ids = [None]
+            if self.rank == 0:
+                try:
+                    ids = [self.ctx.comm_unique_id()]
+                except Exception as err:                      # (librccl not loadable: every rank falls back together)
+                    import warnings
+                    warnings.warn(f"in-library RCCL communicator unavailable ({err}); using torch.distributed's all-reduce")
             td.broadcast_object_list(ids, src=0)
-            self.ctx.comm_init(self.world, self.rank, ids[0])
-            begin = self.ctx.grad_allreduce_begin
+            if ids[0] is not None:
+                self.ctx.comm_init(self.world, self.rank, ids[0])
+                begin = self.ctx.grad_allreduce_begin
         self.rccl_in_lib = begin is not None
+        self._fused_n = self.rccl_in_lib and not os.environ.get("MFM_NO_FUSED_AT_N")
         self._deferred = DeferredAllReduce(lambda: self.ctx.adamw_step(self.grads), begin)
         self.ctx.before_params = self._deferred.flush
 
@@ -212,11 +225,12 @@ class Engine:
 
     def train_iter(self, count, K, flow_mode, key_gen, key_train, beta, step_size, pos, logp, grad, acc=None, nsteps=None,
                    loss_out=None):
-        """One loop iteration (exe_flow_matching.py:432-439): generator + train_step.  One rank: a single library call
-        (``mfm_train_iter``).  More ranks: the separate calls, so that the MALA step — which needs neither the parameters
-        nor the gradient buffer — runs while the previous iteration's gradient all-reduce is still in flight."""
+        """One loop iteration (exe_flow_matching.py:432-439): generator + train_step.  A single library call (``mfm_train_iter``) on one
+        rank, and on more with the library's own communicator (the gradient all-reduce in line behind the weight-gradient kernel).  The
+        split forms (MFM_NO_FUSED_AT_N / MFM_TORCH_ALLREDUCE, or a process group that is not RCCL): the separate calls, so that the MALA
+        step — which needs neither the parameters nor the gradient buffer — runs while the previous iteration's all-reduce is in flight."""
         loss = self.loss if loss_out is None else loss_out
-        if self.world == 1 and not self._split_calls:
+        if (self.world == 1 and not self._split_calls) or self._fused_n:
             self.ctx.train_iter(count, K, flow_mode, key_gen, key_train, beta, step_size, pos, logp, grad, loss, self.grads,
                                 acc=acc, nsteps=nsteps)
             self.reseed_padding(pos, logp, grad)

@@ -99,15 +99,15 @@ def _rccl_worker(rank, world, port, out, in_lib):
     import torch
     import torch.distributed as td
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MFM_COLLECTIVES_AT_WORLD1="1")
-    if in_lib:
-        os.environ["MFM_RCCL_IN_LIB"] = "1"
+    os.environ.update({0: {"MFM_TORCH_ALLREDUCE": "1"}, 1: {"MFM_NO_FUSED_AT_N": "1"}, 2: {}}[in_lib])
     torch.cuda.set_device(0)
     td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     from mfm_amd import distributions as D, exe_flow_matching as E
     res, res_, ex = E.run(D.PhiFour(64), _args(64), None, log_every=3, return_extras=True)
     eng = ex["engine"]
-    assert eng._split_calls                                   # the multi-rank call sequence (deferred AdamW behind the async all-reduce)
-    assert eng.rccl_in_lib == bool(in_lib)                    # ... through torch.distributed's RCCL backend, or the context's own communicator
+    assert eng._split_calls                                   # the multi-rank configuration (collectives issued)
+    assert eng.rccl_in_lib == bool(in_lib)                    # torch.distributed's RCCL backend, or the context's own communicator
+    assert eng._fused_n == (in_lib == 2)                      # one mfm_train_iter per iteration with the all-reduce in line (the default)
     np.savez(out % rank, metrics=ex["metrics"], pos=ex["states"].position.cpu().numpy(), params=eng.ctx.get_params(),
              opt=np.array([eng.ctx.opt_state()[k] for k in ("step", "count")]), res=res,
              idx=ex["final"]["idx"].cpu().numpy(), flow=ex["flow_samples"].cpu().numpy())
@@ -115,14 +115,15 @@ def _rccl_worker(rank, world, port, out, in_lib):
     td.destroy_process_group()
 
 
-@pytest.mark.parametrize("in_lib", [0, 1])
+@pytest.mark.parametrize("in_lib", [0, 1, 2])
 def test_rccl_call_pattern_on_a_one_rank_communicator(tmp_path, in_lib):
     """RCCL refuses two ranks on one device, so what a one-GPU box can check of the backend the 8-GPU runs use is the CALL
-    PATTERN: the multi-rank sequence (separate MALA / loss-gradient calls, the gradient all-reduce issued asynchronously on RCCL's
-    stream, AdamW deferred behind it, all-gathers of the final evaluation) on a one-rank `nccl` communicator.  A sum over one
-    rank is the identity, so the run must reproduce the single-call run bit for bit.  in_lib = 1: the all-reduce inside the
-    library on a communicator the context owns (mfm_comm_init / mfm_grad_allreduce_begin, ncclAllReduce on the context's
-    communication stream) instead of torch.distributed's."""
+    PATTERN on a one-rank `nccl` communicator.  A sum over one rank is the identity, so each form must reproduce the single-call
+    run bit for bit.  in_lib = 2, the DEFAULT with more than one rank: the context owns the communicator (mfm_comm_init), every
+    iteration is one mfm_train_iter -- MALA step inside the training kernel, ncclAllReduce in line on the context's stream behind the
+    weight-gradient kernel, AdamW behind it -- plus the all-gathers of the final evaluation.  in_lib = 1 (MFM_NO_FUSED_AT_N): separate
+    MALA / loss-gradient calls, the all-reduce started on the context's communication stream (mfm_grad_allreduce_begin), AdamW
+    deferred behind the next MALA step.  in_lib = 0 (MFM_TORCH_ALLREDUCE): the same split sequence through torch.distributed."""
     import torch.multiprocessing as mp
     from mfm_amd import distributions as D, exe_flow_matching as E
     out = str(tmp_path / "n%d.npz")

@@ -49,7 +49,7 @@ def _worker(rank, world, port, out, n_total):
     d.submit(buf2)                                              # ... but a submit while armed flushes the first one
     d.flush()
     assert len(applied) == 3
-    # the in-library form (context-owned communicator, MFM_RCCL_IN_LIB=1): submit() starts the reduction through the library's
+    # the in-library split form (context-owned communicator, MFM_NO_FUSED_AT_N=1): submit() starts the reduction through the library's
     # begin call and issues no torch collective; the optimizer step (which awaits the reduction inside the library) runs at flush
     order = []
     buf3 = torch.full((3,), float(rank + 1), dtype=torch.float64)
