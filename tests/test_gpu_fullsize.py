@@ -294,3 +294,58 @@ def test_headline_flow_step_all_4096_chains_against_libmfm_ref(trained_phi4):
     assert (np.abs(la_g[fin] - la_o[fin]) < 250.0).all() and (la_o[shallow & np.isposinf(la_g)] > 88.7 - 250.0).all()
     # decisions: nearly every proposal is rejected in this regime, on both sides, and the same few are accepted
     assert (acc_g != info.is_accepted).sum() <= 2
+
+
+def test_headline_mala_steps_loss_and_gradient_all_4096_chains_against_libmfm_ref(trained_phi4):
+    """The other half of a benchmarked iteration at its full size, live against the oracle: three MALA steps of all 4096 chains, then the
+    flow-matching loss and its 214,272-element gradient on their positions, with the trained network of bench.py's timed region -- the
+    kernels through the C ABI against libmfm_ref (oracle/cref) fed the same keys."""
+    import torch
+    from oracle import cref, mala, targets
+    from oracle.vfield import flat_params
+    from tests import gpu_util as gu
+    tp = trained_phi4
+    B, d = 4096, 256
+    dist, model, args = tp["dist"], tp["model"], tp["args32"]
+    params = gu.unflat_params(model, tp["params_flat"])
+    x32 = tp["pos"]
+    ctx = gu.make_ctx(dist, args, n_local=B, n_total=B, fourier=model.f, params=params)
+    cr = cref.CRef(model, params)
+    pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
+    ctx.mala_init(pos, 1.0, logp, grad)
+    st = mala.init(x32.astype(np.float64), targets.Tempered(dist, 1.0).value_and_grad)
+    assert np.abs(logp.cpu().numpy() - st.logdensity).max() < 1e-7 * np.abs(st.logdensity).max()
+    acc = torch.empty(B, device="cuda"); isacc = torch.empty(B, dtype=torch.uint8, device="cuda")
+    flips, moved, ok = 0, 0, np.ones(B, bool)
+    for it in range(6):        # three steps of the rule as written (far from equilibrium it rejects: min(1, 1 / alpha)), three of the textbook rule
+        textbook = it >= 3
+        k = prng.split(prng.PRNGKey(99), 6)[it]
+        ctx.mala_step(k, 1.0, args.step_size, pos, logp, grad, acc, isacc, textbook=textbook)
+        st, info = cr.mala_kernel(prng.split(k, B), st, args.step_size, textbook=textbook)
+        same = isacc.cpu().numpy().astype(bool) == info.is_accepted
+        flips += int((~same).sum()); moved += int(info.is_accepted.sum())
+        ok &= same             # a chain whose decision differs (u within rounding of p) has left the oracle's trajectory: compare the others
+        pg, po = acc.cpu().numpy().astype(np.float64)[ok], info.acceptance_rate[ok]
+        big = po > 1e-30
+        relp = np.abs(pg[big] - po[big]) / po[big] if big.any() else np.zeros(1)
+        print(f"   step {it} ({'textbook' if textbook else 'as written'}): acceptance mean {po.mean():.3e}, accepted {int(info.is_accepted.sum())}, "
+              f"representable in float32: {int(big.sum())}, p rel. error median {np.median(relp):.1e} max {relp.max():.1e}")
+        assert np.median(relp) < 1e-3 and np.quantile(relp, 0.99) < 5e-2
+        assert (pg[~big] < 1e-29).all()
+    assert moved > 3 * B // 2 and flips <= 8 and ok.mean() > 0.998, (moved, flips, ok.mean())
+    e = np.abs(pos.cpu().numpy().astype(np.float64) - st.position)[ok]
+    print(f"full-size MALA: six steps, {moved} accepted moves, decisions flipped {flips}, |dx| max {e.max():.2e}")
+    assert e.max() < 2e-6 * max(1.0, np.abs(st.position).max())
+    # ---- loss and gradient on the oracle's positions (float32-rounded: what the kernel is given) ----
+    xk = st.position.astype(np.float32)
+    key = prng.PRNGKey(123)
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda"); g = torch.zeros(ctx.n_params, device="cuda")
+    ctx.fm_loss_grad(key, _dev(xk), loss, g)
+    lo, go = cr.fm_loss_grad(*fm.cond_flow_batch(key, xk.astype(np.float64), args.sigma))
+    gof = flat_params(go).astype(np.float64)
+    gg = g.cpu().numpy().astype(np.float64)
+    rel_l = abs(loss.item() - lo) / abs(lo)
+    rel_g = np.linalg.norm(gg - gof) / np.linalg.norm(gof)
+    print(f"full-size loss {loss.item():.6e} vs {lo:.6e} (rel {rel_l:.1e}); gradient rel. L2 {rel_g:.1e}, max |d| / max |g| {np.abs(gg - gof).max() / np.abs(gof).max():.1e}")
+    assert rel_l < 2e-5 and rel_g < 3e-4 and np.abs(gg - gof).max() < 5e-4 * np.abs(gof).max()
+    ctx.close()
