@@ -274,7 +274,8 @@ class Context:
                                               _ptr(scratch, F64), _ptr(idx, I32)))
 
     def gather_rows(self, src, idx, dst):
-        _chk(self.lib.mfm_gather_rows(self.h, _ptr(src, F32), _ptr(idx, I32), src.shape[0], src.shape[1], _ptr(dst, F32)))
+        """dst[r] = src[idx[r]] for the ``idx.shape[0]`` rows of ``dst`` (``src`` may hold more rows: the all-gathered particles of a sharded SMC step)."""
+        _chk(self.lib.mfm_gather_rows(self.h, _ptr(src, F32), _ptr(idx, I32), idx.shape[0], src.shape[1], _ptr(dst, F32)))
 
     def fm_loss_grad(self, key, pos, loss, grads):
         self._p()

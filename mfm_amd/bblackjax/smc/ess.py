@@ -9,4 +9,9 @@ def ess_solver(logdensity_fn, particles, target_ess: float, max_delta: float, ro
     if root_solver is not solver.dichotomy:
         raise NotImplementedError("only the dichotomy root solver (solver.py:20-82, the reference default) is built")
     eng = _engine_of(particles)
-    return eng.ctx.smc_delta(logdensity_fn(particles), target_ess, max_delta)
+    ll = logdensity_fn(particles)
+    from .base import _sharded
+    if _sharded(eng):                      # the effective sample size is over ALL particles: every rank solves on the gathered log-likelihoods
+        from ...engine import allgather_cat
+        ll = allgather_cat(ll.contiguous())
+    return eng.ctx.smc_delta(ll, target_ess, max_delta)

@@ -14,7 +14,7 @@ from . import random as jr
 from . import wandb_shim as wandb
 from .bblackjax.mcmc import mala
 from .bblackjax.smc import adaptive_tempered, base as smc_base, resampling
-from .engine import Engine
+from .engine import Engine, allgather_cat
 from .exe_flow_matching import _logprob_any, stein_disc
 
 logger = logging.getLogger(__name__)
@@ -30,8 +30,8 @@ def run(dist, args, target_gn=None, return_extras=False):
     key_target, key_sample, key_init, key_dist, key_fourier, key_gen = jr.split(jr.PRNGKey(args.seed), 6)     # :33
     dist.initialize_model(key_dist, n_chain)                                                # :34
     eng = Engine(dist, args, None, max_eval_samples=n_iter * n_chain)
-    if eng.world != 1:
-        raise NotImplementedError("the SMC baseline resamples over ALL particles: single GPU only")
+    if eng.n_valid != eng.n_local:
+        raise NotImplementedError("the SMC baseline needs num_chain to be a multiple of 16 per GPU (no padding rows among the particles)")
     smc_base.attach(eng)
     real_samples = None
     if target_gn is not None:                                                               # :36-39
@@ -56,7 +56,7 @@ def run(dist, args, target_gn=None, return_extras=False):
     collected = []
     for k in keys2:                                                                         # :108
         state, info = tempered.step(k, state)
-        collected.append(state.particles)
+        collected.append(allgather_cat(state.particles.contiguous()))                        # (more than one rank: every rank evaluates ALL particles)
     flow_samples = torch.cat(collected)                                                     # :109 "not really flow but MCMC"
     exact_samples = flow_samples                                                            # :110
 

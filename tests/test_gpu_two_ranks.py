@@ -140,3 +140,43 @@ def test_rccl_call_pattern_on_a_one_rank_communicator(tmp_path, in_lib):
     opt = ex["engine"].ctx.opt_state()
     assert tuple(z["opt"]) == (opt["step"], opt["count"])
     ex["engine"].close()
+
+
+def _smc_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as td
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from mfm_amd import distributions as D, exe_others as X
+    a = _args(128); a.do_smc = True; a.learning_iter = 10; a.eval_iter = 2
+    res, res_, ex = X.run(D.PhiFour(64), a, None, return_extras=True)
+    eng = ex["engine"]
+    assert (eng.world, eng.n_local, eng.offset) == (world, 64, 64 * rank)
+    assert ex["state"].particles.shape == (64, 64) and ex["state"].weights.shape == (128,)
+    np.savez(out % rank, lmbdas=ex["lmbdas"], samples=ex["samples"].cpu().numpy(), res=res, shard=ex["state"].particles.cpu().numpy(),
+             weights=ex["state"].weights.cpu().numpy())
+    eng.close()
+    td.destroy_process_group()
+
+
+def test_two_ranks_run_the_smc_baseline_like_one_process(tmp_path):
+    """Adaptive tempered SMC on the MALA kernel (exe_others.py:79-111) with the particles sharded over two ranks: resampling and the
+    ESS solver work on ALL particles (weights and log-likelihoods all-gathered, ancestors fetched from the gathered particles), the
+    MCMC moves on each rank's shard with the particle's own key -- so the run is the single-process run, bit for bit."""
+    import torch.multiprocessing as mp
+    from mfm_amd import distributions as D, exe_others as X
+    out = str(tmp_path / "s%d.npz")
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_smc_worker, args=(2, port, out), nprocs=2, join=True)
+    a = _args(128); a.do_smc = True; a.learning_iter = 10; a.eval_iter = 2
+    res, res_, ex = X.run(D.PhiFour(64), a, None, return_extras=True)
+    z = [np.load(out % r) for r in range(2)]
+    assert ex["lmbdas"][-1] > ex["lmbdas"][0] >= 0.0
+    for r in range(2):
+        np.testing.assert_array_equal(z[r]["lmbdas"], ex["lmbdas"])
+        np.testing.assert_array_equal(z[r]["samples"], ex["samples"].cpu().numpy())
+        np.testing.assert_array_equal(z[r]["weights"], ex["state"].weights.cpu().numpy())
+        np.testing.assert_array_equal(z[r]["shard"], ex["state"].particles.cpu().numpy()[64 * r:64 * r + 64])
+        np.testing.assert_array_equal(z[r]["res"][:4], res[:4])
+    ex["engine"].close()
