@@ -128,6 +128,14 @@ int mfm_mala_step_keys(mfm_ctx* ctx, const uint32_t* d_keys, double beta, double
                        float* d_pos, double* d_logp, float* d_grad,
                        float* d_acceptance_rate, uint8_t* d_is_accepted, float* d_proposed_position,
                        float* d_proposed_weight);
+/* BUILD-SIDE MODE, not on the reference's MFM path (BASELINE.json's north star names a "MALA/HMC" step; the reference's loop uses
+ * MALA only and vendors no hmc.py: SURVEY.md note 7): one Hamiltonian Monte Carlo step of every local chain as in blackjax's hmc
+ * kernel (oracle/hmc.py restates it): momentum ~ N(0, I) from split(key, n_chain_total)[chain_offset + b] -> split(., 2)[0],
+ * num_steps velocity-Verlet steps of size step_size on beta * loglik + logprior, accept with min(1, exp(H_0 - H_end)).  State
+ * updated in place like mfm_mala_step; d_acceptance_rate / d_is_accepted may be null.  phi-four and mixture targets
+ * (MFM_EUNSUPPORTED for the Cox process). */
+int mfm_hmc_step(mfm_ctx* ctx, uint32_t key0, uint32_t key1, double beta, double step_size, int32_t num_steps,
+                 float* d_pos, double* d_logp, float* d_grad, float* d_acceptance_rate, uint8_t* d_is_accepted);
 /* vmap(dist.loglik) (exe_flow_matching.py:418) */
 int mfm_loglik(mfm_ctx* ctx, const float* d_pos, double* d_out);
 

@@ -60,6 +60,7 @@ _SIGS = {
     "mfm_mala_init": (C.c_int, [_P, _P, C.c_double, _P, _P]),
     "mfm_mala_step": (C.c_int, [_P, _U32, _U32, C.c_double, C.c_double, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "mfm_mala_step_keys": (C.c_int, [_P, _P, C.c_double, C.c_double, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "mfm_hmc_step": (C.c_int, [_P, _U32, _U32, C.c_double, C.c_double, C.c_int, _P, _P, _P, _P, _P]),
     "mfm_loglik": (C.c_int, [_P, _P, _P]),
     "mfm_smc_delta": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]),
     "mfm_smc_weights": (C.c_int, [_P, _P, C.c_int, C.c_double, _P, C.POINTER(C.c_double)]),
@@ -242,6 +243,11 @@ class Context:
         _chk(self.lib.mfm_mala_step_keys(self.h, _ptr(keys, I32), float(beta), float(step_size), int(textbook),
                                          _ptr(pos, F32), _ptr(logp, F64), _ptr(grad, F32), _ptr(acc, F32), _ptr(is_acc, U8),
                                          _ptr(proposed, F32), _ptr(weight, F32)))
+
+    def hmc_step(self, key, beta, step_size, num_steps, pos, logp, grad, acc=None, is_acc=None):
+        """Build-side mode (``mfm_hmc_step``): one HMC step of every local chain, state updated in place."""
+        _chk(self.lib.mfm_hmc_step(self.h, int(key[0]), int(key[1]), float(beta), float(step_size), int(num_steps),
+                                   _ptr(pos, F32), _ptr(logp, F64), _ptr(grad, F32), _ptr(acc, F32), _ptr(is_acc, U8)))
 
     def loglik(self, pos, out):
         _chk(self.lib.mfm_loglik(self.h, _ptr(pos, F32), _ptr(out, F64)))

@@ -13,6 +13,7 @@
 
 #include "mala.hip"
 #include "lgcp.hip"
+#include "hmc.hip"
 #include "fm.hip"
 #include "optim.hip"
 #include "wgrad_sk.hip"
@@ -593,6 +594,25 @@ extern "C" int mfm_mala_step_keys(mfm_ctx* x, const uint32_t* d_keys, double bet
                                   double* d_logp, float* d_grad, float* d_acc, uint8_t* d_isacc, float* d_prop, float* d_pw) { use_ctx(x);
   if (!d_keys) return fail(MFM_EINVAL, "null key array");
   return mala_step_common(x, 0, 0, d_keys, beta, step, textbook, d_pos, d_logp, d_grad, d_acc, d_isacc, d_prop, d_pw);
+}
+
+// Build-side mode (hmc.hip; not on the reference's MFM path): one HMC step of every local chain, state updated in place like mfm_mala_step
+extern "C" int mfm_hmc_step(mfm_ctx* x, uint32_t k0, uint32_t k1, double beta, double step, int num_steps, float* d_pos, double* d_logp,
+                            float* d_grad, float* d_acc, uint8_t* d_isacc) { use_ctx(x);
+  NEED_TARGET();
+  if (!d_pos || !d_logp || !d_grad) return fail(MFM_EINVAL, "null device pointer");
+  if (!(step > 0)) return fail(MFM_EINVAL, "step_size must be positive");
+  if (num_steps < 1 || num_steps > 100000) return fail(MFM_EINVAL, "num_steps must be in [1, 100000] (got %d)", num_steps);
+  if (x->net.T.kind == MFM_TARGET_LGCP) return fail(MFM_EUNSUPPORTED, "the HMC step serves the phi-four and mixture targets (the Cox process needs the K^-1 GEMM tile)");
+  HmcArgs a; memset(&a, 0, sizeof a);
+  a.T = x->net.T; a.key = Key2{k0, k1}; a.n_total = x->cfg.n_chain_total; a.chain_offset = x->cfg.chain_offset; a.B = x->cfg.n_chain_local;
+  a.num_steps = num_steps; a.beta = beta; a.eps = step;
+  a.pos = d_pos; a.logp = d_logp; a.grad = d_grad; a.acc_prob = d_acc; a.accepted = d_isacc;
+  ProfScope ps_(x, PROF_MALA);
+  if (launch_hmc_step(a, x->stream)) return fail(MFM_ETOOLARGE, "dim %d too large for the HMC kernel", x->cfg.dim);
+  LAUNCHCHK();
+  x->ctr[CTR_MALA] += x->cfg.n_chain_local;
+  return MFM_OK;
 }
 
 extern "C" int mfm_loglik(mfm_ctx* x, const float* d_pos, double* d_out) { use_ctx(x);

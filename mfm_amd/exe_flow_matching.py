@@ -220,6 +220,8 @@ def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
         lps = _logprob_any(eng, xs, beta=beta)                                             # :288
         eng.ctx.cis_select(rng_key, n_is, u0, vol0, refs, xs, vols, lps, pos, logp, info["acc"], info["isacc"], info["prop"], info["w"])
 
+    use_hmc = getattr(args, "mcmc_kernel", "mala") == "hmc"
+
     def train_data_generator(rng_key, states, count, vector_field_param=None, beta=1.0):
         """:300-314.  States are updated IN PLACE (and returned); infos are views of reused device buffers."""
         _maybe_upload(eng, vector_field_param)
@@ -233,6 +235,8 @@ def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
             conditional_importance_sampling(rng_key, beta, pos, logp)
         elif do_flow:
             eng.ctx.flow_step(mode, rng_key, beta, pos, logp, grad, info["acc"], info["isacc"], info["prop"], info["nsteps"])
+        elif use_hmc:          # build-side mode (--mcmc_kernel hmc): the iteration's MCMC move is an HMC step (mfm_hmc_step) instead of :313
+            eng.ctx.hmc_step(rng_key, beta, args.step_size, int(args.hmc_steps), pos, logp, grad, info["acc"], info["isacc"])
         else:
             eng.ctx.mala_step(rng_key, beta, args.step_size, pos, logp, grad, info["acc"], info["isacc"], info["prop"], info["w"])
         return MALAState(pos, logp, grad), MALAInfo(info["acc"], info["isacc"], info["prop"], info["w"])
@@ -248,7 +252,7 @@ def create_train_data_gn(dist, vector_field_apply, ode_integrator, args):
     train_data_generator.info_buffers = info
     # what run() needs to issue generator + train_step as ONE library call (mfm_train_iter) where that is the same computation
     train_data_generator.flow_mode = mode
-    train_data_generator.one_call_ok = n_is <= 0 and args.mcmc_per_flow_steps >= 1 and float(args.mcmc_per_flow_steps).is_integer()
+    train_data_generator.one_call_ok = n_is <= 0 and args.mcmc_per_flow_steps >= 1 and float(args.mcmc_per_flow_steps).is_integer() and not use_hmc
     return train_data_generator, init_fn, transform_and_logdet
 
 

@@ -151,6 +151,10 @@ def build_parser():
     # Dopri5 of jax.experimental.ode.odeint, exe_flow_matching.py:345-349, which stays the default): --ode_method rk4 --ode_steps 64
     parser.add_argument('--ode_method', type=str, default='dopri5', choices=['dopri5', 'rk4', 'euler'])
     parser.add_argument('--ode_steps', type=int, default=0)
+    # the MCMC move of a non-flow iteration: the reference's MALA step (exe_flow_matching.py:313), or -- BASELINE.json's "MALA/HMC" step,
+    # not in the reference -- an HMC step of --hmc_steps velocity-Verlet steps of size --step_size (mfm_amd/bblackjax/mcmc/hmc.py)
+    parser.add_argument('--mcmc_kernel', type=str, default='mala', choices=['mala', 'hmc'])
+    parser.add_argument('--hmc_steps', type=int, default=10)
     return parser
 
 

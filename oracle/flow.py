@@ -128,6 +128,10 @@ def train_data_generator(key, states, count, model, params, dist, args, beta=1.0
     if do_flow:
         step = cis_step if args.num_importance_samples > 0 else imh_step if args.num_importance_samples < 0 else rwmh_step   # :298
         return step(keys, states, vg, model, params, args, stats)
+    if getattr(args, "mcmc_kernel", "mala") == "hmc":       # build-side mode (oracle/hmc.py), not in the reference
+        from . import hmc
+        st, hi, _ = hmc.kernel(keys, states, vg, args.step_size, int(args.hmc_steps))
+        return st, MALAInfo(hi.acceptance_rate, hi.is_accepted, hi.proposed_position, np.zeros_like(hi.acceptance_rate))
     st, info, _ = mala.kernel(keys, states, vg, args.step_size)                                    # :313
     return st, info
 

@@ -22,7 +22,8 @@ def default_args(**kw):
              eval_iter=100, alpha=0.95, anneal_iter=200, num_anneal_temp=200, non_linearity="relu",
              hidden_x=[128, 128], hidden_t=[128, 128], hidden_xt=[128, 128], step_size=0.2,
              learning_rate=1e-3, weight_decay=1e-4, adam_beta1=0.9, adam_beta2=0.999,
-             adam_epsilon=1e-8, gradient_clip=1.0, warmup_steps=0, rtol=1e-5, atol=1e-5, mxstep=1000.0)
+             adam_epsilon=1e-8, gradient_clip=1.0, warmup_steps=0, rtol=1e-5, atol=1e-5, mxstep=1000.0,
+             mcmc_kernel="mala", hmc_steps=10)      # (the last two: build-side mode, mfm_amd/multi_modal.py)
     a.update(kw)
     ns = SimpleNamespace(**a)
     ns.n_ts = 5 if ns.example == "4-mode" else 2          # exe_flow_matching.py:347
