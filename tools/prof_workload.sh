@@ -1,14 +1,11 @@
 #!/bin/bash
-# rocprofv3 evidence for a non-headline bench workload: kernel trace + stats, then the HBM-traffic PMC passes (separate runs, no
-# trace domains besides --kernel-trace).  usage (on the GPU box): tools/prof_workload.sh WORKLOAD [TAG] [STEPS WARMUP for the PMC passes]
+# rocprofv3 evidence for a non-headline bench workload: the HBM-traffic PMC passes (separate runs, no trace domains besides
+# --kernel-trace), then kernel trace + stats.  usage (on the GPU box): tools/prof_workload.sh WORKLOAD [TAG] [STEPS WARMUP for the PMC passes]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 WL=$1; TAG=${2:-r02}; PS=${3:-101}; PW=${4:-101}
 OUT=$R/gpurun_out/prof_${WL}_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --workload $WL --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
-echo "trace done"; head -8 $OUT/kernel_stats.csv | cut -c1-160
 i=0
 for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
@@ -55,3 +52,10 @@ for k, cs in sorted(res.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", {}).get
     if k.startswith("_"): continue
     print(k, {c: "%.4g" % v["mean_per_launch"] for c, v in cs.items()})
 PY
+# the PMC summary goes into profiles/ BEFORE the traced run, whose JSON line quotes `traffic` from that committed file
+case $WL in 4-mode) SHORT=4mode;; gaussian-mixture) SHORT=gmm;; *) SHORT=$WL;; esac
+cp $OUT/pmc_summary.json $R/profiles/${TAG}_${SHORT}_pmc_summary.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --workload $WL --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+echo "trace done"; head -8 $OUT/kernel_stats.csv | cut -c1-160
+cp $OUT/kernel_stats.csv $R/gpurun_out/${TAG}_${SHORT}_kernel_stats.csv; cp $OUT/bench_under_rocprof.json $R/gpurun_out/${TAG}_${SHORT}_bench_under_rocprof.json; cp $OUT/pmc_summary.json $R/gpurun_out/${TAG}_${SHORT}_pmc_summary.json
