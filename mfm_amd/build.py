@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libmfm_hip.so")
 SOURCES = ["api.hip"]          # unity build: api.hip includes the kernel translation units
-SCHED_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-kernarg-preload-count=8"]
+SCHED_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-kernarg-preload-count=12"]
 
 
 def _stale():
@@ -28,6 +28,9 @@ def build(force=False, verbose=False):
     # the default strategy's register-pressure heuristics to win; measured on the same chain states (tools/flow_ab.py): flow step
     # 48.68 -> 46.04 ms, bench 7.56 -> 7.90 M chain-steps/s (0.710 -> 0.748 of the MFMA peak); the other workloads within +-0.7 %
     # (tools/dbg/ab_workloads.sh).  Same arithmetic: attempt counts and results are unchanged.
+    # -amdgpu-kernarg-preload-count: scalar kernel arguments at the head of the list arrive in SGPRs with the wave instead of through a read
+    # of the argument segment; wgrad_sk and the training kernel repeat the pointers of their first loads there (tools/dbg/ab_iter.sh on one
+    # box: iteration 78.4 -> 77.8 us).  Same fallback as the scheduling strategy.
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
     tail = ["-o", LIB] + SOURCES
     cmd = base + SCHED_FLAGS + tail

@@ -112,8 +112,13 @@ __device__ __forceinline__ float target_gclip(const NetDev& n, const float* xbuf
 // MALA: the workgroup first advances its 16 chains by one MALA step (two chains per wave, mala_chain_step: the arithmetic of
 // mala_step_kernel, bit for bit) and builds the batch from the new positions left in LDS -- one launch less per iteration, and
 // the positions do not travel through HBM between the two.
+// The six leading pointer arguments repeat fields of `a` (first layer's packed weights; position, gradient, prefetched MALA draws,
+// log-density and prefetched uniforms of the chains): scalar arguments at the head of the list are preloaded into SGPRs (-amdgpu-kernarg-preload-count,
+// mfm_amd/build.py), so the first loads of the prologue -- the weight prefetch and the MALA step's -- go out before the read of the
+// 850-byte argument struct has returned.
 template <int TPW, bool TRAIN, bool STATIC = false, int ACT = -1, bool MALA = false>      // ACT >= 0: the activation as a compile-time constant (the five-way
-__global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs a) {      // run-time selection in every epilogue triples the code)
+__global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(const float* pl_w0, const float* pl_pos, const float* pl_grad, const draw_t* pl_pren,
+                                                                         const double* pl_logp, const double* pl_preu, FmArgs a) {      // run-time selection in every epilogue triples the code)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   NetDev nloc = a.net;
   if constexpr (ACT >= 0) nloc.act = ACT;
@@ -128,6 +133,16 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
   const NetDev& n = nloc;
   const FmLds L = fm_lds_layout(n, TRAIN);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
+  WChain wch; wch.have = false;
+  if constexpr (STATIC) {      // the first tile's first fragment group: requested before everything else -- from a preloaded pointer,
+                               // ahead of the first read of the argument struct --, it arrives under the prologue
+    const __amdgpu_buffer_rsrc_t w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pl_w0) + (size_t)wave * (n.L[0].Kp / 16) * 256, 0,
+                                                                        (n.L[0].Kp / 16) * 1024, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wch.b[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w0, lane * 16, u * 1024, 0));
+    wch.have = true;
+  }
+  __builtin_amdgcn_sched_barrier(0);
   const int bb = blockIdx.x, b0 = bb * 16, nbb = a.B / 16;
   const int d = n.d;
 
@@ -144,14 +159,6 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     store_packed(base, tile_row, nbb, bb, lane, v);
     sq_acc = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[3], v[3], sq_acc))));
   };
-  WChain wch; wch.have = false;
-  if constexpr (STATIC) {      // the first tile's first fragment group: requested before everything else, it arrives under the prologue
-    const __amdgpu_buffer_rsrc_t w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(n.Wp + n.L[0].w_off) + (size_t)wave * (n.L[0].Kp / 16) * 256, 0,
-                                                                        (n.L[0].Kp / 16) * 1024, 0x00020000);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) wch.b[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w0, lane * 16, u * 1024, 0));
-    wch.have = true;
-  }
   FM_STAMP(0);
   // ---------------- prologue: K3 batch construction (exe_flow_matching.py:151-169 / :139-147) ----------------
   // draws produced ahead of time (noise.hip): every load of the tile is issued in one go, well before the first use (behind the
@@ -248,9 +255,9 @@ __global__ __launch_bounds__((MLP_WAVES_FM * 64)) void fm_fwd_bwd_kernel(FmArgs 
     MalaArgs m;
     m.T = n.T; m.T.dim = d; m.key = a.mala.key; m.keys = nullptr; m.n_total = a.n_total; m.chain_offset = a.chain_offset; m.B = a.B;
     m.beta = a.mala.beta; m.eps = a.mala.eps; m.textbook = a.mala.textbook;
-    m.pos = const_cast<float*>(a.pos); m.logp = a.mala.logp; m.grad = a.mala.grad;
+    m.pos = const_cast<float*>(pl_pos); m.logp = const_cast<double*>(pl_logp); m.grad = const_cast<float*>(pl_grad);
     m.acc_prob = a.mala.acc_prob; m.accepted = nullptr; m.proposed = nullptr; m.prop_weight = nullptr;
-    m.pre_n = a.mala.pre_n; m.pre_u = a.mala.pre_u;
+    m.pre_n = pl_pren; m.pre_u = pl_preu;
     const int bs[2] = {b0 + wave, b0 + wave + 8};
     float* const xs[2] = {bDV + wave * L.lddv + 4, bDV + (wave + 8) * L.lddv + 4};
     float* const gsm[2] = {gcs + wave * 8, gcs + (wave + 8) * 8};
@@ -1040,13 +1047,13 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
 #define FM_LAUNCH_A(T, TR, ACT_)                                                                           \
   do {                                                                                                     \
     (void)hipFuncSetAttribute((const void*)fm_fwd_bwd_kernel<T, TR, false, ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-    hipLaunchKernelGGL((fm_fwd_bwd_kernel<T, TR, false, ACT_>), grid, block, sm, stream, a);              \
+    hipLaunchKernelGGL((fm_fwd_bwd_kernel<T, TR, false, ACT_>), grid, block, sm, stream, a.net.Wp + a.net.L[0].w_off, a.pos, a.mala.grad, a.mala.pre_n, a.mala.logp, a.mala.pre_u, a);              \
   } while (0)
 #define FM_LAUNCH(T, TR) do { if (a.net.act == MFM_ACT_RELU) FM_LAUNCH_A(T, TR, MFM_ACT_RELU); else FM_LAUNCH_A(T, TR, -1); } while (0)
 #define FM_LAUNCH_M(T, STATIC_, ACT_)                                                                      \
   do {                                                                                                     \
     (void)hipFuncSetAttribute((const void*)fm_fwd_bwd_kernel<T, true, STATIC_, ACT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-    hipLaunchKernelGGL((fm_fwd_bwd_kernel<T, true, STATIC_, ACT_, true>), grid, block, sm, stream, a);    \
+    hipLaunchKernelGGL((fm_fwd_bwd_kernel<T, true, STATIC_, ACT_, true>), grid, block, sm, stream, a.net.Wp + a.net.L[0].w_off, a.pos, a.mala.grad, a.mala.pre_n, a.mala.logp, a.mala.pre_u, a);    \
   } while (0)
   const NetDev& n = a.net;
   bool headline = n.d == 256 && n.dp == 256 && n.F == 128 && n.F2p == 256 && n.ht1 == 128 && n.ht2 == 128 && n.hx1 == 128 &&
@@ -1056,7 +1063,7 @@ int launch_fm(const FmArgs& a, bool train, hipStream_t stream) {
 #define FM_LAUNCH_S(TR)                                                                                    \
   do {                                                                                                     \
     (void)hipFuncSetAttribute((const void*)fm_fwd_bwd_kernel<2, TR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-    hipLaunchKernelGGL((fm_fwd_bwd_kernel<2, TR, true>), grid, block, sm, stream, a);                     \
+    hipLaunchKernelGGL((fm_fwd_bwd_kernel<2, TR, true>), grid, block, sm, stream, a.net.Wp + a.net.L[0].w_off, a.pos, a.mala.grad, a.mala.pre_n, a.mala.logp, a.mala.pre_u, a);                     \
   } while (0)
   if (a.mala.on) {      // the iteration's MALA step in the same launch (callers ask fm_mala_fusable first)
     if (!train || !fm_mala_fusable(n)) return -3;

@@ -134,7 +134,7 @@ __device__ __forceinline__ WskElem wsk_decode(const NetDev& n, const WskJob& J, 
 }
 
 // The first six arguments repeat fields of `a`: scalar arguments at the head of the argument list are PRELOADED into SGPRs by the
-// command processor (-mllvm -amdgpu-kernarg-preload-count=8, mfm_amd/build.py), so the unit-range lookup and the first fetches of the
+// command processor (-mllvm -amdgpu-kernarg-preload-count, mfm_amd/build.py), so the unit-range lookup and the first fetches of the
 // ring do not wait for a read of the kernel-argument segment first (three dependent scalar-load round trips in the by-value form:
 // xcd flag -> G -> pointers; tools/wsk_stamps.py: 3.6 us from the workgroup's start to the ring's last prime fetch).  On a stack
 // without the preload the compiler's compatibility prologue loads them the usual way.
