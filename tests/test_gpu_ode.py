@@ -44,7 +44,7 @@ def test_ode_transform_and_inverse_match_oracle(d, hidden, F):
         assert np.abs(y - y_o).max() < 2e-3 * max(1.0, np.abs(y_o).max()), np.abs(y - y_o).max()
         assert np.abs(y - y_o).mean() < 1e-4, np.abs(y - y_o).mean()
         # the Hutchinson log-det integrates z.(Jz) of a piecewise-linear field: it is the least accurate component
-        # of BOTH solvers (the oracle itself is ~3e-2 from a rtol=1e-8 solve on this setup, tools/debug_ode.py)
+        # of BOTH solvers (the oracle itself is ~3e-2 from a rtol=1e-8 solve on this setup, tools/dbg/debug_ode.py)
         assert np.abs(l - l_o).max() < 5e-2 * max(1.0, np.abs(l_o).max()), (np.abs(l - l_o).max(), np.abs(l_o).max())
         assert np.abs(l - l_o).mean() < 1e-2 * max(1.0, np.abs(l_o).max())
         # own controllers: a float32 and a float64 error norm round differently near ratio = 1 and at ReLU kinks, so individual

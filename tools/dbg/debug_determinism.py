@@ -1,6 +1,6 @@
 """Development aid: run-to-run determinism of the phi-four loop (generic solver shape) and of the headline shape."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests.test_gpu_loop import _args
 from mfm_amd import distributions as D, exe_flow_matching as E
