@@ -1,6 +1,6 @@
 """Development aid: shape-specialised solver (ode_fast.hip) vs the generic solver tile on the same inputs."""
 import sys, os, subprocess
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from oracle import prng

@@ -1,7 +1,7 @@
 """Per-chain differences of the flow step on a prescribed step sequence (development aid for the tail modes of fast::solve2)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import prng
 from tests import gpu_util as gu
