@@ -112,15 +112,30 @@ class CRef:
         assert self.lib.mfmref_fm_loss_grad(C.byref(self._net), _p(cond), _p(target), _p(t), cond.shape[0], C.byref(loss), _p(g)) == 0
         return loss.value, unflat_params(self.model, g)
 
-    # ode.transform_and_logdet (sign = +1) / inverse_and_logdet (-1), Hutchinson probes z [B, d] given, one output time (t = 1)
-    def solve(self, x0, z, sign, rtol, atol, mxstep, stats=None):
+    # ode.transform_and_logdet (sign = +1) / inverse_and_logdet (-1), Hutchinson probes z [B, d] given, one output time (t = 1).
+    # replay = dict(dt=[B, cap], acc=[B, cap]): the prescribed step sequence of ode.odeint's parity instrumentation; record = cap: the
+    # chain's own sequence into stats["dt_seq"] [B, cap] / stats["acc_seq"] [B, cap] (zero past its last attempt), as ode.odeint records it
+    def solve(self, x0, z, sign, rtol, atol, mxstep, stats=None, replay=None, record=0):
         x0, z = _f64(x0), _f64(z); B = x0.shape[0]
         xo, ldj, natt = np.empty_like(x0), np.empty(B), np.empty(B, dtype=np.int64)
         nev = C.c_longlong(0)
+        rp_dt = rp_acc = rec_dt = rec_acc = None
+        cap = 0
+        if replay is not None:
+            rp_dt = _f64(replay["dt"]); cap = rp_dt.shape[1]
+            acc_in = np.asarray(replay["acc"]).astype(np.uint8)          # (numpy's sequences: A + 1 step sizes, A decisions)
+            rp_acc = np.zeros((B, cap), dtype=np.uint8); rp_acc[:, :min(cap, acc_in.shape[1])] = acc_in[:, :cap]
+            assert rp_dt.shape == (B, cap)
+        elif record:
+            cap = int(record)
+            rec_dt = np.zeros((B, cap)); rec_acc = np.zeros((B, cap), dtype=np.uint8)
         assert self.lib.mfmref_cnf_solve(C.byref(self._net), _p(x0), _p(z), int(sign), C.c_double(rtol), C.c_double(atol), int(mxstep), B,
-                                         _p(xo), _p(ldj), _p(natt), C.byref(nev)) == 0
+                                         _p(xo), _p(ldj), _p(natt), C.byref(nev), _p(rp_dt), _p(rp_acc), _p(rec_dt), _p(rec_acc), cap) == 0
         if stats is not None:
             stats["n_attempted"], stats["n_evals_total"] = natt, int(nev.value)
+            if rec_dt is not None:
+                assert natt.max() < cap, "record capacity too small"
+                stats["dt_seq"], stats["acc_seq"] = rec_dt, rec_acc.astype(bool)
         return xo, ldj
 
     # mala.kernel: one key per chain (mala.py:93 key_integrator, key_rmh), draws by oracle/prng.py, arithmetic in C
@@ -132,14 +147,16 @@ class CRef:
         return st, MALAInfo(p, acc, None, None)
 
     # flow.rwmh_step (exe_flow_matching.py:264-278): keys and draws by oracle/prng.py, the two CNF solves and the target in C
-    def rwmh_step(self, keys, prev, args, temper=1.0, stats=None):
+    def rwmh_step(self, keys, prev, args, temper=1.0, stats=None, replay=None, record=0):
+        """``replay = dict(inv=..., fwd=...)`` / ``record``: see ``solve`` (``stats["inv"]`` / ``stats["fwd"]`` carry the recorded sequences)."""
         d = self.d
         kk = prng.split_rows(keys, 4)                                # :265 key_gen, key_acc, key_hutch1, key_hutch2
         o = (args.rtol, args.atol, args.mxstep)
         si, sf = {}, {}
-        u0, vol0 = self.solve(prev.position, prng.normal_rows(kk[:, 3], d), -1, *o, stats=si)            # :267
+        rp = replay or {}
+        u0, vol0 = self.solve(prev.position, prng.normal_rows(kk[:, 3], d), -1, *o, stats=si, replay=rp.get("inv"), record=record)     # :267
         up = u0 + (2.38 / np.sqrt(d)) * prng.normal_rows(kk[:, 0], d)                                   # :262,268
-        xp, volp = self.solve(up, prng.normal_rows(kk[:, 2], d), +1, *o, stats=sf)                     # :269
+        xp, volp = self.solve(up, prng.normal_rows(kk[:, 2], d), +1, *o, stats=sf, replay=rp.get("fwd"), record=record)              # :269
         lpn, gn = self.value_and_grad(xp, temper)                                                       # :270
         with np.errstate(over="ignore", invalid="ignore"):
             a = np.exp(lpn - volp - prev.logdensity - vol0)                                             # :271-274
@@ -147,6 +164,6 @@ class CRef:
         m = acc[:, None]
         if stats is not None:
             stats.update(n_att_inv=si["n_attempted"], n_att_fwd=sf["n_attempted"], u0=u0, vol0=vol0, up=up, volp=volp,
-                         log_alpha=lpn - volp - prev.logdensity - vol0)
+                         log_alpha=lpn - volp - prev.logdensity - vol0, inv=si, fwd=sf)
         state = MALAState(np.where(m, xp, prev.position), np.where(acc, lpn, prev.logdensity), np.where(m, gn, prev.logdensity_grad))
         return state, MALAInfo(a, acc, xp, np.zeros_like(a))

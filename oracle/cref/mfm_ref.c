@@ -362,7 +362,11 @@ static void rhs(rhs_t* R, const double* y, double t, double* out) {
 static double norm2(const double* a, const double* scale, int n) { double s = 0.0; for (int i = 0; i < n; ++i) { const double q = a[i] / scale[i]; s += q * q; } return sqrt(s); }
 
 /* one chain: y0 = (x0, 0) at t = 0 to t = 1; returns the attempted-step count */
-static long long solve_chain(rhs_t* R, const double* x0, double rtol, double atol, int mxstep, double* xout, double* ldj) {
+/* rp_dt / rp_acc (replay, PARITY INSTRUMENTATION as in oracle/ode.py: odeint): the solve takes the prescribed step sizes [cap] and accept
+ * decisions [cap] instead of its controller's.  rec_dt / rec_acc (record): rec_dt[0] = the initial step, rec_dt[j + 1] = the step size
+ * after attempt j (0 once the chain has reached the end), rec_acc[j] = attempt j accepted -- the `dt_seq` / `acc_seq` of oracle/ode.py. */
+static long long solve_chain(rhs_t* R, const double* x0, double rtol, double atol, int mxstep, double* xout, double* ldj,
+                             const double* rp_dt, const unsigned char* rp_acc, double* rec_dt, unsigned char* rec_acc, int cap) {
   const int d = R->N->d, n = d + 1;
   double* mem = (double*)malloc(sizeof(double) * n * 24);
   double *y = mem, *f = mem + n, *y1 = mem + 2 * n, *err = mem + 3 * n, *yi = mem + 4 * n, *scale = mem + 5 * n, *tmp = mem + 6 * n;
@@ -383,6 +387,8 @@ static long long solve_chain(rhs_t* R, const double* x0, double rtol, double ato
   const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
   double dt = fmin(100.0 * h0, h1);
   if (!(dt >= 0.0) && !isnan(dt)) dt = 0.0;
+  if (rp_dt) dt = rp_dt[0];
+  if (rec_dt) rec_dt[0] = dt;
   double last_t = t;
   for (int c = 0; c < 5; ++c) memcpy(co[c], y, sizeof(double) * n);
   long long natt = 0;
@@ -418,11 +424,19 @@ static long long solve_chain(rhs_t* R, const double* x0, double rtol, double ato
       ndt = isnan(fr) ? NAN : dt * fmin(10.0, fmax(fr, dfac));
     }
     if (!isnan(ndt) && ndt < 0.0) ndt = 0.0;
-    if (ratio <= 1.0) {                                     /* accept (NaN: reject) */
+    int accept = ratio <= 1.0;                              /* (NaN: reject) */
+    if (rp_dt) {
+      const long long j = natt < cap - 1 ? natt : cap - 1, j1 = natt + 1 < cap - 1 ? natt + 1 : cap - 1;
+      accept = rp_acc[j] != 0; ndt = rp_dt[j1];
+    }
+    if (accept) {
       for (int c = 0; c < 5; ++c) memcpy(co[c], nco[c], sizeof(double) * n);
       last_t = t; memcpy(y, y1, sizeof(double) * n); memcpy(f, k[6], sizeof(double) * n); t = t + dt;
     }
-    dt = ndt; ++natt;
+    dt = ndt;
+    if (rec_acc && natt < cap) rec_acc[natt] = (unsigned char)accept;
+    if (rec_dt && natt + 1 < cap) rec_dt[natt + 1] = t < 1.0 ? dt : 0.0;
+    ++natt;
   }
   const double s = (1.0 - last_t) / (t - last_t);          /* value at the output time: the last accepted step's 4th-order interpolant */
   for (int i = 0; i < n; ++i) { const double o = (((co[0][i] * s + co[1][i]) * s + co[2][i]) * s + co[3][i]) * s + co[4][i]; if (i < d) xout[i] = o; else *ldj = o; }
@@ -432,7 +446,8 @@ static long long solve_chain(rhs_t* R, const double* x0, double rtol, double ato
 
 /* sign = +1: transform_and_logdet (:206-221); sign = -1: inverse_and_logdet (:223-242).  z [B][d]: the Hutchinson probes. */
 int mfmref_cnf_solve(const mfmref_net* N, const double* x0, const double* z, int sign, double rtol, double atol, int mxstep, int B,
-                     double* xout, double* ldj, long long* n_att, long long* n_evals) {
+                     double* xout, double* ldj, long long* n_att, long long* n_evals,
+                     const double* rp_dt, const unsigned char* rp_acc, double* rec_dt, unsigned char* rec_acc, int cap) {
   netd P; if (net_build(N, &P)) return -1;
   const int d = N->d;
   long long ev = 0;
@@ -443,7 +458,9 @@ int mfmref_cnf_solve(const mfmref_net* N, const double* x0, const double* z, int
 #pragma omp for schedule(dynamic, 1)
     for (int b = 0; b < B; ++b) {
       rhs_t R = {N, &P, &w, z + (size_t)b * d, sign, v, v + d, 0};
-      n_att[b] = solve_chain(&R, x0 + (size_t)b * d, rtol, atol, mxstep, xout + (size_t)b * d, ldj + b);
+      n_att[b] = solve_chain(&R, x0 + (size_t)b * d, rtol, atol, mxstep, xout + (size_t)b * d, ldj + b,
+                             rp_dt ? rp_dt + (size_t)b * cap : NULL, rp_acc ? rp_acc + (size_t)b * cap : NULL,
+                             rec_dt ? rec_dt + (size_t)b * cap : NULL, rec_acc ? rec_acc + (size_t)b * cap : NULL, cap);
       ev += R.evals;
     }
     free(v);

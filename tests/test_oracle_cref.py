@@ -128,3 +128,29 @@ def test_keyed_mala_kernel_and_flow_mh_step_equal_the_numpy_restatement():
     assert np.abs(sc["log_alpha"] - so["log_alpha"]).max() < 1e-7 * max(1.0, np.abs(so["log_alpha"]).max())
     assert (ic.is_accepted == io.is_accepted).all()
     assert _rel(fc.position, fo.position) < 1e-9 and _rel(fc.logdensity, fo.logdensity) < 1e-9
+
+
+def test_recorded_step_sequences_and_their_replay_equal_the_numpy_restatement():
+    """ode.odeint's parity instrumentation in C: the recorded step sequence of a natural solve equals numpy's (float64 step sizes to rounding,
+    decisions exactly), and replaying a float32-rounded sequence gives numpy's replayed result."""
+    args, dist, model, params, cr = _setup(64, 12, hidden=32, F=16)
+    params = gu.rand_params(model, seed=4, scale=1.0, out_scale=0.3)
+    gl = model.zero_layers()[0]
+    params[gl]["kernel"] *= np.float32(1e-3 / 0.3); params[gl]["bias"] *= np.float32(1e-3)
+    cr.set_params(params)
+    rng = np.random.default_rng(3)
+    x0, z = rng.uniform(-1, 1, (12, 64)), rng.standard_normal((12, 64))
+    st, sc = {}, {}
+    ode.transform_and_logdet(model, params, None, x0, True, 1e-5, 1e-5, 1000, z=z, stats=st)
+    cr.solve(x0, z, +1, 1e-5, 1e-5, 1000, stats=sc, record=64)
+    A = st["acc_seq"].shape[1]
+    np.testing.assert_array_equal(sc["acc_seq"][:, :A], st["acc_seq"])
+    assert not sc["acc_seq"][:, A:].any()
+    np.testing.assert_allclose(sc["dt_seq"][:, :A + 1], st["dt_seq"], rtol=1e-7, atol=0)      # (the controller amplifies the rounding of the error norm: measured 4e-9)
+    rp = dict(dt=st["dt_seq"].astype(np.float32).astype(np.float64), acc=st["acc_seq"])
+    so = {}
+    xo, lo = ode.transform_and_logdet(model, params, None, x0, True, 1e-5, 1e-5, 1000, z=z, stats=so, replay=rp)
+    s2 = {}
+    xc, lc = cr.solve(x0, z, +1, 1e-5, 1e-5, 1000, stats=s2, replay=rp)
+    assert (s2["n_attempted"] == so["n_attempted"]).all()
+    assert np.abs(xc - xo).max() < 1e-11 and np.abs(lc - lo).max() < 1e-10
