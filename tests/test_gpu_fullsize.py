@@ -225,6 +225,9 @@ def test_static_training_kernel_equals_the_runtime_shape_kernel(monkeypatch):
     ctx.close()
 
 
+_NATURAL = {}
+
+
 def test_headline_flow_step_all_4096_chains_against_libmfm_ref(trained_phi4):
     """The WHOLE benchmarked launch against the oracle, live: phi-four d = 256, all 4096 chains and the network bench.py's timed region starts
     from (one trained cycle), one flow-MH step with each side's own controllers -- the float32 kernel through the C ABI, and libmfm_ref
@@ -260,7 +263,8 @@ def test_headline_flow_step_all_4096_chains_against_libmfm_ref(trained_phi4):
     vg = targets.Tempered(dist, 1.0).value_and_grad
     st0 = mala.init(x32.astype(np.float64), vg)
     so = {}
-    st1, info = cr.rwmh_step(prng.split(key, B), st0, args, stats=so)
+    st1, info = cr.rwmh_step(prng.split(key, B), st0, args, stats=so, record=1001)
+    _NATURAL["run"] = (key, st0, so)                  # (the prescribed-step test below replays this run's step sequences)
     n_o = so["n_att_inv"] + so["n_att_fwd"]
     la_o = so["log_alpha"]
     qs = [0.1, 0.5, 0.9, 0.99]
@@ -365,15 +369,18 @@ def test_headline_flow_step_all_4096_chains_on_prescribed_steps_against_libmfm_r
     dist, model, args = tp["dist"], tp["model"], tp["args32"]
     params = gu.unflat_params(model, tp["params_flat"])
     x32 = tp["pos"]
-    key = prng.PRNGKey(777)
     ctx = gu.make_ctx(dist, args, n_local=B, n_total=B, fourier=model.f, params=params)
     pos = _dev(x32); logp = torch.empty(B, dtype=torch.float64, device="cuda"); grad = torch.empty(B, d, device="cuda")
     ctx.mala_init(pos, 1.0, logp, grad)
-    st0 = mala.MALAState(x32.astype(np.float64), logp.cpu().numpy(), grad.cpu().numpy().astype(np.float64))
     cr = cref.CRef(model, params)
+    if "run" in _NATURAL:                              # the natural run of the test above (same state, same key): its recorded sequences
+        key, st0, nat = _NATURAL["run"]
+    else:
+        key = prng.PRNGKey(4242)
+        st0 = mala.init(x32.astype(np.float64), targets.Tempered(dist, 1.0).value_and_grad)
+        nat = {}
+        cr.rwmh_step(prng.split(key, B), st0, args, stats=nat, record=1001)
     keys = prng.split(key, B)
-    nat = {}
-    cr.rwmh_step(keys, st0, args, stats=nat, record=1001)
     amax = int(max(nat["n_att_inv"].max(), nat["n_att_fwd"].max()))
     cap = amax + 2
     dt = np.zeros((2, B, cap), np.float32); acc = np.zeros((2, B, cap), np.uint8)
